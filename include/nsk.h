@@ -1,0 +1,143 @@
+/*
+ * nsk.h — C ABI of the MI355X-native velocity-pressure linear-solve path.
+ *
+ * Drop-in boundary for what the reference does inside
+ *   int NSSolverStationary::solve_system()   lab_new/src/NSSolverStationary.cpp:579-647
+ *   int NSSolver::solve_system()             lab_new/src/NSSolver.cpp:601-672
+ * i.e. "build PreconditionBlockDiagonal / BlockTriangular / aSIMPLE from blocks of
+ * jacobian_matrix and pressure_mass, run SolverGMRES / SolverFGMRES / SolverBicgstab
+ * on (jacobian_matrix, delta_owned, residual_vector), return last_step()".
+ *
+ * The reference has no FFI layer (duck-typed C++ templates over deal.II/Trilinos
+ * objects); these entry points are what a binding on the reference side would call
+ * with the raw arrays of its Epetra objects (INTEGRATION.md shows that stub):
+ *   jacobian_matrix.block(i,j).trilinos_matrix().ExtractCrsDataPointers(rowptr,col,val)
+ *   ColMap().MyGlobalElements()  -> ghost ids,  Importer() -> halo plan
+ *   residual_vector.block(b).trilinos_vector()[0] -> contiguous owned f64
+ *
+ * Conventions: plain pointers and sizes only; host pointers are caller-owned and only
+ * read/written during the call; the library owns all device memory; one opaque handle
+ * per rank/GPU; calls on one handle are not thread-safe; collective calls
+ * (nsk_setup_preconditioner, nsk_solve*, nsk_spmv with nranks > 1) must be entered by
+ * all ranks.  No exception crosses this ABI.
+ *
+ * Return codes: 0 success; 1 outer solver not converged (iters/final_res still valid —
+ * the reference would throw SolverControl::NoConvergence); 2 BiCGStab breakdown
+ * restarts exhausted; 3 an inner (preconditioner) solver did not converge;
+ * < 0 usage / HIP / RCCL error, text via nsk_last_error().
+ */
+#ifndef NSK_H
+#define NSK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nsk_handle_s *nsk_handle;
+
+/* matrix blocks of the hand-off */
+enum {
+  NSK_BLK_F = 0,        /* jacobian_matrix.block(0,0)            NSSolverStationary.cpp:584,602,622 */
+  NSK_BLK_BT = 1,       /* jacobian_matrix.block(0,1)            NSSolverStationary.cpp:624         */
+  NSK_BLK_B = 2,        /* jacobian_matrix.block(1,0)            NSSolverStationary.cpp:604,623     */
+  NSK_BLK_MP = 3,       /* pressure_mass.block(1,1)              NSSolverStationary.cpp:585,603     */
+  NSK_BLK_BT_GHOST = 4, /* rows of block(0,1) for this rank's ghost velocity DoFs: what EpetraExt's
+                           MatrixMatrix::Multiply imports for mmult (NSSolverStationary.hpp:275);
+                           only needed when nranks > 1 and the preconditioner is aSIMPLE */
+  NSK_BLK_S = 5         /* Schur approximation B diag(F)^-1 B^T (read-only, built by the library) */
+};
+enum { NSK_SPACE_U = 0, NSK_SPACE_P = 1 };
+enum { NSK_SOLVER_GMRES = 0, NSK_SOLVER_FGMRES = 1, NSK_SOLVER_BICGSTAB = 2 };          /* -s */
+enum { NSK_PREC_BLOCK_DIAGONAL = 0, NSK_PREC_BLOCK_TRIANGULAR = 1, NSK_PREC_ASIMPLE = 2 }; /* -p */
+enum { NSK_VARIANT_STATIONARY = 0, NSK_VARIANT_UNSTEADY = 1 };
+/* which triangular preconditioner object */
+enum { NSK_TRI_VELOCITY = 0, NSK_TRI_PRESSURE = 1 };
+
+/* options (nsk_set_option) */
+enum {
+  NSK_OPT_TRI_ORDERING = 0, /* 0 natural (default), 1 rank-local multicolour permutation */
+  NSK_OPT_SUBDOMAINS = 1,   /* emulated MPI ranks per GPU for the block-Jacobi ILU/SGS (default 1) */
+  NSK_OPT_FUSE_BLOCK_ROW = 2 /* 1 (default): F x_u + Bt x_p in one kernel */
+};
+
+typedef struct {
+  double setup_ms, solve_ms;
+  int64_t outer_iters, inner_u_its, inner_p_its, prec_applies, spmv_calls, tri_applies, reductions, host_syncs;
+  double spmv_bytes, tri_bytes, blas1_bytes; /* algorithmic bytes moved (SURVEY 8d formulas) */
+  int32_t n_colors_u, n_levels_u, n_colors_p, n_levels_p;
+  int64_t nnz_s;
+} nsk_stats;
+
+/* 128-byte RCCL unique id, produced on rank 0 and distributed by the caller (e.g. MPI_Bcast). */
+int nsk_get_unique_id(void *out128);
+
+/* One handle per rank.  unique_id may be NULL when nranks == 1. */
+nsk_handle nsk_create(int rank, int nranks, int device_id, const void *rccl_unique_id);
+void nsk_destroy(nsk_handle h);
+const char *nsk_last_error(nsk_handle h);
+
+/* Row partition of one block space: owned global range and ghost global ids (ColMap order). */
+int nsk_set_partition(nsk_handle h, int space, int64_t owned_begin, int64_t owned_end, int n_ghost,
+                      const int32_t *ghost_gids);
+/* Halo plan of one space (what Epetra_Import holds): for neighbour k, send owned local ids
+ * send_idx[send_ptr[k]..send_ptr[k+1]) and receive ghost slots [recv_ptr[k], recv_ptr[k+1]). */
+int nsk_set_halo_plan(nsk_handle h, int space, int n_neighbors, const int32_t *peer_rank, const int32_t *send_ptr,
+                      const int32_t *send_idx, const int32_t *recv_ptr);
+
+/* Local CSR block: int32 local column ids (owned first, ghosts appended), f64 values.
+ * The pattern is fixed for the run (jacobian_matrix.reinit(sparsity), NSSolverStationary.cpp:304). */
+int nsk_set_block_csr(nsk_handle h, int blk, int n_rows, int n_cols, const int32_t *rowptr, const int32_t *col,
+                      const double *val);
+/* New values on the same pattern (every Newton iteration). */
+int nsk_update_values(nsk_handle h, int blk, const double *val);
+
+int nsk_set_option(nsk_handle h, int opt, double value);
+
+/* Preconditioner::initialize(...)  (NSSolverStationary.hpp:120,176,242; NSSolver.hpp:143,198,263).
+ * Symbolic analysis is cached per pattern; numeric work (diag, SpGEMM, ILU) runs on the GPU. */
+int nsk_setup_preconditioner(nsk_handle h, int type, int variant, double alpha);
+
+/* solver.solve(jacobian_matrix, delta_owned, residual_vector, preconditioner):
+ * x_u/x_p are the initial guess on entry (delta_owned is not zeroed by the reference) and the
+ * solution on exit; *iters = solver_control.last_step(). */
+int nsk_solve(nsk_handle h, int solver, double tol_abs, int max_iter, const double *rhs_u, const double *rhs_p,
+              double *x_u, double *x_p, int *iters, double *final_res);
+
+/* The same in three steps, for callers that keep vectors resident in HBM between solves. */
+int nsk_upload_system(nsk_handle h, const double *rhs_u, const double *rhs_p, const double *x_u, const double *x_p);
+int nsk_solve_resident(nsk_handle h, int solver, double tol_abs, int max_iter, int *iters, double *final_res);
+int nsk_download_solution(nsk_handle h, double *x_u, double *x_p);
+
+/* ---- single operations of the path (parity tests, micro-benchmarks) ---- */
+/* y = A x (add = 0) or y += A x; x has the block's owned column entries (ghosts are imported). */
+int nsk_spmv(nsk_handle h, int blk, const double *x_owned, double *y, int add);
+/* y = jacobian_matrix * x */
+int nsk_jacobian_vmult(nsk_handle h, const double *x_u, const double *x_p, double *y_u, double *y_p);
+/* dot(x,y) and ||x||_2 over the owned entries of all ranks */
+int nsk_dot(nsk_handle h, int n, const double *x, const double *y, double *dot_out, double *norm_x_out);
+/* x = M^-1 b with the velocity / pressure triangular preconditioner of the current setup */
+int nsk_tri_apply(nsk_handle h, int which, const double *b, double *x);
+/* ordering used by that triangular preconditioner: perm[new] = old (identity when natural) */
+int nsk_tri_get_perm(nsk_handle h, int which, int32_t *perm);
+/* preconditioner.vmult(dst, src), applied `calls` times on the same object; dst is in/out */
+int nsk_precond_vmult(nsk_handle h, const double *src_u, const double *src_p, double *dst_u, double *dst_p,
+                      int calls);
+/* size and content of a block held by the library (used for NSK_BLK_S) */
+int64_t nsk_block_nnz(nsk_handle h, int blk);
+int nsk_get_block(nsk_handle h, int blk, int32_t *rowptr, int32_t *col, double *val);
+
+int nsk_get_stats(nsk_handle h, nsk_stats *out);
+int nsk_reset_stats(nsk_handle h);
+
+/* Device-side timing of one operation repeated `reps` times between HIP events on the
+ * library's stream: op 0..5 = SpMV of block op; 10 = jacobian vmult; 20/21 = velocity /
+ * pressure triangular apply; 30 = dot; 31 = axpy; 32 = fused add_and_dot.
+ * Returns average milliseconds per repetition and the algorithmic bytes of one repetition. */
+int nsk_time_op(nsk_handle h, int op, int reps, double *avg_ms, double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

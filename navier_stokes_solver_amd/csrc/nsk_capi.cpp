@@ -1,0 +1,741 @@
+// nsk_capi.cpp — the C ABI (include/nsk.h) and the block preconditioners of the path.
+//
+// Host-side mirror of
+//   PreconditionBlockDiagonal   NSSolverStationary.hpp:115-167 | NSSolver.hpp:138-190
+//   PreconditionBlockTriangular NSSolverStationary.hpp:170-238 | NSSolver.hpp:193-257
+//   PreconditionaSIMPLE         NSSolverStationary.hpp:240-335 | NSSolver.hpp:259-384
+//   solve_system()              NSSolverStationary.cpp:579-647 | NSSolver.cpp:601-672
+// with every vector and matrix resident in HBM and all arithmetic in nsk_kernels.hip.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <memory>
+
+#include "../../include/nsk.h"
+#include "nsk_solver.hpp"
+#include "nsk_tri.hpp"
+
+using namespace nsk;
+
+namespace {
+double wall_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+struct nsk_handle_s {
+  Ctx ctx;
+  std::string err;
+  Space sp[2];
+  Csr blk[6];
+  VecPool pool_u, pool_p, pool_b;
+  bool pools_ready = false;
+  int tri_ordering = ORDER_NATURAL, subdomains = 1, fuse_block_row = 1;
+
+  int prec_type = -1, variant = 0;
+  double alpha = 0.5;
+  TriSolve tF, tMp, tS;
+  bool tF_ok = false, tMp_ok = false, tS_ok = false, s_symbolic = false;
+  int tF_key = -1, tMp_key = -1, tS_key = -1;
+  TriSolve *tP = nullptr;
+  int s_max_row = 0;
+  double *D = nullptr, *Dinv = nullptr, *tmp_p = nullptr, *delta_p = nullptr, *tmp_u = nullptr, *tmp_b = nullptr;
+  double *rhs_b = nullptr, *x_b = nullptr;
+  long inner_u = 0, inner_p = 0, prec_applies = 0, outer_iters = 0;
+  double setup_ms = 0, solve_ms = 0;
+
+  int n_u() const { return sp[0].n; }
+  int n_p() const { return sp[1].n; }
+  int N() const { return sp[0].n + sp[1].n; }
+  DVec ub(double *base) const { return DVec{base, base + N(), n_u()}; }
+  DVec pb(double *base) const { return DVec{base + n_u(), base + N() + sp[0].ng, n_p()}; }
+  DVec bb(double *base) const { return DVec{base, base + N(), N()}; }
+  hipStream_t s() { return ctx.stream; }
+
+  void ensure_pools() {
+    if (pools_ready) return;
+    if (!blk[NSK_BLK_F].present || !blk[NSK_BLK_B].present) throw Error(-40, "set blocks F and B before this call");
+    pool_u.init(&ctx, sp[0].n, sp[0].ng);
+    pool_p.init(&ctx, sp[1].n, sp[1].ng);
+    pool_b.init(&ctx, N(), sp[0].ng + sp[1].ng);
+    rhs_b = pool_b.get(true);
+    x_b = pool_b.get(true);
+    pools_ready = true;
+  }
+  void halo(int space, const DVec &x) { ctx.comm.halo_exchange(sp[space], x, s()); }
+  void spmv_nohalo(Csr &A, const DVec &x, double *y, int mode = 0, const double *z = nullptr) {
+    nsk::spmv(s(), A.view(), A.lpr, x.own, x.ghost, y, mode, z);
+    ++ctx.st.spmv_calls;
+    ctx.st.spmv_bytes += (double)A.spmv_bytes() + (mode == 1 ? 8.0 * A.n_rows : 0.0);
+  }
+  // BlockSparseMatrix::vmult on jacobian_matrix: y_u = F x_u + Bt x_p ; y_p = B x_u (+ 0 x_p)
+  void jacobian_vmult(const DVec &xb, double *yb) {
+    const DVec xu = ub(xb.own), xp = pb(xb.own);
+    halo(0, xu);
+    halo(1, xp);
+    Csr &F = blk[NSK_BLK_F], &Bt = blk[NSK_BLK_BT], &B = blk[NSK_BLK_B];
+    if (fuse_block_row) {
+      nsk::spmv2(s(), F.view(), xu.own, xu.ghost, Bt.view(), xp.own, xp.ghost, yb, F.lpr);
+      ctx.st.spmv_calls += 2;
+      ctx.st.spmv_bytes += (double)F.spmv_bytes() + (double)Bt.spmv_bytes() - 8.0 * F.n_rows - 4.0 * (F.n_rows + 1);
+    } else {
+      spmv_nohalo(F, xu, yb, 0);
+      spmv_nohalo(Bt, xp, yb, 1);
+    }
+    spmv_nohalo(B, xu, yb + n_u(), 0);
+  }
+  std::vector<int> sub_offsets(int space) const {
+    std::vector<int> off;
+    if (subdomains <= 1) return off;
+    const int n = sp[space].n;
+    off.resize(subdomains + 1);
+    for (int k = 0; k <= subdomains; ++k) {
+      long v = (long)n * k / subdomains;
+      if (space == 0) v &= ~1L;  // keep both velocity components of a node together
+      off[k] = (int)v;
+    }
+    off[subdomains] = n;
+    return off;
+  }
+  void schur_symbolic();
+  void setup(int type, int variant_, double alpha_);
+  void prec_vmult(DVec &dst, const DVec &src);
+  int solve_resident(int solver, double tol, int max_iter, int *iters, double *final_res);
+};
+using H = nsk_handle_s;
+
+// S pattern = structural product of B and [Bt ; Bt_ghost]  (EpetraExt MatrixMatrix::Multiply)
+void H::schur_symbolic() {
+  Csr &B = blk[NSK_BLK_B], &Bt = blk[NSK_BLK_BT], &Btg = blk[NSK_BLK_BT_GHOST], &S = blk[NSK_BLK_S];
+  if (!Bt.present) throw Error(-41, "aSIMPLE needs block (0,1)");
+  if (sp[0].ng > 0 && !Btg.present) throw Error(-42, "aSIMPLE on several ranks needs NSK_BLK_BT_GHOST");
+  const int np = B.n_rows, ncols = sp[1].n + sp[1].ng;
+  std::vector<int> rp(np + 1, 0);
+  std::vector<std::vector<int>> rows(np);
+#pragma omp parallel
+  {
+    std::vector<int> mark(ncols, -1), cols;
+#pragma omp for schedule(dynamic, 256)
+    for (int i = 0; i < np; ++i) {
+      cols.clear();
+      for (int k = B.h_rowptr[i]; k < B.h_rowptr[i + 1]; ++k) {
+        const int m = B.h_col[k];
+        const Csr &R = m < B.n_own_cols ? Bt : Btg;
+        const int mr = m < B.n_own_cols ? m : m - B.n_own_cols;
+        for (int q = R.h_rowptr[mr]; q < R.h_rowptr[mr + 1]; ++q) {
+          const int j = R.h_col[q];
+          if (mark[j] != i) { mark[j] = i; cols.push_back(j); }
+        }
+      }
+      std::sort(cols.begin(), cols.end());
+      rows[i] = cols;
+    }
+  }
+  s_max_row = 0;
+  for (int i = 0; i < np; ++i) {
+    rp[i + 1] = rp[i] + (int)rows[i].size();
+    s_max_row = std::max(s_max_row, (int)rows[i].size());
+  }
+  if (s_max_row > 448) throw Error(-43, "Schur row too long for the LDS-staged SpGEMM kernel");
+  S.n_rows = np;
+  S.n_cols = ncols;
+  S.n_own_cols = sp[1].n;
+  S.nnz = rp[np];
+  S.h_rowptr = rp;
+  S.h_col.resize((size_t)S.nnz);
+  for (int i = 0; i < np; ++i) std::copy(rows[i].begin(), rows[i].end(), S.h_col.begin() + rp[i]);
+  S.rowptr.upload(S.h_rowptr, s());
+  S.col.upload(S.h_col, s());
+  S.val.alloc((size_t)S.nnz);
+  S.lpr = pick_lpr(S.nnz, S.n_rows);
+  S.present = true;
+  ctx.sync();
+  s_symbolic = true;
+}
+
+void H::setup(int type, int variant_, double alpha_) {
+  if (type < 0 || type > 2) throw Error(-44, "Invalid preconditioner type. Use 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE.");
+  ensure_pools();
+  const double t0 = wall_ms();
+  prec_type = type;
+  variant = variant_;
+  alpha = alpha_;
+  const int key = tri_ordering * 100000 + subdomains;
+  Csr &F = blk[NSK_BLK_F];
+  // kinds: blockDiagonal stationary = SSOR/SSOR, unsteady = ILU/ILU; blockTriangular = (AMG->ILU)/ILU; aSIMPLE = ILU/ILU
+  const int kindF = (type == 0 && variant == 0) ? 1 : 0;
+  const int kindP = (type == 0 && variant == 0) ? 1 : 0;
+  if (!tF_ok || tF_key != key) {
+    tF.analyze(&ctx, F, kindF, tri_ordering, sub_offsets(0));
+    tF_ok = true;
+    tF_key = key;
+  }
+  tF.kind = kindF;
+  tF.numeric(F.val.p);
+  if (type == 2) {
+    if (!s_symbolic) schur_symbolic();
+    if (!D) { D = pool_u.get(true); Dinv = pool_u.get(true); tmp_u = pool_u.get(true); }
+    if (!tmp_p) tmp_p = pool_p.get(true);
+    if (!delta_p) delta_p = pool_p.get(true);
+    if (!tmp_b) tmp_b = pool_b.get(true);
+    // D = diag(F), D^-1 (NSSolverStationary.hpp:259-264); ghosts of D^-1 feed the SpGEMM
+    extract_diag(s(), F.view(), D, Dinv);
+    halo(0, pool_u.view(Dinv));
+    Csr &S = blk[NSK_BLK_S], &B = blk[NSK_BLK_B], &Bt = blk[NSK_BLK_BT], &Btg = blk[NSK_BLK_BT_GHOST];
+    spgemm_bdbt_numeric(s(), B.view(), Dinv, Dinv + n_u(), Bt.view(), Btg.present ? Btg.view() : Bt.view(), S.rowptr.p,
+                        S.col.p, S.val.p, S.n_rows, std::max(1, s_max_row));
+    if (!tS_ok || tS_key != key) {
+      tS.analyze(&ctx, S, 0, tri_ordering, sub_offsets(1));
+      tS_ok = true;
+      tS_key = key;
+    }
+    tS.kind = 0;
+    tS.numeric(S.val.p);
+    tP = &tS;
+    // delta_p.reinit(...) in initialize(): zero
+    vec_set(s(), n_p(), delta_p, 0.0);
+  } else {
+    Csr &Mp = blk[NSK_BLK_MP];
+    if (!Mp.present) throw Error(-45, "this preconditioner needs pressure_mass.block(1,1)");
+    if (!tMp_ok || tMp_key != key) {
+      tMp.analyze(&ctx, Mp, kindP, tri_ordering, sub_offsets(1));
+      tMp_ok = true;
+      tMp_key = key;
+    }
+    tMp.kind = kindP;
+    tMp.numeric(Mp.val.p);
+    tP = &tMp;
+    if (!tmp_p) tmp_p = pool_p.get(true);
+  }
+  ctx.sync();
+  setup_ms = wall_ms() - t0;
+}
+
+void H::prec_vmult(DVec &dst, const DVec &src) {
+  ++prec_applies;
+  Csr &F = blk[NSK_BLK_F], &B = blk[NSK_BLK_B], &Bt = blk[NSK_BLK_BT];
+  DVec du = ub(dst.own), dp = pb(dst.own);
+  const DVec su = ub(src.own), spv = pb(src.own);
+  const int nu = n_u(), np = n_p();
+  MatVec A_F = [&](const DVec &x, double *y) { halo(0, x); spmv_nohalo(F, x, y); };
+  PrecVmult P_F = [&](DVec &d, const DVec &r) { tF.apply(r.own, d.own); };
+  PrecVmult P_P = [&](DVec &d, const DVec &r) { tP->apply(r.own, d.own); };
+  const int sl = ctx.alloc_slots(4);
+  struct Rel { Ctx &c; int sl; ~Rel() { c.slot_top = sl; } } rel{ctx, sl};
+  auto norm_of = [&](const double *v, int n) { ctx.norm2(n, v, sl); return ctx.read_slots(sl + 1, 1)[0]; };
+
+  if (prec_type == 0 || prec_type == 1) {
+    Csr &Mp = blk[NSK_BLK_MP];
+    MatVec A_M = [&](const DVec &x, double *y) { halo(1, x); spmv_nohalo(Mp, x, y); };
+    int max_u, max_p;
+    double tol_u, tol_p;
+    if (prec_type == 0) {
+      if (variant == 0) { max_u = 100001; max_p = 100000; tol_u = 1e-1 * norm_of(su.own, nu); tol_p = 1e-1 * norm_of(spv.own, np); }
+      else { max_u = max_p = 1000; tol_u = tol_p = 1e-1; }
+    } else {
+      if (variant == 0) { max_u = 10000001; max_p = 100000; tol_u = 1e-2 * norm_of(su.own, nu); tol_p = 1e-2 * norm_of(spv.own, np); }
+      else { max_u = 2000001; max_p = 2000000; tol_u = 1e-4 * norm_of(su.own, nu); tol_p = 1e-5 * norm_of(spv.own, np); }
+    }
+    SolverControl cu(max_u, tol_u), cp(max_p, tol_p);
+    try {
+      SolverFGMRES sv(ctx, pool_u, cu);
+      sv.solve(A_F, du, su, P_F);
+      inner_u += cu.last_step();
+      if (prec_type == 0) {
+        SolverCG sc(ctx, pool_p, cp);
+        sc.solve(A_M, dp, spv, P_P);
+      } else {
+        // tmp.reinit; B->vmult(tmp, dst_u); tmp.sadd(-1, src_p)  =>  tmp = src_p - B u
+        halo(0, du);
+        spmv_nohalo(B, du, tmp_p, 2, spv.own);
+        DVec tp = pool_p.view(tmp_p);
+        SolverCG sc(ctx, pool_p, cp);
+        sc.solve(A_M, dp, tp, P_P);
+      }
+      inner_p += cp.last_step();
+    } catch (NoConvergence &e) {
+      throw NoConvergence(3, e.last_step, e.last_residual);
+    }
+    return;
+  }
+  if (variant == 0) {
+    // stationary aSIMPLE (NSSolverStationary.hpp:282-311)
+    Csr &S = blk[NSK_BLK_S];
+    MatVec A_S = [&](const DVec &x, double *y) { halo(1, x); spmv_nohalo(S, x, y); };
+    try {
+      SolverControl cF(100000, 1e-1 * norm_of(su.own, nu));
+      SolverFGMRES sF(ctx, pool_u, cF);
+      sF.solve(A_F, du, su, P_F);                       // F u~ = src_u
+      inner_u += cF.last_step();
+      halo(0, du);
+      spmv_nohalo(B, du, tmp_p, 2, spv.own);             // tmp_p = src_p - B u~
+      SolverControl cS(100000, 1e-1 * norm_of(tmp_p, np));
+      SolverCG sS(ctx, pool_p, cS);
+      DVec dlt = pool_p.view(delta_p), tp = pool_p.view(tmp_p);
+      sS.solve(A_S, dlt, tp, P_P);                      // S delta_p = tmp_p, stale delta_p as start
+      inner_p += cS.last_step();
+    } catch (NoConvergence &e) {
+      throw NoConvergence(3, e.last_step, e.last_residual);
+    }
+    vec_scale(s(), np, sref(alpha), delta_p);           // delta_p *= alpha
+    DVec dlt = pool_p.view(delta_p);
+    halo(1, dlt);
+    spmv_nohalo(Bt, dlt, tmp_u, 0);                      // tmp_u = B^T delta_p
+    vec_submul(s(), nu, Dinv, tmp_u, du.own);            // u = u~ - D^-1 tmp_u
+    vec_copy(s(), np, delta_p, dp.own);
+    return;
+  }
+  // unsteady aSIMPLE (NSSolver.hpp:294-350): ILU applies only
+  tF.apply(su.own, du.own);
+  halo(0, du);
+  vec_copy(s(), np, spv.own, tmp_p);
+  spmv_nohalo(B, du, tmp_p, 1);                          // tmp_p = src_p + B~ u   (vmult_add)
+  tP->apply(tmp_p, dp.own);
+  vec_mul(s(), nu, D, du.own);                           // u .*= D
+  vec_scale(s(), np, sref(1.0 / alpha), dp.own);         // p /= alpha
+  halo(1, dp);
+  spmv_nohalo(Bt, dp, tmp_u, 0);
+  vec_sub_then_mul(s(), nu, tmp_u, Dinv, du.own);        // u = (u - B~^T p) .* D^-1
+}
+
+int H::solve_resident(int solver, double tol, int max_iter, int *iters, double *final_res) {
+  if (prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
+  if (solver < 0 || solver > 2) throw Error(-47, "Invalid solver type. Use 0: GMRES, 1: FGMRES, 2: Bicgstab.");
+  SolverControl control(max_iter, tol);
+  MatVec A = [&](const DVec &x, double *y) { jacobian_vmult(x, y); };
+  PrecVmult P = [&](DVec &d, const DVec &r) { prec_vmult(d, r); };
+  DVec x = bb(x_b);
+  const DVec b = bb(rhs_b);
+  int rc = 0;
+  const double t0 = wall_ms();
+  const int slot_mark = ctx.slot_top;
+  try {
+    if (solver == 0) { SolverGMRES sv(ctx, pool_b, control); sv.solve(A, x, b, P); }
+    else if (solver == 1) { SolverFGMRES sv(ctx, pool_b, control); sv.solve(A, x, b, P); }
+    else { SolverBicgstab sv(ctx, pool_b, control); sv.solve(A, x, b, P); }
+  } catch (NoConvergence &e) {
+    rc = e.code;
+  }
+  ctx.slot_top = slot_mark;
+  ctx.sync();
+  solve_ms = wall_ms() - t0;
+  outer_iters += control.last_step();
+  if (iters) *iters = control.last_step();
+  if (final_res) *final_res = control.last_value();
+  return rc;
+}
+
+// ================================================================== C ABI
+#define NSK_TRY(h) try {
+#define NSK_CATCH(h)                                  \
+  }                                                   \
+  catch (const Error &e) {                            \
+    (h)->err = e.what();                              \
+    return e.code;                                    \
+  }                                                   \
+  catch (const std::exception &e) {                   \
+    (h)->err = e.what();                              \
+    return -1;                                        \
+  }
+
+extern "C" {
+
+int nsk_get_unique_id(void *out128) {
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return -20;
+  std::memcpy(out128, &id, sizeof(id));
+  return 0;
+}
+
+nsk_handle nsk_create(int rank, int nranks, int device_id, const void *uid) {
+  H *h = new H();
+  try {
+    h->ctx.init(device_id);
+    h->ctx.comm.init(rank, nranks, uid);
+  } catch (const std::exception &e) {
+    fprintf(stderr, "nsk_create: %s\n", e.what());
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+
+void nsk_destroy(nsk_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->ctx.device);
+  (void)hipStreamSynchronize(h->ctx.stream);
+  h->pool_u.destroy();
+  h->pool_p.destroy();
+  h->pool_b.destroy();
+  h->ctx.destroy();
+  delete h;
+}
+
+const char *nsk_last_error(nsk_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int nsk_set_partition(nsk_handle h, int space, int64_t b, int64_t e, int n_ghost, const int32_t *gids) {
+  NSK_TRY(h)
+  if (space < 0 || space > 1 || e < b || n_ghost < 0) throw Error(-50, "nsk_set_partition: bad arguments");
+  if (h->pools_ready) throw Error(-51, "partition is fixed once vectors exist");
+  Space &S = h->sp[space];
+  S.n = (int)(e - b);
+  S.ng = n_ghost;
+  S.gbegin = b;
+  S.gend = e;
+  S.ghost_gid.assign(gids, gids + n_ghost);
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_set_halo_plan(nsk_handle h, int space, int nn, const int32_t *peer, const int32_t *send_ptr,
+                      const int32_t *send_idx, const int32_t *recv_ptr) {
+  NSK_TRY(h)
+  if (space < 0 || space > 1 || nn < 0) throw Error(-52, "nsk_set_halo_plan: bad arguments");
+  Space &S = h->sp[space];
+  S.peers.assign(peer, peer + nn);
+  S.send_ptr.assign(send_ptr, send_ptr + nn + 1);
+  S.recv_ptr.assign(recv_ptr, recv_ptr + nn + 1);
+  S.n_send = nn ? send_ptr[nn] : 0;
+  for (int k = 0; k < S.n_send; ++k)
+    if (send_idx[k] < 0 || send_idx[k] >= S.n) throw Error(-53, "halo plan: send index outside the owned range");
+  if (nn && recv_ptr[nn] != S.ng) throw Error(-54, "halo plan: receive counts do not cover the ghost list");
+  (void)hipSetDevice(h->ctx.device);
+  S.d_send_idx.upload(send_idx, (size_t)S.n_send, h->s());
+  S.d_send_buf.alloc((size_t)std::max(1, S.n_send));
+  h->ctx.sync();
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_set_block_csr(nsk_handle h, int b, int n_rows, int n_cols, const int32_t *rowptr, const int32_t *col,
+                      const double *val) {
+  NSK_TRY(h)
+  if (b < 0 || b > NSK_BLK_BT_GHOST) throw Error(-55, "nsk_set_block_csr: bad block id");
+  (void)hipSetDevice(h->ctx.device);
+  const int rs = (b == NSK_BLK_F || b == NSK_BLK_BT) ? 0 : 1;   // row space
+  const int cs = (b == NSK_BLK_F || b == NSK_BLK_B) ? 0 : 1;    // column space
+  const Space &R = h->sp[rs], &Cc = h->sp[cs];
+  const int want_rows = b == NSK_BLK_BT_GHOST ? h->sp[0].ng : R.n;
+  if (n_rows != want_rows) throw Error(-56, "nsk_set_block_csr: row count does not match the partition");
+  if (n_cols != Cc.n + Cc.ng) throw Error(-57, "nsk_set_block_csr: column count does not match owned+ghost");
+  const int64_t nnz = rowptr[n_rows];
+  for (int i = 0; i < n_rows; ++i)
+    if (rowptr[i + 1] < rowptr[i]) throw Error(-58, "nsk_set_block_csr: rowptr not monotone");
+  for (int64_t k = 0; k < nnz; ++k)
+    if (col[k] < 0 || col[k] >= n_cols) throw Error(-59, "nsk_set_block_csr: column id out of range");
+  Csr &A = h->blk[b];
+  A.n_rows = n_rows;
+  A.n_cols = n_cols;
+  A.n_own_cols = Cc.n;
+  A.nnz = nnz;
+  A.h_rowptr.assign(rowptr, rowptr + n_rows + 1);
+  A.h_col.assign(col, col + nnz);
+  A.rowptr.upload(rowptr, (size_t)n_rows + 1, h->s());
+  A.col.upload(col, (size_t)nnz, h->s());
+  A.val.upload(val, (size_t)nnz, h->s());
+  A.lpr = pick_lpr(nnz, n_rows);
+  A.present = true;
+  h->ctx.sync();
+  // a new pattern invalidates cached symbolic data
+  if (b == NSK_BLK_F) h->tF_ok = false;
+  if (b == NSK_BLK_MP) h->tMp_ok = false;
+  if (b == NSK_BLK_B || b == NSK_BLK_BT || b == NSK_BLK_BT_GHOST) { h->s_symbolic = false; h->tS_ok = false; }
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_update_values(nsk_handle h, int b, const double *val) {
+  NSK_TRY(h)
+  if (b < 0 || b > NSK_BLK_BT_GHOST || !h->blk[b].present) throw Error(-60, "nsk_update_values: block not set");
+  (void)hipSetDevice(h->ctx.device);
+  Csr &A = h->blk[b];
+  NSK_HIP(hipMemcpyAsync(A.val.p, val, sizeof(double) * (size_t)A.nnz, hipMemcpyHostToDevice, h->s()));
+  h->ctx.sync();
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_set_option(nsk_handle h, int opt, double v) {
+  NSK_TRY(h)
+  switch (opt) {
+    case NSK_OPT_TRI_ORDERING: h->tri_ordering = v != 0.0 ? ORDER_MULTICOLOR : ORDER_NATURAL; break;
+    case NSK_OPT_SUBDOMAINS: h->subdomains = std::max(1, (int)v); break;
+    case NSK_OPT_FUSE_BLOCK_ROW: h->fuse_block_row = v != 0.0; break;
+    default: throw Error(-61, "nsk_set_option: unknown option");
+  }
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_setup_preconditioner(nsk_handle h, int type, int variant, double alpha) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  h->setup(type, variant, alpha);
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_upload_system(nsk_handle h, const double *ru, const double *rp, const double *xu, const double *xp) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  h->ensure_pools();
+  const size_t bu = sizeof(double) * (size_t)h->n_u(), bp = sizeof(double) * (size_t)h->n_p();
+  NSK_HIP(hipMemcpyAsync(h->rhs_b, ru, bu, hipMemcpyHostToDevice, h->s()));
+  NSK_HIP(hipMemcpyAsync(h->rhs_b + h->n_u(), rp, bp, hipMemcpyHostToDevice, h->s()));
+  NSK_HIP(hipMemcpyAsync(h->x_b, xu, bu, hipMemcpyHostToDevice, h->s()));
+  NSK_HIP(hipMemcpyAsync(h->x_b + h->n_u(), xp, bp, hipMemcpyHostToDevice, h->s()));
+  h->ctx.sync();
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_solve_resident(nsk_handle h, int solver, double tol, int max_iter, int *iters, double *final_res) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  return h->solve_resident(solver, tol, max_iter, iters, final_res);
+  NSK_CATCH(h)
+}
+
+int nsk_download_solution(nsk_handle h, double *xu, double *xp) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  NSK_HIP(hipMemcpyAsync(xu, h->x_b, sizeof(double) * (size_t)h->n_u(), hipMemcpyDeviceToHost, h->s()));
+  NSK_HIP(hipMemcpyAsync(xp, h->x_b + h->n_u(), sizeof(double) * (size_t)h->n_p(), hipMemcpyDeviceToHost, h->s()));
+  h->ctx.sync();
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_solve(nsk_handle h, int solver, double tol, int max_iter, const double *ru, const double *rp, double *xu,
+              double *xp, int *iters, double *final_res) {
+  int rc = nsk_upload_system(h, ru, rp, xu, xp);
+  if (rc < 0) return rc;
+  const int rs = nsk_solve_resident(h, solver, tol, max_iter, iters, final_res);
+  if (rs < 0) return rs;
+  rc = nsk_download_solution(h, xu, xp);
+  return rc < 0 ? rc : rs;
+}
+
+int nsk_spmv(nsk_handle h, int b, const double *x, double *y, int add) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  h->ensure_pools();
+  if (b < 0 || b > NSK_BLK_S || !h->blk[b].present) throw Error(-62, "nsk_spmv: block not set");
+  Csr &A = h->blk[b];
+  const int rs = (b == NSK_BLK_F || b == NSK_BLK_BT) ? 0 : 1, cs = (b == NSK_BLK_F || b == NSK_BLK_B) ? 0 : 1;
+  if (b == NSK_BLK_BT_GHOST) throw Error(-63, "nsk_spmv: ghost rows are not an operator");
+  VecPool &pc = cs == 0 ? h->pool_u : h->pool_p, &pr = rs == 0 ? h->pool_u : h->pool_p;
+  double *xv = pc.get(true), *yv = pr.get(true);
+  NSK_HIP(hipMemcpyAsync(xv, x, sizeof(double) * (size_t)pc.n, hipMemcpyHostToDevice, h->s()));
+  if (add) NSK_HIP(hipMemcpyAsync(yv, y, sizeof(double) * (size_t)pr.n, hipMemcpyHostToDevice, h->s()));
+  h->halo(cs, pc.view(xv));
+  h->spmv_nohalo(A, pc.view(xv), yv, add ? 1 : 0);
+  NSK_HIP(hipMemcpyAsync(y, yv, sizeof(double) * (size_t)pr.n, hipMemcpyDeviceToHost, h->s()));
+  h->ctx.sync();
+  pc.put(xv);
+  pr.put(yv);
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_jacobian_vmult(nsk_handle h, const double *xu, const double *xp, double *yu, double *yp) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  h->ensure_pools();
+  double *xb = h->pool_b.get(true), *yb = h->pool_b.get(true);
+  NSK_HIP(hipMemcpyAsync(xb, xu, sizeof(double) * (size_t)h->n_u(), hipMemcpyHostToDevice, h->s()));
+  NSK_HIP(hipMemcpyAsync(xb + h->n_u(), xp, sizeof(double) * (size_t)h->n_p(), hipMemcpyHostToDevice, h->s()));
+  h->jacobian_vmult(h->bb(xb), yb);
+  NSK_HIP(hipMemcpyAsync(yu, yb, sizeof(double) * (size_t)h->n_u(), hipMemcpyDeviceToHost, h->s()));
+  NSK_HIP(hipMemcpyAsync(yp, yb + h->n_u(), sizeof(double) * (size_t)h->n_p(), hipMemcpyDeviceToHost, h->s()));
+  h->ctx.sync();
+  h->pool_b.put(xb);
+  h->pool_b.put(yb);
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_dot(nsk_handle h, int n, const double *x, const double *y, double *dot_out, double *norm_out) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  DBuf<double> dx, dy;
+  dx.upload(x, (size_t)n, h->s());
+  dy.upload(y, (size_t)n, h->s());
+  const int sl = h->ctx.alloc_slots(4);
+  h->ctx.dot(n, dx.p, dy.p, sl);
+  h->ctx.norm2(n, dx.p, sl + 1);
+  const double *r = h->ctx.read_slots(sl, 3);
+  if (dot_out) *dot_out = r[0];
+  if (norm_out) *norm_out = r[2];
+  h->ctx.slot_top = sl;
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_tri_apply(nsk_handle h, int which, const double *b, double *x) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  if (h->prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
+  TriSolve *T = which == NSK_TRI_VELOCITY ? &h->tF : h->tP;
+  VecPool &p = which == NSK_TRI_VELOCITY ? h->pool_u : h->pool_p;
+  double *bv = p.get(true), *xv = p.get(true);
+  NSK_HIP(hipMemcpyAsync(bv, b, sizeof(double) * (size_t)p.n, hipMemcpyHostToDevice, h->s()));
+  T->apply(bv, xv);
+  NSK_HIP(hipMemcpyAsync(x, xv, sizeof(double) * (size_t)p.n, hipMemcpyDeviceToHost, h->s()));
+  h->ctx.sync();
+  p.put(bv);
+  p.put(xv);
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_tri_get_perm(nsk_handle h, int which, int32_t *perm) {
+  NSK_TRY(h)
+  if (h->prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
+  TriSolve *T = which == NSK_TRI_VELOCITY ? &h->tF : h->tP;
+  for (int i = 0; i < T->n; ++i) perm[i] = T->perm.empty() ? i : T->perm[i];
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_precond_vmult(nsk_handle h, const double *su, const double *sp_, double *du, double *dp, int calls) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  if (h->prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
+  double *sb = h->pool_b.get(true), *db = h->pool_b.get(true);
+  const size_t bu = sizeof(double) * (size_t)h->n_u(), bp = sizeof(double) * (size_t)h->n_p();
+  NSK_HIP(hipMemcpyAsync(sb, su, bu, hipMemcpyHostToDevice, h->s()));
+  NSK_HIP(hipMemcpyAsync(sb + h->n_u(), sp_, bp, hipMemcpyHostToDevice, h->s()));
+  NSK_HIP(hipMemcpyAsync(db, du, bu, hipMemcpyHostToDevice, h->s()));
+  NSK_HIP(hipMemcpyAsync(db + h->n_u(), dp, bp, hipMemcpyHostToDevice, h->s()));
+  int rc = 0;
+  DVec d = h->bb(db);
+  const DVec sv = h->bb(sb);
+  try {
+    for (int k = 0; k < calls; ++k) h->prec_vmult(d, sv);
+  } catch (NoConvergence &e) {
+    rc = e.code;
+  }
+  NSK_HIP(hipMemcpyAsync(du, db, bu, hipMemcpyDeviceToHost, h->s()));
+  NSK_HIP(hipMemcpyAsync(dp, db + h->n_u(), bp, hipMemcpyDeviceToHost, h->s()));
+  h->ctx.sync();
+  h->pool_b.put(sb);
+  h->pool_b.put(db);
+  return rc;
+  NSK_CATCH(h)
+}
+
+int64_t nsk_block_nnz(nsk_handle h, int b) {
+  if (!h || b < 0 || b > NSK_BLK_S || !h->blk[b].present) return -1;
+  return h->blk[b].nnz;
+}
+
+int nsk_get_block(nsk_handle h, int b, int32_t *rowptr, int32_t *col, double *val) {
+  NSK_TRY(h)
+  if (b < 0 || b > NSK_BLK_S || !h->blk[b].present) throw Error(-64, "nsk_get_block: block not set");
+  (void)hipSetDevice(h->ctx.device);
+  Csr &A = h->blk[b];
+  std::copy(A.h_rowptr.begin(), A.h_rowptr.end(), rowptr);
+  std::copy(A.h_col.begin(), A.h_col.end(), col);
+  NSK_HIP(hipMemcpyAsync(val, A.val.p, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToHost, h->s()));
+  h->ctx.sync();
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_get_stats(nsk_handle h, nsk_stats *o) {
+  NSK_TRY(h)
+  const Stats &st = h->ctx.st;
+  o->setup_ms = h->setup_ms;
+  o->solve_ms = h->solve_ms;
+  o->outer_iters = h->outer_iters;
+  o->inner_u_its = h->inner_u;
+  o->inner_p_its = h->inner_p;
+  o->prec_applies = h->prec_applies;
+  o->spmv_calls = st.spmv_calls;
+  o->tri_applies = st.tri_applies;
+  o->reductions = st.reductions;
+  o->host_syncs = st.host_syncs;
+  o->spmv_bytes = st.spmv_bytes;
+  o->tri_bytes = st.tri_bytes;
+  o->blas1_bytes = st.blas1_bytes;
+  o->n_colors_u = h->tF_ok ? h->tF.n_colors : 0;
+  o->n_levels_u = h->tF_ok ? h->tF.n_levels_L : 0;
+  o->n_colors_p = h->tP ? h->tP->n_colors : 0;
+  o->n_levels_p = h->tP ? h->tP->n_levels_L : 0;
+  o->nnz_s = h->blk[NSK_BLK_S].present ? h->blk[NSK_BLK_S].nnz : 0;
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_reset_stats(nsk_handle h) {
+  NSK_TRY(h)
+  h->ctx.st = Stats{};
+  h->inner_u = h->inner_p = h->prec_applies = h->outer_iters = 0;
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_time_op(nsk_handle h, int op, int reps, double *avg_ms, double *bytes) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  h->ensure_pools();
+  if (reps < 1) reps = 1;
+  hipEvent_t e0, e1;
+  NSK_HIP(hipEventCreate(&e0));
+  NSK_HIP(hipEventCreate(&e1));
+  double *xb = h->pool_b.get(true), *yb = h->pool_b.get(true), *zb = h->pool_b.get(true);
+  vec_set(h->s(), h->N(), xb, 1.0);
+  vec_set(h->s(), h->N(), zb, 0.5);
+  const int sl = h->ctx.alloc_slots(4);
+  double by = 0.0;
+  std::function<void()> f;
+  if (op >= 0 && op <= NSK_BLK_S && op != NSK_BLK_BT_GHOST) {
+    if (!h->blk[op].present) throw Error(-62, "nsk_time_op: block not set");
+    Csr &A = h->blk[op];
+    const int cs = (op == NSK_BLK_F || op == NSK_BLK_B) ? 0 : 1;
+    const DVec xv = cs == 0 ? h->ub(xb) : h->pb(xb);
+    by = (double)A.spmv_bytes();
+    f = [=, &A]() { h->halo(cs, xv); h->spmv_nohalo(A, xv, yb, 0); };
+  } else if (op == 10) {
+    Csr &F = h->blk[NSK_BLK_F], &Bt = h->blk[NSK_BLK_BT], &B = h->blk[NSK_BLK_B];
+    by = (double)F.spmv_bytes() + (double)Bt.spmv_bytes() + (double)B.spmv_bytes();
+    f = [=]() { h->jacobian_vmult(h->bb(xb), yb); };
+  } else if (op == 20 || op == 21) {
+    if (h->prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
+    TriSolve *T = op == 20 ? &h->tF : h->tP;
+    by = (double)T->apply_bytes();
+    f = [=]() { T->apply(xb, yb); };
+  } else if (op == 30) {
+    by = 16.0 * h->N();
+    f = [=]() { h->ctx.dot(h->N(), xb, zb, sl); };
+  } else if (op == 31) {
+    by = 24.0 * h->N();
+    f = [=]() { vec_axpy(h->s(), h->N(), sref(1e-9), xb, zb); };
+  } else if (op == 32) {
+    by = 32.0 * h->N();
+    f = [=]() { h->ctx.axpy_dot(h->N(), sref(1e-9), xb, zb, yb, sl); };
+  } else {
+    throw Error(-65, "nsk_time_op: unknown op");
+  }
+  f();  // warm-up
+  NSK_HIP(hipEventRecord(e0, h->s()));
+  for (int r = 0; r < reps; ++r) f();
+  NSK_HIP(hipEventRecord(e1, h->s()));
+  NSK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  NSK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (avg_ms) *avg_ms = (double)ms / reps;
+  if (bytes) *bytes = by;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  h->ctx.slot_top = sl;
+  h->pool_b.put(xb);
+  h->pool_b.put(yb);
+  h->pool_b.put(zb);
+  return 0;
+  NSK_CATCH(h)
+}
+
+}  // extern "C"

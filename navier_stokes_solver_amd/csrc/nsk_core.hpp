@@ -1,0 +1,179 @@
+// nsk_core.hpp — device context, vectors, CSR blocks and the inter-GPU layer.
+//
+// Data layout in HBM (per rank / GPU):
+//   * a "space" is a row-partitioned index set (velocity or pressure) with
+//     n owned entries followed by ng ghost entries (Epetra ColMap convention:
+//     owned first, ghosts appended, grouped by owning rank).
+//   * a block vector is ONE allocation [u_owned | p_owned | u_ghost | p_ghost]
+//     so BLAS-1 on the whole block vector is a single launch over the first
+//     n_u + n_p entries, while SpMV reads (owned, ghost) pointer pairs.
+//   * matrices are CSR, f64 values / int32 local column ids.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "nsk_kernels.h"
+
+struct ncclComm;
+
+namespace nsk {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define NSK_HIP(call)                                                                              \
+  do {                                                                                             \
+    hipError_t e__ = (call);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      throw ::nsk::Error(-10, std::string(#call) + ": " + hipGetErrorString(e__) + " @" __FILE__ ":" + \
+                                  std::to_string(__LINE__));                                       \
+  } while (0)
+
+template <class T>
+struct DBuf {  // owning device buffer
+  T *p = nullptr;
+  size_t n = 0;
+  DBuf() = default;
+  DBuf(const DBuf &) = delete;
+  DBuf &operator=(const DBuf &) = delete;
+  DBuf(DBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DBuf &operator=(DBuf &&o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) NSK_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+  }
+  void upload(const T *h, size_t count, hipStream_t s) {
+    if (count != n) alloc(count);
+    if (count) NSK_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void upload(const std::vector<T> &h, hipStream_t s) { upload(h.data(), h.size(), s); }
+};
+
+// index space (velocity or pressure DoFs of this rank)
+struct Space {
+  int n = 0;   // owned
+  int ng = 0;  // ghosts
+  int64_t gbegin = 0, gend = 0;
+  std::vector<int> ghost_gid;
+  // halo plan (what Epetra_Import holds): per neighbour, owned entries to send and the ghost slice to receive
+  std::vector<int> peers, send_ptr, recv_ptr;
+  DBuf<int> d_send_idx;
+  DBuf<double> d_send_buf;
+  int n_send = 0;
+};
+
+// view of a vector on one space: owned part and ghost tail
+struct DVec {
+  double *own = nullptr;
+  double *ghost = nullptr;
+  int n = 0;
+};
+
+struct Csr {  // device CSR block with host copy of the pattern
+  int n_rows = 0, n_cols = 0, n_own_cols = 0;
+  int64_t nnz = 0;
+  std::vector<int> h_rowptr, h_col;  // host pattern (symbolic phases)
+  DBuf<int> rowptr, col;
+  DBuf<double> val;
+  int lpr = 16;  // lanes per row chosen from the mean row length
+  bool present = false;
+  CsrView view() const { return CsrView{n_rows, n_own_cols, rowptr.p, col.p, val.p}; }
+  size_t spmv_bytes() const {  // 12 nnz + 4 (rows+1) + 8 rows + 8 cols
+    return (size_t)12 * nnz + 4 * ((size_t)n_rows + 1) + 8 * (size_t)n_rows + 8 * (size_t)n_cols;
+  }
+};
+
+inline int pick_lpr(int64_t nnz, int n_rows) {
+  const double mean = n_rows > 0 ? (double)nnz / n_rows : 0.0;
+  if (mean <= 6) return 4;
+  if (mean <= 20) return 8;
+  if (mean <= 80) return 16;
+  if (mean <= 200) return 32;
+  return 64;
+}
+
+// RCCL over xGMI: one communicator per handle, everything on the compute stream.
+struct Comm {
+  int rank = 0, nranks = 1;
+  ncclComm *comm = nullptr;
+  void init(int rank, int nranks, const void *unique_id);
+  void destroy();
+  void allreduce_sum(double *d, int count, hipStream_t s);
+  void halo_exchange(Space &sp, const DVec &x, hipStream_t s);
+};
+
+struct Stats {
+  double setup_ms = 0, solve_ms = 0;
+  long outer_iters = 0, inner_u_its = 0, inner_p_its = 0, prec_applies = 0, spmv_calls = 0, tri_applies = 0,
+       reductions = 0, host_syncs = 0;
+  double spmv_bytes = 0, tri_bytes = 0, blas1_bytes = 0;
+};
+
+struct Ctx {
+  hipStream_t stream = nullptr;
+  int device = 0;
+  Comm comm;
+  ReduceWs ws{};
+  DBuf<double> ws_partials;
+  DBuf<unsigned> ws_ticket;
+  // device scalar slots + pinned host mirror
+  static constexpr int kSlots = 4096;
+  DBuf<double> d_scal;
+  double *h_scal = nullptr;
+  int slot_top = 0;
+  Stats st;
+
+  void init(int device_id);
+  void destroy();
+  int alloc_slots(int k) {
+    if (slot_top + k > kSlots) throw Error(-11, "out of device scalar slots");
+    const int s = slot_top;
+    slot_top += k;
+    return s;
+  }
+  double *slot(int i) { return d_scal.p + i; }
+  // copy `count` slots starting at `first` to the host (one sync)
+  const double *read_slots(int first, int count);
+  void sync() { NSK_HIP(hipStreamSynchronize(stream)); }
+
+  // ---- reductions with the cross-rank sum folded in (BlockVector::operator*, l2_norm) ----
+  void dot(int n, const double *x, const double *y, int slot_out);
+  void norm2(int n, const double *x, int slot_out);  // slot_out = sum of squares, slot_out+1 = norm
+  void axpy_dot(int n, SRef a, const double *x, double *y, const double *w, int slot_out);
+  void axpy_norm2(int n, SRef a, const double *x, double *y, int slot_out);
+  void cg_update(int n, SRef a, const double *d, const double *h, double *x, double *g, int slot_out);
+  void spmv(Csr &A, Space &colspace, const DVec &x, double *y, int mode = 0, const double *z = nullptr);
+};
+
+// pool of work vectors of one shape: [owned n | ghost ng]
+struct VecPool {
+  int n = 0, ng = 0;
+  std::vector<double *> free_list;
+  std::vector<double *> all;
+  Ctx *ctx = nullptr;
+  void init(Ctx *c, int n_, int ng_) { ctx = c; n = n_; ng = ng_; }
+  double *get(bool zero);
+  void put(double *p) { free_list.push_back(p); }
+  void destroy();
+  DVec view(double *p) const { return DVec{p, p + n, n}; }
+};
+
+}  // namespace nsk

@@ -1,0 +1,103 @@
+// nsk_kernels.h — launchers of the gfx950 kernels (nsk_kernels.hip).
+// All launchers are asynchronous on the given stream and never allocate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nsk {
+
+// A scalar operand that lives on the device: value = c * (*num) / (*den)
+// (null pointers count as 1).  Lets Krylov recurrences chain kernels without
+// a host round trip (one device->host scalar per iteration).
+struct SRef {
+  double c;
+  const double *num;
+  const double *den;
+};
+inline SRef sref(double c) { return SRef{c, nullptr, nullptr}; }
+inline SRef sref(double c, const double *num) { return SRef{c, num, nullptr}; }
+inline SRef sref(double c, const double *num, const double *den) { return SRef{c, num, den}; }
+
+// workspace of the grid-wide reductions (one per stream)
+struct ReduceWs {
+  double *partials;   // >= kMaxReduceBlocks * 2
+  unsigned *ticket;   // zero-initialised, reset by the last block
+};
+constexpr int kMaxReduceBlocks = 1024;
+
+// ---- CSR SpMV: y = A x | y += A x.  Columns >= n_own read x_ghost[col - n_own]. ----
+struct CsrView {
+  int n_rows;
+  int n_own_cols;
+  const int *rowptr;
+  const int *col;
+  const double *val;
+};
+// mode 0: y = A x ; 1: y += A x ; 2: y = z - A x
+void spmv(hipStream_t s, const CsrView &A, int lanes_per_row, const double *x_own, const double *x_ghost, double *y,
+          int mode, const double *z);
+// y_u = F x_u + Bt x_p in one pass (the (0,:) block row of jacobian_matrix.vmult)
+void spmv2(hipStream_t s, const CsrView &A, const double *xa_own, const double *xa_ghost, const CsrView &B,
+           const double *xb_own, const double *xb_ghost, double *y, int lanes_per_row);
+
+// ---- BLAS-1 with device scalars ----
+void vec_set(hipStream_t s, int n, double *y, double v);
+void vec_copy(hipStream_t s, int n, const double *x, double *y);
+void vec_equ(hipStream_t s, int n, SRef a, const double *x, double *y);                 // y = a x
+void vec_axpy(hipStream_t s, int n, SRef a, const double *x, double *y);                // y += a x
+void vec_sadd(hipStream_t s, int n, SRef sc, SRef a, const double *x, double *y);       // y = sc y + a x
+void vec_axpy2(hipStream_t s, int n, SRef a, const double *x, SRef b, const double *z, double *y);  // y += a x + b z
+void vec_scale(hipStream_t s, int n, SRef a, double *y);                                // y *= a
+void vec_mul(hipStream_t s, int n, const double *d, double *y);                         // y = y .* d
+void vec_submul(hipStream_t s, int n, const double *d, const double *x, double *y);     // y -= d .* x
+void vec_sub_then_mul(hipStream_t s, int n, const double *x, const double *d, double *y);  // y = (y - x) .* d
+void vec_recip(hipStream_t s, int n, const double *x, double *y);                       // y = 1 / x
+// reductions: results land in out[0] (and out[1] = sqrt(out[0]) when want_sqrt)
+void vec_dot(hipStream_t s, const ReduceWs &ws, int n, const double *x, const double *y, double *out, int want_sqrt);
+// y += a x ; out = y . w  (w may alias y)  — deal.II add_and_dot, one pass
+void vec_axpy_dot(hipStream_t s, const ReduceWs &ws, int n, SRef a, const double *x, double *y, const double *w,
+                  double *out, int want_sqrt);
+// CG update: x += a d ; g += a h ; out = g.g, out[1] = sqrt
+void vec_cg_update(hipStream_t s, const ReduceWs &ws, int n, SRef a, const double *d, const double *h, double *x,
+                   double *g, double *out);
+void scalar_sqrt(hipStream_t s, const double *in, double *out);                         // out = sqrt(|in|)
+void vec_gather(hipStream_t s, int n, const int *idx, const double *x, double *y);      // y[i] = x[idx[i]]
+void extract_diag(hipStream_t s, const CsrView &A, double *d, double *dinv);
+
+// ---- level-scheduled sparse triangular solves on a permuted CSR factor ----
+struct TriView {
+  int n;
+  const int *rowptr;
+  const int *diag;
+  const int *col;
+  const double *val;
+  const int *perm;  // perm[new] = old, or null
+};
+// kind: 0 = ILU(0) factor (unit L, U with diagonal), 1 = SGS on the matrix itself
+// lower: y[i] from rhs (natural order, gathered through perm); rows = level list
+void tri_lower_level(hipStream_t s, const TriView &T, int kind, int lpr, const int *rows, int nrows, const double *rhs,
+                     double *y);
+// upper: in place on y; also scatters the result to out (natural order)
+void tri_upper_level(hipStream_t s, const TriView &T, int kind, int lpr, const int *rows, int nrows, double *y,
+                     double *out);
+// runs of small levels inside one workgroup (levels [l0, l1) of lvl_ptr/rows)
+void tri_lower_serial(hipStream_t s, const TriView &T, int kind, const int *lvl_ptr, const int *rows, int l0, int l1,
+                      const double *rhs, double *y);
+void tri_upper_serial(hipStream_t s, const TriView &T, int kind, const int *lvl_ptr, const int *rows, int l0, int l1,
+                      double *y, double *out);
+// ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
+void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,
+                       const int *col, double *val, int max_row_nnz);
+void ilu0_factor_serial(hipStream_t s, const int *lvl_ptr, const int *rows, int l0, int l1, const int *rowptr,
+                        const int *diag, const int *col, double *val, int max_row_nnz);
+
+// ---- S = B diag(dinv) Bt, numeric phase on a fixed pattern ----
+// Rows of Bt for ghost columns of B come from Bt_ghost (may be null when n_ghost == 0).
+void spgemm_bdbt_numeric(hipStream_t s, const CsrView &B, const double *dinv_own, const double *dinv_ghost,
+                         const CsrView &Bt, const CsrView &Btg, const int *s_rowptr, const int *s_col, double *s_val,
+                         int n_rows, int max_row_nnz);
+
+// ---- halo pack ----
+void halo_pack(hipStream_t s, int n, const int *idx, const double *x, double *buf);
+
+}  // namespace nsk

@@ -1,0 +1,511 @@
+// nsk_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the Krylov /
+// block-preconditioner inner loop.  Everything here is HBM-bandwidth bound f64
+// streaming or gather work: no MFMA.  Conventions:
+//   * 256-thread workgroups (4 wavefronts); sub-wavefront row groups of LPR lanes.
+//   * reductions are two-stage and deterministic: per-block partials, then the
+//     last-arriving block (agent-scope release/acquire around a ticket) folds
+//     them in a fixed order, so a given n always sums in the same order.
+//   * scalars produced by reductions stay on the device (SRef) and feed the
+//     next kernel without a host round trip.
+#include "nsk_kernels.h"
+
+namespace nsk {
+
+namespace {
+
+constexpr int BLK = 256;
+
+__device__ __forceinline__ double sval(const SRef &s) {
+  double v = s.c;
+  if (s.num) v *= *s.num;
+  if (s.den) v /= *s.den;
+  return v;
+}
+
+template <int W>
+__device__ __forceinline__ double subwave_sum(double v) {
+#pragma unroll
+  for (int off = W / 2; off > 0; off >>= 1) v += __shfl_down(v, off, W);
+  return v;
+}
+
+inline int ew_grid(int n) {
+  long b = ((long)n + BLK * 4 - 1) / (BLK * 4);
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+inline int red_grid(int n) {
+  long b = ((long)n + BLK * 8 - 1) / (BLK * 8);
+  if (b < 1) b = 1;
+  if (b > kMaxReduceBlocks) b = kMaxReduceBlocks;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------ SpMV (CSR, LPR lanes per row)
+template <int LPR, int MODE>
+__global__ __launch_bounds__(BLK) void spmv_kernel(CsrView A, const double *__restrict__ xo,
+                                                   const double *__restrict__ xg, double *__restrict__ y,
+                                                   const double *__restrict__ z) {
+  const long tid = (long)blockIdx.x * BLK + threadIdx.x;
+  const int row = (int)(tid / LPR);
+  const int lane = (int)(tid % LPR);
+  double s = 0.0;
+  if (row < A.n_rows) {
+    const int re = A.rowptr[row + 1];
+    for (int k = A.rowptr[row] + lane; k < re; k += LPR) {
+      const int c = A.col[k];
+      const double xv = c < A.n_own_cols ? xo[c] : xg[c - A.n_own_cols];
+      s += A.val[k] * xv;
+    }
+  }
+  s = subwave_sum<LPR>(s);
+  if (lane == 0 && row < A.n_rows) {
+    if (MODE == 0) y[row] = s;
+    else if (MODE == 1) y[row] += s;
+    else y[row] = z[row] - s;
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(BLK) void spmv2_kernel(CsrView A, const double *__restrict__ xao,
+                                                    const double *__restrict__ xag, CsrView B,
+                                                    const double *__restrict__ xbo, const double *__restrict__ xbg,
+                                                    double *__restrict__ y) {
+  const long tid = (long)blockIdx.x * BLK + threadIdx.x;
+  const int row = (int)(tid / LPR);
+  const int lane = (int)(tid % LPR);
+  double s = 0.0;
+  if (row < A.n_rows) {
+    int re = A.rowptr[row + 1];
+    for (int k = A.rowptr[row] + lane; k < re; k += LPR) {
+      const int c = A.col[k];
+      s += A.val[k] * (c < A.n_own_cols ? xao[c] : xag[c - A.n_own_cols]);
+    }
+    re = B.rowptr[row + 1];
+    for (int k = B.rowptr[row] + lane; k < re; k += LPR) {
+      const int c = B.col[k];
+      s += B.val[k] * (c < B.n_own_cols ? xbo[c] : xbg[c - B.n_own_cols]);
+    }
+  }
+  s = subwave_sum<LPR>(s);
+  if (lane == 0 && row < A.n_rows) y[row] = s;
+}
+
+// ------------------------------------------------------------------ element-wise
+template <class F>
+__global__ __launch_bounds__(BLK) void ew_kernel(int n, F f) {
+  for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) f((int)i);
+}
+
+// ------------------------------------------------------------------ grid-wide deterministic reduction
+template <int NOUT>
+__device__ __forceinline__ void reduce_finish(double (&v)[NOUT], ReduceWs ws, double *out, int want_sqrt) {
+  __shared__ double wsum[NOUT][BLK / 64];
+  __shared__ int is_last;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    v[o] = subwave_sum<64>(v[o]);
+    if (lane == 0) wsum[o][w] = v[o];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      double s = 0.0;
+      for (int i = 0; i < BLK / 64; ++i) s += wsum[o][i];
+      __hip_atomic_store(&ws.partials[o * kMaxReduceBlocks + blockIdx.x], s, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();  // agent-scope release of the partials before the ticket
+    const unsigned t = atomicAdd(ws.ticket, 1u);
+    is_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (is_last) {
+    __threadfence();  // agent-scope acquire
+    double acc[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      acc[o] = 0.0;
+      for (int i = threadIdx.x; i < (int)gridDim.x; i += BLK)
+        acc[o] += __hip_atomic_load(&ws.partials[o * kMaxReduceBlocks + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc[o] = subwave_sum<64>(acc[o]);
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) wsum[o][w] = acc[o];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        double s = 0.0;
+        for (int i = 0; i < BLK / 64; ++i) s += wsum[o][i];
+        out[o] = s;
+      }
+      if (want_sqrt) out[NOUT] = sqrt(fabs(out[0]));
+      *ws.ticket = 0u;
+    }
+  }
+}
+
+template <class F>
+__global__ __launch_bounds__(BLK) void reduce1_kernel(int n, F f, ReduceWs ws, double *out, int want_sqrt) {
+  double v[1] = {0.0};
+  for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) v[0] += f((int)i);
+  reduce_finish<1>(v, ws, out, want_sqrt);
+}
+
+// ------------------------------------------------------------------ triangular solves
+template <int LPR, int KIND, bool LOWER>
+__device__ __forceinline__ void tri_row(const TriView &T, int i, int lane, const double *__restrict__ rhs,
+                                        double *__restrict__ y, double *__restrict__ out) {
+  const int d = T.diag[i];
+  int kb, ke;
+  if (LOWER) { kb = T.rowptr[i]; ke = d; } else { kb = d + 1; ke = T.rowptr[i + 1]; }
+  double s = 0.0;
+  for (int k = kb + lane; k < ke; k += LPR) s += T.val[k] * y[T.col[k]];
+  s = subwave_sum<LPR>(s);
+  if (lane == 0) {
+    const double dv = T.val[d];
+    double r;
+    if (LOWER) {
+      const double b = rhs[T.perm ? T.perm[i] : i];
+      r = KIND == 0 ? (b - s) : (b - s) / dv;  // ILU: unit L ; SGS: (D+L) y = b
+      y[i] = r;
+    } else {
+      r = KIND == 0 ? (y[i] - s) / dv : y[i] - s / dv;  // ILU: U x = y ; SGS: (D+U) x = D y
+      y[i] = r;
+      out[T.perm ? T.perm[i] : i] = r;
+    }
+  }
+}
+
+template <int LPR, int KIND, bool LOWER>
+__global__ __launch_bounds__(BLK) void tri_level_kernel(TriView T, const int *__restrict__ rows, int nrows,
+                                                        const double *__restrict__ rhs, double *__restrict__ y,
+                                                        double *__restrict__ out) {
+  const long tid = (long)blockIdx.x * BLK + threadIdx.x;
+  const int r = (int)(tid / LPR), lane = (int)(tid % LPR);
+  // every lane of a sub-wave shares r, so the shuffles below stay convergent
+  if (r < nrows) tri_row<LPR, KIND, LOWER>(T, rows[r], lane, rhs, y, out);
+}
+
+constexpr int SERIAL_BLK = 1024;
+template <int KIND, bool LOWER>
+__global__ __launch_bounds__(SERIAL_BLK) void tri_serial_kernel(TriView T, const int *__restrict__ lvl_ptr,
+                                                                const int *__restrict__ rows, int l0, int l1,
+                                                                const double *__restrict__ rhs, double *__restrict__ y,
+                                                                double *__restrict__ out) {
+  constexpr int LPR = 8;
+  const int sub = threadIdx.x / LPR, lane = threadIdx.x % LPR;
+  for (int l = l0; l < l1; ++l) {
+    const int b = lvl_ptr[l], e = lvl_ptr[l + 1];
+    for (int r = b + sub; r < e; r += SERIAL_BLK / LPR) tri_row<LPR, KIND, LOWER>(T, rows[r], lane, rhs, y, out);
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ ILU(0) numeric, one wavefront per row
+__device__ __forceinline__ void ilu0_row(int i, int lane, double *w, const int *__restrict__ rowptr,
+                                         const int *__restrict__ diag, const int *__restrict__ col, double *val) {
+  const int rs = rowptr[i], re = rowptr[i + 1], di = diag[i];
+  for (int k = rs + lane; k < re; k += 64) w[k - rs] = val[k];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int k = rs; k < di; ++k) {
+    const int c = col[k];
+    const int dc = diag[c];
+    const double l = w[k - rs] / val[dc];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) w[k - rs] = l;
+    const int ce = rowptr[c + 1];
+    for (int m = dc + 1 + lane; m < ce; m += 64) {
+      const int j = col[m];
+      int lo = k + 1, hi = re;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (col[mid] < j) lo = mid + 1; else hi = mid;
+      }
+      if (lo < re && col[lo] == j) w[lo - rs] -= l * val[m];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int k = rs + lane; k < re; k += 64) val[k] = w[k - rs];
+}
+
+__global__ __launch_bounds__(BLK) void ilu0_level_kernel(int nrows, const int *__restrict__ rows,
+                                                         const int *__restrict__ rowptr, const int *__restrict__ diag,
+                                                         const int *__restrict__ col, double *val, int max_nnz) {
+  extern __shared__ double lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (BLK / 64) + wave;
+  if (r < nrows) ilu0_row(rows[r], lane, lds + (size_t)wave * max_nnz, rowptr, diag, col, val);
+}
+
+__global__ __launch_bounds__(SERIAL_BLK) void ilu0_serial_kernel(const int *__restrict__ lvl_ptr,
+                                                                 const int *__restrict__ rows, int l0, int l1,
+                                                                 const int *__restrict__ rowptr,
+                                                                 const int *__restrict__ diag,
+                                                                 const int *__restrict__ col, double *val,
+                                                                 int max_nnz) {
+  extern __shared__ double lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int l = l0; l < l1; ++l) {
+    const int b = lvl_ptr[l], e = lvl_ptr[l + 1];
+    for (int r = b + wave; r < e; r += SERIAL_BLK / 64)
+      ilu0_row(rows[r], lane, lds + (size_t)wave * max_nnz, rowptr, diag, col, val);
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ S = B diag(dinv) Bt (numeric)
+__global__ __launch_bounds__(BLK) void spgemm_kernel(CsrView B, const double *__restrict__ dio,
+                                                     const double *__restrict__ dig, CsrView Bt, CsrView Btg,
+                                                     const int *__restrict__ srp, const int *__restrict__ scol,
+                                                     double *__restrict__ sval, int n_rows, int max_nnz) {
+  extern __shared__ double lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (BLK / 64) + wave;
+  if (i >= n_rows) return;
+  double *acc = lds + (size_t)wave * max_nnz;
+  const int ss = srp[i], se = srp[i + 1];
+  for (int k = lane; k < se - ss; k += 64) acc[k] = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int k = B.rowptr[i]; k < B.rowptr[i + 1]; ++k) {
+    const int m = B.col[k];
+    const bool own = m < B.n_own_cols;
+    const double a = B.val[k] * (own ? dio[m] : dig[m - B.n_own_cols]);
+    const CsrView &R = own ? Bt : Btg;
+    const int mr = own ? m : m - B.n_own_cols;
+    const int qe = R.rowptr[mr + 1];
+    for (int q = R.rowptr[mr] + lane; q < qe; q += 64) {
+      const int j = R.col[q];
+      int lo = ss, hi = se;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (scol[mid] < j) lo = mid + 1; else hi = mid;
+      }
+      acc[lo - ss] += a * R.val[q];  // the pattern is the structural product, so j is always present
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int k = lane; k < se - ss; k += 64) sval[ss + k] = acc[k];
+}
+
+template <int LPR, int MODE>
+void launch_spmv(hipStream_t s, const CsrView &A, const double *xo, const double *xg, double *y, const double *z) {
+  const long threads = (long)A.n_rows * LPR;
+  const int grid = (int)((threads + BLK - 1) / BLK);
+  if (grid > 0) hipLaunchKernelGGL((spmv_kernel<LPR, MODE>), dim3(grid), dim3(BLK), 0, s, A, xo, xg, y, z);
+}
+template <int LPR>
+void launch_spmv_mode(hipStream_t s, const CsrView &A, const double *xo, const double *xg, double *y, int mode,
+                      const double *z) {
+  if (mode == 0) launch_spmv<LPR, 0>(s, A, xo, xg, y, z);
+  else if (mode == 1) launch_spmv<LPR, 1>(s, A, xo, xg, y, z);
+  else launch_spmv<LPR, 2>(s, A, xo, xg, y, z);
+}
+
+template <int KIND, bool LOWER>
+void launch_tri_level(hipStream_t s, const TriView &T, int lpr, const int *rows, int nrows, const double *rhs,
+                      double *y, double *out) {
+  if (nrows <= 0) return;
+#define NSK_TRI_CASE(L)                                                                                      \
+  case L: {                                                                                                  \
+    const int grid = (int)(((long)nrows * L + BLK - 1) / BLK);                                               \
+    hipLaunchKernelGGL((tri_level_kernel<L, KIND, LOWER>), dim3(grid), dim3(BLK), 0, s, T, rows, nrows, rhs, y, out); \
+  } break;
+  switch (lpr) {
+    NSK_TRI_CASE(4)
+    NSK_TRI_CASE(8)
+    NSK_TRI_CASE(16)
+    NSK_TRI_CASE(32)
+    default: NSK_TRI_CASE(64)
+  }
+#undef NSK_TRI_CASE
+}
+
+}  // namespace
+
+// ================================================================== launchers
+void spmv(hipStream_t s, const CsrView &A, int lpr, const double *xo, const double *xg, double *y, int mode,
+          const double *z) {
+  switch (lpr) {
+    case 2: launch_spmv_mode<2>(s, A, xo, xg, y, mode, z); break;
+    case 4: launch_spmv_mode<4>(s, A, xo, xg, y, mode, z); break;
+    case 8: launch_spmv_mode<8>(s, A, xo, xg, y, mode, z); break;
+    case 16: launch_spmv_mode<16>(s, A, xo, xg, y, mode, z); break;
+    case 32: launch_spmv_mode<32>(s, A, xo, xg, y, mode, z); break;
+    default: launch_spmv_mode<64>(s, A, xo, xg, y, mode, z); break;
+  }
+}
+
+void spmv2(hipStream_t s, const CsrView &A, const double *xao, const double *xag, const CsrView &B, const double *xbo,
+           const double *xbg, double *y, int lpr) {
+  const int L = lpr >= 32 ? 32 : (lpr >= 16 ? 16 : 8);
+  const int grid = (int)(((long)A.n_rows * L + BLK - 1) / BLK);
+  if (grid <= 0) return;
+  if (L == 32) hipLaunchKernelGGL((spmv2_kernel<32>), dim3(grid), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, y);
+  else if (L == 16) hipLaunchKernelGGL((spmv2_kernel<16>), dim3(grid), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, y);
+  else hipLaunchKernelGGL((spmv2_kernel<8>), dim3(grid), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, y);
+}
+
+#define NSK_EW(n, ...)                                                                       \
+  do {                                                                                       \
+    if ((n) > 0) {                                                                           \
+      auto f__ = __VA_ARGS__;                                                                \
+      hipLaunchKernelGGL((ew_kernel<decltype(f__)>), dim3(ew_grid(n)), dim3(BLK), 0, s, n, f__); \
+    }                                                                                        \
+  } while (0)
+
+void vec_set(hipStream_t s, int n, double *y, double v) { NSK_EW(n, [=] __device__(int i) { y[i] = v; }); }
+void vec_copy(hipStream_t s, int n, const double *x, double *y) { NSK_EW(n, [=] __device__(int i) { y[i] = x[i]; }); }
+void vec_equ(hipStream_t s, int n, SRef a, const double *x, double *y) {
+  NSK_EW(n, [=] __device__(int i) { y[i] = sval(a) * x[i]; });
+}
+void vec_axpy(hipStream_t s, int n, SRef a, const double *x, double *y) {
+  NSK_EW(n, [=] __device__(int i) { y[i] += sval(a) * x[i]; });
+}
+void vec_sadd(hipStream_t s, int n, SRef sc, SRef a, const double *x, double *y) {
+  NSK_EW(n, [=] __device__(int i) { y[i] = sval(sc) * y[i] + sval(a) * x[i]; });
+}
+void vec_axpy2(hipStream_t s, int n, SRef a, const double *x, SRef b, const double *z, double *y) {
+  NSK_EW(n, [=] __device__(int i) { y[i] += sval(a) * x[i] + sval(b) * z[i]; });
+}
+void vec_scale(hipStream_t s, int n, SRef a, double *y) { NSK_EW(n, [=] __device__(int i) { y[i] *= sval(a); }); }
+void vec_mul(hipStream_t s, int n, const double *d, double *y) { NSK_EW(n, [=] __device__(int i) { y[i] *= d[i]; }); }
+void vec_submul(hipStream_t s, int n, const double *d, const double *x, double *y) {
+  NSK_EW(n, [=] __device__(int i) { y[i] -= d[i] * x[i]; });
+}
+void vec_sub_then_mul(hipStream_t s, int n, const double *x, const double *d, double *y) {
+  NSK_EW(n, [=] __device__(int i) { y[i] = (y[i] - x[i]) * d[i]; });
+}
+void vec_recip(hipStream_t s, int n, const double *x, double *y) {
+  NSK_EW(n, [=] __device__(int i) { y[i] = 1.0 / x[i]; });
+}
+void scalar_sqrt(hipStream_t s, const double *in, double *out) {
+  const int n = 1;
+  NSK_EW(n, [=] __device__(int) { out[0] = sqrt(fabs(in[0])); });
+}
+void vec_gather(hipStream_t s, int n, const int *idx, const double *x, double *y) {
+  NSK_EW(n, [=] __device__(int i) { y[i] = x[idx[i]]; });
+}
+void halo_pack(hipStream_t s, int n, const int *idx, const double *x, double *buf) { vec_gather(s, n, idx, x, buf); }
+
+void extract_diag(hipStream_t s, const CsrView &A, double *d, double *dinv) {
+  const int n = A.n_rows;
+  NSK_EW(n, [=] __device__(int i) {
+    double v = 0.0;
+    for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+      if (A.col[k] == i) v = A.val[k];
+    d[i] = v;
+    dinv[i] = 1.0 / v;
+  });
+}
+
+#define NSK_RED(n, ...)                                                                                  \
+  do {                                                                                                   \
+    auto f__ = __VA_ARGS__;                                                                              \
+    hipLaunchKernelGGL((reduce1_kernel<decltype(f__)>), dim3(red_grid(n)), dim3(BLK), 0, s, n, f__, ws, out, \
+                       want_sqrt);                                                                       \
+  } while (0)
+
+void vec_dot(hipStream_t s, const ReduceWs &ws, int n, const double *x, const double *y, double *out, int want_sqrt) {
+  NSK_RED(n, [=] __device__(int i) -> double { return x[i] * y[i]; });
+}
+void vec_axpy_dot(hipStream_t s, const ReduceWs &ws, int n, SRef a, const double *x, double *y, const double *w,
+                  double *out, int want_sqrt) {
+  if (w == y) {
+    NSK_RED(n, [=] __device__(int i) -> double {
+      const double v = y[i] + sval(a) * x[i];
+      y[i] = v;
+      return v * v;
+    });
+  } else {
+    NSK_RED(n, [=] __device__(int i) -> double {
+      const double v = y[i] + sval(a) * x[i];
+      y[i] = v;
+      return v * w[i];
+    });
+  }
+}
+void vec_cg_update(hipStream_t s, const ReduceWs &ws, int n, SRef a, const double *d, const double *h, double *x,
+                   double *g, double *out) {
+  const int want_sqrt = 1;
+  NSK_RED(n, [=] __device__(int i) -> double {
+    const double al = sval(a);
+    x[i] += al * d[i];
+    const double v = g[i] + al * h[i];
+    g[i] = v;
+    return v * v;
+  });
+}
+
+void tri_lower_level(hipStream_t s, const TriView &T, int kind, int lpr, const int *rows, int nrows, const double *rhs,
+                     double *y) {
+  if (kind == 0) launch_tri_level<0, true>(s, T, lpr, rows, nrows, rhs, y, nullptr);
+  else launch_tri_level<1, true>(s, T, lpr, rows, nrows, rhs, y, nullptr);
+}
+void tri_upper_level(hipStream_t s, const TriView &T, int kind, int lpr, const int *rows, int nrows, double *y,
+                     double *out) {
+  if (kind == 0) launch_tri_level<0, false>(s, T, lpr, rows, nrows, nullptr, y, out);
+  else launch_tri_level<1, false>(s, T, lpr, rows, nrows, nullptr, y, out);
+}
+void tri_lower_serial(hipStream_t s, const TriView &T, int kind, const int *lvl_ptr, const int *rows, int l0, int l1,
+                      const double *rhs, double *y) {
+  if (l1 <= l0) return;
+  if (kind == 0)
+    hipLaunchKernelGGL((tri_serial_kernel<0, true>), dim3(1), dim3(SERIAL_BLK), 0, s, T, lvl_ptr, rows, l0, l1, rhs, y,
+                       (double *)nullptr);
+  else
+    hipLaunchKernelGGL((tri_serial_kernel<1, true>), dim3(1), dim3(SERIAL_BLK), 0, s, T, lvl_ptr, rows, l0, l1, rhs, y,
+                       (double *)nullptr);
+}
+void tri_upper_serial(hipStream_t s, const TriView &T, int kind, const int *lvl_ptr, const int *rows, int l0, int l1,
+                      double *y, double *out) {
+  if (l1 <= l0) return;
+  if (kind == 0)
+    hipLaunchKernelGGL((tri_serial_kernel<0, false>), dim3(1), dim3(SERIAL_BLK), 0, s, T, lvl_ptr, rows, l0, l1,
+                       (const double *)nullptr, y, out);
+  else
+    hipLaunchKernelGGL((tri_serial_kernel<1, false>), dim3(1), dim3(SERIAL_BLK), 0, s, T, lvl_ptr, rows, l0, l1,
+                       (const double *)nullptr, y, out);
+}
+
+void ilu0_factor_level(hipStream_t s, int nrows, const int *rows, const int *rowptr, const int *diag, const int *col,
+                       double *val, int max_row_nnz) {
+  if (nrows <= 0) return;
+  const int grid = (nrows + BLK / 64 - 1) / (BLK / 64);
+  const size_t lds = sizeof(double) * (size_t)max_row_nnz * (BLK / 64);
+  hipLaunchKernelGGL(ilu0_level_kernel, dim3(grid), dim3(BLK), lds, s, nrows, rows, rowptr, diag, col, val,
+                     max_row_nnz);
+}
+void ilu0_factor_serial(hipStream_t s, const int *lvl_ptr, const int *rows, int l0, int l1, const int *rowptr,
+                        const int *diag, const int *col, double *val, int max_row_nnz) {
+  if (l1 <= l0) return;
+  const size_t lds = sizeof(double) * (size_t)max_row_nnz * (SERIAL_BLK / 64);
+  hipLaunchKernelGGL(ilu0_serial_kernel, dim3(1), dim3(SERIAL_BLK), lds, s, lvl_ptr, rows, l0, l1, rowptr, diag, col,
+                     val, max_row_nnz);
+}
+
+void spgemm_bdbt_numeric(hipStream_t s, const CsrView &B, const double *dio, const double *dig, const CsrView &Bt,
+                         const CsrView &Btg, const int *s_rowptr, const int *s_col, double *s_val, int n_rows,
+                         int max_row_nnz) {
+  if (n_rows <= 0) return;
+  const int grid = (n_rows + BLK / 64 - 1) / (BLK / 64);
+  const size_t lds = sizeof(double) * (size_t)max_row_nnz * (BLK / 64);
+  hipLaunchKernelGGL(spgemm_kernel, dim3(grid), dim3(BLK), lds, s, B, dio, dig, Bt, Btg, s_rowptr, s_col, s_val,
+                     n_rows, max_row_nnz);
+}
+
+}  // namespace nsk

@@ -1,0 +1,230 @@
+// nsk_tri.cpp — host symbolic analysis + device numeric/apply of ILU(0) and SGS.
+#include "nsk_tri.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+namespace nsk {
+
+namespace {
+constexpr int kSerialThreshold = 1024;  // levels smaller than this are fused into single-workgroup runs
+
+void build_schedule(const std::vector<int> &lvl_ptr, std::vector<TriSolve::Step> &sched) {
+  sched.clear();
+  const int nl = (int)lvl_ptr.size() - 1;
+  int l = 0;
+  while (l < nl) {
+    const int sz = lvl_ptr[l + 1] - lvl_ptr[l];
+    if (sz >= kSerialThreshold) {
+      sched.push_back(TriSolve::Step{0, l, l + 1, lvl_ptr[l], sz});
+      ++l;
+    } else {
+      int e = l;
+      while (e < nl && lvl_ptr[e + 1] - lvl_ptr[e] < kSerialThreshold) ++e;
+      sched.push_back(TriSolve::Step{1, l, e, lvl_ptr[l], lvl_ptr[e] - lvl_ptr[l]});
+      l = e;
+    }
+  }
+}
+
+void level_lists(const std::vector<int> &level, int n_levels, std::vector<int> &lvl_ptr, std::vector<int> &rows) {
+  const int n = (int)level.size();
+  lvl_ptr.assign(n_levels + 1, 0);
+  for (int i = 0; i < n; ++i) ++lvl_ptr[level[i] + 1];
+  for (int l = 0; l < n_levels; ++l) lvl_ptr[l + 1] += lvl_ptr[l];
+  rows.resize(n);
+  std::vector<int> cur(lvl_ptr.begin(), lvl_ptr.end() - 1);
+  for (int i = 0; i < n; ++i) rows[cur[level[i]]++] = i;  // ascending row id inside a level
+}
+}  // namespace
+
+void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off) {
+  ctx = c;
+  n = A.n_rows;
+  kind = kind_;
+  ordering = ordering_;
+  const std::vector<int> &rp = A.h_rowptr, &cl = A.h_col;
+  if ((int)rp.size() != n + 1) throw Error(-30, "TriSolve::analyze: host pattern missing");
+
+  // emulated-rank id of every row (additive Schwarz, overlap 0, inside this GPU)
+  std::vector<int> shard;
+  const bool sharded = sub_off.size() > 2;
+  if (sharded) {
+    shard.resize(n);
+    for (size_t s = 0; s + 1 < sub_off.size(); ++s)
+      for (int i = sub_off[s]; i < sub_off[s + 1]; ++i) shard[i] = (int)s;
+  }
+  auto keep = [&](int i, int cc) { return cc < n && (!sharded || shard[cc] == shard[i]); };
+
+  // restricted pattern R (local square block, cross-shard couplings dropped) and where each entry sits in A
+  std::vector<int> rrp(n + 1, 0);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    int cnt = 0;
+    for (int k = rp[i]; k < rp[i + 1]; ++k) cnt += keep(i, cl[k]) ? 1 : 0;
+    rrp[i + 1] = cnt;
+  }
+  for (int i = 0; i < n; ++i) rrp[i + 1] += rrp[i];
+  nnz = rrp[n];
+  std::vector<int> rcol((size_t)nnz), rpos((size_t)nnz);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    int w = rrp[i];
+    for (int k = rp[i]; k < rp[i + 1]; ++k)
+      if (keep(i, cl[k])) { rcol[w] = cl[k]; rpos[w] = k; ++w; }
+  }
+
+  perm.clear();
+  std::vector<int> pcolor;
+  n_colors = 0;
+  if (ordering == ORDER_MULTICOLOR) {
+    // greedy distance-1 colouring on the graph of R + R^T, rows visited in natural order
+    std::vector<int> trp(n + 1, 0);
+    for (int64_t k = 0; k < nnz; ++k) ++trp[rcol[k] + 1];
+    for (int i = 0; i < n; ++i) trp[i + 1] += trp[i];
+    std::vector<int> tcol((size_t)nnz), cur(trp.begin(), trp.end() - 1);
+    for (int i = 0; i < n; ++i)
+      for (int k = rrp[i]; k < rrp[i + 1]; ++k) tcol[cur[rcol[k]]++] = i;
+    std::vector<int> color(n, -1), mark;
+    for (int i = 0; i < n; ++i) {
+      auto visit = [&](int j) {
+        const int cj = color[j];
+        if (cj >= 0) {
+          if (cj >= (int)mark.size()) mark.resize(cj + 1, -1);
+          mark[cj] = i;
+        }
+      };
+      for (int k = rrp[i]; k < rrp[i + 1]; ++k) if (rcol[k] != i) visit(rcol[k]);
+      for (int k = trp[i]; k < trp[i + 1]; ++k) if (tcol[k] != i) visit(tcol[k]);
+      int cc = 0;
+      while (cc < (int)mark.size() && mark[cc] == i) ++cc;
+      color[i] = cc;
+      if (cc + 1 > n_colors) n_colors = cc + 1;
+    }
+    // perm: colours ascending, natural order inside a colour (counting sort, stable)
+    std::vector<int> cptr(n_colors + 1, 0);
+    for (int i = 0; i < n; ++i) ++cptr[color[i] + 1];
+    for (int q = 0; q < n_colors; ++q) cptr[q + 1] += cptr[q];
+    perm.resize(n);
+    pcolor.resize(n);
+    for (int i = 0; i < n; ++i) { const int w = cptr[color[i]]++; perm[w] = i; pcolor[w] = color[i]; }
+  }
+
+  // permuted CSR (sorted columns), source position of every entry, diagonal positions
+  std::vector<int> iperm;
+  if (!perm.empty()) {
+    iperm.resize(n);
+    for (int i = 0; i < n; ++i) iperm[perm[i]] = i;
+  }
+  std::vector<int> prp(n + 1, 0), pcol((size_t)nnz), psrc((size_t)nnz), pdiag(n, -1);
+  for (int i = 0; i < n; ++i) {
+    const int r = perm.empty() ? i : perm[i];
+    prp[i + 1] = prp[i] + (rrp[r + 1] - rrp[r]);
+  }
+  int maxw = 0;
+  bool missing_diag = false;
+#pragma omp parallel
+  {
+    std::vector<std::pair<int, int>> buf;
+    int lmax = 0;
+    bool lmiss = false;
+#pragma omp for schedule(static)
+    for (int i = 0; i < n; ++i) {
+      const int r = perm.empty() ? i : perm[i];
+      buf.clear();
+      for (int k = rrp[r]; k < rrp[r + 1]; ++k)
+        buf.emplace_back(perm.empty() ? rcol[k] : iperm[rcol[k]], rpos[k]);
+      std::sort(buf.begin(), buf.end());
+      int w = prp[i];
+      for (auto &e : buf) {
+        pcol[w] = e.first;
+        psrc[w] = e.second;
+        if (e.first == i) pdiag[i] = w;
+        ++w;
+      }
+      lmax = std::max(lmax, (int)buf.size());
+      if (pdiag[i] < 0) lmiss = true;
+    }
+#pragma omp critical
+    {
+      maxw = std::max(maxw, lmax);
+      missing_diag = missing_diag || lmiss;
+    }
+  }
+  if (missing_diag) throw Error(-31, "TriSolve::analyze: a row has no diagonal entry");
+  max_row_nnz = maxw;
+  if (max_row_nnz > 448) throw Error(-32, "TriSolve::analyze: row too long for the LDS-staged ILU kernel");
+
+  // level schedule of the lower and upper dependency DAGs
+  std::vector<int> levL(n, 0), levU(n, 0);
+  n_levels_L = n_levels_U = 0;
+  if (!perm.empty()) {
+    // colour classes are independent sets: level = colour is a valid schedule for both DAGs
+    // and keeps every level one contiguous run of rows
+    for (int i = 0; i < n; ++i) { levL[i] = pcolor[i]; levU[i] = n_colors - 1 - pcolor[i]; }
+    n_levels_L = n_levels_U = n_colors;
+  } else
+  for (int i = 0; i < n; ++i) {
+    int l = 0;
+    for (int k = prp[i]; k < pdiag[i]; ++k) l = std::max(l, levL[pcol[k]] + 1);
+    levL[i] = l;
+    n_levels_L = std::max(n_levels_L, l + 1);
+  }
+  if (perm.empty())
+  for (int i = n - 1; i >= 0; --i) {
+    int l = 0;
+    for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k) l = std::max(l, levU[pcol[k]] + 1);
+    levU[i] = l;
+    n_levels_U = std::max(n_levels_U, l + 1);
+  }
+  if (n == 0) n_levels_L = n_levels_U = 0;
+  std::vector<int> hLp, hLr, hUp, hUr;
+  level_lists(levL, n_levels_L, hLp, hLr);
+  level_lists(levU, n_levels_U, hUp, hUr);
+  build_schedule(hLp, schedL);
+  build_schedule(hUp, schedU);
+
+  const double mean_half = n > 0 ? 0.5 * (double)nnz / n : 0.0;
+  lpr = mean_half <= 6 ? 4 : (mean_half <= 14 ? 8 : (mean_half <= 48 ? 16 : 32));
+
+  hipStream_t s = ctx->stream;
+  rowptr.upload(prp, s);
+  col.upload(pcol, s);
+  srcpos.upload(psrc, s);
+  diag.upload(pdiag, s);
+  if (!perm.empty()) d_perm.upload(perm, s);
+  lvlL_ptr.upload(hLp, s);
+  lvlL_rows.upload(hLr, s);
+  lvlU_ptr.upload(hUp, s);
+  lvlU_rows.upload(hUr, s);
+  val.alloc((size_t)nnz);
+  y.alloc((size_t)n + 1);
+  ctx->sync();  // host staging vectors die at scope exit
+}
+
+void TriSolve::numeric(const double *a_val_dev) {
+  hipStream_t s = ctx->stream;
+  vec_gather(s, (int)nnz, srcpos.p, a_val_dev, val.p);
+  if (kind != 0) return;
+  for (const Step &st : schedL) {
+    if (st.serial) ilu0_factor_serial(s, lvlL_ptr.p, lvlL_rows.p, st.l0, st.l1, rowptr.p, diag.p, col.p, val.p, max_row_nnz);
+    else ilu0_factor_level(s, st.nrows, lvlL_rows.p + st.row_off, rowptr.p, diag.p, col.p, val.p, max_row_nnz);
+  }
+}
+
+void TriSolve::apply(const double *b, double *x) {
+  hipStream_t s = ctx->stream;
+  const TriView T = view();
+  for (const Step &st : schedL) {
+    if (st.serial) tri_lower_serial(s, T, kind, lvlL_ptr.p, lvlL_rows.p, st.l0, st.l1, b, y.p);
+    else tri_lower_level(s, T, kind, lpr, lvlL_rows.p + st.row_off, st.nrows, b, y.p);
+  }
+  for (const Step &st : schedU) {
+    if (st.serial) tri_upper_serial(s, T, kind, lvlU_ptr.p, lvlU_rows.p, st.l0, st.l1, y.p, x);
+    else tri_upper_level(s, T, kind, lpr, lvlU_rows.p + st.row_off, st.nrows, y.p, x);
+  }
+  ++ctx->st.tri_applies;
+  ctx->st.tri_bytes += (double)apply_bytes();
+}
+
+}  // namespace nsk

@@ -1,0 +1,51 @@
+// nsk_tri.hpp — rank-local triangular preconditioners on the GPU:
+//   TrilinosWrappers::PreconditionILU  (Ifpack "ILU", level 0, overlap 0)   NSSolverStationary.hpp:231,325-326
+//   TrilinosWrappers::PreconditionSSOR (Ifpack point relaxation, SGS, 1 sweep) NSSolverStationary.hpp:160,166
+// Both are two sparse triangular solves on the rank-local diagonal block.  The
+// dependency DAG is level-scheduled on the host once per sparsity pattern; the
+// numeric ILU(0) factorisation and every apply run on the device.
+//
+// Ordering: NATURAL keeps the caller's DoF order (exactly what one MPI rank of
+// the reference factorises, but a lattice ordering has O(nx+ny) levels of a few
+// hundred rows each).  MULTICOLOR applies a rank-local symmetric permutation
+// from a greedy distance-1 colouring first: ILU(0)/SGS of P A P^T has as many
+// levels as colours (~34 for the Q3 velocity block), each level a contiguous
+// run of rows — the form a GPU can stream.  The permutation is internal: rhs and
+// result stay in the caller's order.
+#pragma once
+#include "nsk_core.hpp"
+
+namespace nsk {
+
+enum { ORDER_NATURAL = 0, ORDER_MULTICOLOR = 1 };
+
+struct TriSolve {
+  Ctx *ctx = nullptr;
+  int n = 0;
+  int kind = 0;  // 0 ILU(0), 1 SGS
+  int ordering = ORDER_NATURAL;
+  int n_colors = 0, n_levels_L = 0, n_levels_U = 0;
+  int64_t nnz = 0;
+  int max_row_nnz = 0;
+  int lpr = 8;
+  std::vector<int> perm;  // perm[new] = old (empty: identity)
+
+  DBuf<int> rowptr, diag, col, srcpos, d_perm, lvlL_ptr, lvlL_rows, lvlU_ptr, lvlU_rows;
+  DBuf<double> val, y;
+  struct Step {
+    int serial;  // 1: run of small levels in one workgroup
+    int l0, l1;  // level range
+    int row_off, nrows;
+  };
+  std::vector<Step> schedL, schedU;
+
+  // A: host pattern of the local block (columns >= A.n_rows, i.e. ghosts, are dropped);
+  // sub_off: optional n_sub+1 offsets of emulated MPI ranks inside this GPU (block Jacobi)
+  void analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off);
+  void numeric(const double *a_val_dev);           // refresh values (+ factorise for ILU)
+  void apply(const double *b, double *x);          // x = M^{-1} b, caller's ordering
+  TriView view() const { return TriView{n, rowptr.p, diag.p, col.p, val.p, perm.empty() ? nullptr : d_perm.p}; }
+  size_t apply_bytes() const { return (size_t)12 * nnz + 8 * ((size_t)n + 1) * 2 + 16 * (size_t)n; }
+};
+
+}  // namespace nsk

@@ -1,0 +1,231 @@
+"""GPU parity tests: every call goes through the C ABI (libnsk_hip.so) and is compared with the
+CPU oracle on the same inputs.  Tolerances (f64 everywhere, SURVEY 8c tier 2):
+  SpMV / axpy-like ops  : <= 1e-13 relative, element-wise (same products, different summation tree)
+  dots / norms           : <= 1e-12 relative (reduction order differs)
+  ILU(0)/SGS applies     : <= 1e-11 relative (factorisation + two solves, FMA contraction on the GPU)
+  full solves            : true residual <= tol, and ||x_gpu - x_oracle||_inf / ||x_oracle||_inf <= 1e-7
+                           at tol = 1e-12 (both are iterates of a Krylov method stopped on the residual)
+"""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spl
+
+from tests.util import problem, rel_err, rng_vec
+
+pytestmark = pytest.mark.gpu
+
+
+def _S():
+    from navier_stokes_solver_amd import solver as S
+    return S
+
+
+def _O():
+    from oracle import oracle as O
+    return O
+
+
+@pytest.fixture(scope="module")
+def handles():
+    S = _S()
+    cache = {}
+
+    def get(name, ordering=0, subdomains=1):
+        key = (name, ordering, subdomains)
+        if key not in cache:
+            ls = S.LinearSolver()
+            ls.set_problem(problem(name))
+            ls.set_option(S.OPT_TRI_ORDERING, ordering)
+            ls.set_option(S.OPT_SUBDOMAINS, subdomains)
+            cache[key] = ls
+        return cache[key]
+
+    yield get
+    for ls in cache.values():
+        ls.close()
+
+
+def test_library_is_the_hip_one():
+    S = _S()
+    import os
+    assert os.path.exists(S.library_path())
+    S.lib()
+    with open(f"/proc/{os.getpid()}/maps") as f:
+        assert "libnsk_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("name", ["stokes16", "ns60"])
+def test_spmv_blocks(handles, name):
+    S, O = _S(), _O()
+    pr = problem(name)
+    ls = handles(name)
+    for blk, csr in ((S.BLK_F, pr.F), (S.BLK_BT, pr.Bt), (S.BLK_B, pr.B), (S.BLK_MP, pr.Mp)):
+        x = rng_vec(csr.cols, 1234 + blk)
+        ref = O.spmv(O.CsrHolder.from_block(csr), x)
+        got = ls.spmv(blk, x)
+        assert rel_err(got, ref) <= 1e-13, (name, blk)
+        y0 = rng_vec(csr.rows, 77)
+        ref2 = O.spmv(O.CsrHolder.from_block(csr), x, y0, add=True)
+        got2 = ls.spmv(blk, x, y0, add=True)
+        assert rel_err(got2, ref2) <= 1e-13
+
+
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_jacobian_vmult(handles, fuse):
+    S = _S()
+    pr = problem("ns60")
+    ls = handles("ns60")
+    ls.set_option(S.OPT_FUSE_BLOCK_ROW, fuse)
+    xu, xp = rng_vec(pr.n_u, 1), rng_vec(pr.n_p, 2)
+    yu, yp = ls.jacobian_vmult(xu, xp)
+    J = pr.jacobian_scipy()
+    ref = J @ np.concatenate([xu, xp])
+    assert rel_err(np.concatenate([yu, yp]), ref) <= 1e-13
+    ls.set_option(S.OPT_FUSE_BLOCK_ROW, 1)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 257, 100003, 1 << 21])
+def test_dot_norm(handles, n):
+    ls = handles("stokes16")
+    x, y = rng_vec(n, 5), rng_vec(n, 6)
+    d, nrm = ls.dot(x, y)
+    assert abs(d - float(np.dot(x, y))) <= 1e-12 * max(1.0, float(np.abs(x * y).sum()))
+    assert abs(nrm - float(np.linalg.norm(x))) <= 1e-12 * float(np.linalg.norm(x))
+    d2, _ = ls.dot(x, y)
+    assert d2 == d  # fixed summation order: bitwise reproducible
+
+
+@pytest.mark.parametrize("name", ["ns16", "ns60"])
+@pytest.mark.parametrize("ordering", [0, 1])
+@pytest.mark.parametrize("subdomains", [1, 3])
+def test_ilu_apply(handles, name, ordering, subdomains):
+    S, O = _S(), _O()
+    pr = problem(name)
+    ls = handles(name, ordering, subdomains)
+    ls.setup_preconditioner(S.BLOCK_DIAGONAL, S.UNSTEADY)  # ILU(F), ILU(Mp)
+    for which, csr, n in ((S.TRI_VELOCITY, pr.F, pr.n_u), (S.TRI_PRESSURE, pr.Mp, pr.n_p)):
+        perm = ls.tri_perm(which)
+        off = None
+        if subdomains > 1:
+            off = [(n * k // subdomains) & (~1 if which == S.TRI_VELOCITY else ~0) for k in range(subdomains)] + [n]
+        tri = O.Tri(O.CsrHolder.from_block(csr), kind=0, shard_off=off, perm=perm if ordering else None)
+        b = rng_vec(n, 11 + which)
+        assert rel_err(ls.tri_apply(which, b), tri.apply(b)) <= 1e-11, (name, ordering, subdomains, which)
+    st = ls.stats()
+    if ordering:
+        assert 0 < st["n_colors_u"] <= 64 and st["n_levels_u"] == st["n_colors_u"]
+
+
+@pytest.mark.parametrize("ordering", [0, 1])
+def test_sgs_apply(handles, ordering):
+    S, O = _S(), _O()
+    pr = problem("stokes16")
+    ls = handles("stokes16", ordering)
+    ls.setup_preconditioner(S.BLOCK_DIAGONAL, S.STATIONARY)  # SSOR(F), SSOR(Mp)
+    for which, csr, n in ((S.TRI_VELOCITY, pr.F, pr.n_u), (S.TRI_PRESSURE, pr.Mp, pr.n_p)):
+        perm = ls.tri_perm(which)
+        tri = O.Tri(O.CsrHolder.from_block(csr), kind=1, perm=perm if ordering else None)
+        b = rng_vec(n, 21 + which)
+        assert rel_err(ls.tri_apply(which, b), tri.apply(b)) <= 1e-11
+
+
+@pytest.mark.parametrize("name", ["stokes16", "ns60"])
+def test_schur_spgemm(handles, name):
+    S, O = _S(), _O()
+    pr = problem(name)
+    ls = handles(name)
+    ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+    rp, col, val = ls.get_block(S.BLK_S)
+    dinv = 1.0 / pr.F.to_scipy().diagonal()
+    orp, ocol, oval = O.spgemm_adb(O.CsrHolder.from_block(pr.B), dinv, O.CsrHolder.from_block(pr.Bt))
+    assert np.array_equal(rp, orp) and np.array_equal(col, ocol)
+    assert rel_err(val, oval) <= 1e-13
+
+
+@pytest.mark.parametrize("prec,variant", [(2, 1), (2, 0), (0, 0), (0, 1), (1, 0), (1, 1)])
+def test_precond_vmult(handles, prec, variant):
+    """One (and two consecutive: stale delta_p / dst as initial guess) applications."""
+    S, O = _S(), _O()
+    name = "unsteady16" if variant == 1 else "ns16"
+    pr = problem(name)
+    ls = handles(name)
+    ls.setup_preconditioner(prec, variant, 0.5)
+    src = rng_vec(pr.n, 31)
+    src /= np.linalg.norm(src)
+    op = O.OracleProblem.from_local(pr)
+    for calls in (1, 2):
+        ls.setup_preconditioner(prec, variant, 0.5)  # fresh object, as solve_system() builds one per call
+        du, dp, rc = ls.precond_vmult(src[:pr.n_u], src[pr.n_u:], calls=calls)
+        ref, orc = op.prec_apply(src, prec=prec, variant=variant, alpha=0.5, calls=calls)
+        assert rc == 0 and orc == 0
+        tol = 1e-10 if (prec == 2 and variant == 1) else 1e-7
+        assert rel_err(np.concatenate([du, dp]), ref) <= tol, (prec, variant, calls)
+
+
+SOLVE_CASES = [
+    # (problem, solver, prec, variant, tol)
+    ("stokes16", 1, 0, 0, 1e-12),   # the reference's CPU config family: FGMRES + blockDiagonal on a Stokes system
+    ("ns16", 1, 0, 0, 1e-12),
+    ("ns16", 1, 1, 0, 1e-12),
+    ("ns16", 1, 2, 0, 1e-12),       # north-star: FGMRES + aSIMPLE
+    ("unsteady16", 1, 0, 1, 1e-12),
+    ("unsteady16", 1, 1, 1, 1e-12),
+    ("unsteady16", 1, 2, 1, 1e-12),
+    ("unsteady16", 0, 2, 1, 1e-12),  # GMRES (left preconditioning) with a fixed linear preconditioner
+    ("unsteady16", 2, 2, 1, 1e-4),   # BiCGStab: deal.II's absolute breakdown threshold 1e-10 forbids tighter
+]
+
+
+@pytest.mark.parametrize("name,solver,prec,variant,tol", SOLVE_CASES)
+@pytest.mark.parametrize("ordering", [0, 1])
+def test_solve_matches_oracle_and_direct(handles, name, solver, prec, variant, tol, ordering):
+    S, O = _S(), _O()
+    pr = problem(name)
+    ls = handles(name, ordering)
+    J = pr.jacobian_scipy().tocsc()
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    x0 = np.concatenate([pr.x0_u, pr.x0_p])
+    ls.setup_preconditioner(prec, variant, 0.5)
+    kw = {}
+    if ordering:
+        kw["perm_F"] = ls.tri_perm(S.TRI_VELOCITY)
+        kw["perm_S" if prec == 2 else "perm_Mp"] = ls.tri_perm(S.TRI_PRESSURE)
+    op = O.OracleProblem.from_local(pr, **kw)
+    max_iter = 20000 if variant == 0 else 100000
+    xu, xp, its, res, rc = ls.solve(solver, tol, max_iter, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    xo, info = op.solve(b, x0, solver=solver, prec=prec, variant=variant, tol=tol)
+    assert rc == 0 and info["status"] == 0
+    x = np.concatenate([xu, xp])
+    true_res = np.linalg.norm(b - J @ x)
+    if solver == 0:
+        assert true_res <= 1e3 * tol  # left-preconditioned GMRES controls the preconditioned residual
+    else:
+        assert true_res <= 1.05 * tol
+    xs = spl.splu(J).solve(b)
+    scale = 1e-7 if tol <= 1e-10 else 1e-1
+    assert rel_err(x, xo) <= scale, (rel_err(x, xo), its, info["iters"])
+    assert rel_err(x, xs) <= scale
+    assert abs(its - info["iters"]) <= max(3, 0.2 * info["iters"]), (its, info["iters"])
+
+
+def test_solve_system_raises_like_reference(handles):
+    S = _S()
+    pr = problem("ns16")
+    ls = handles("ns16")
+    ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+    xu, xp, its, res, rc = ls.solve(S.FGMRES, 1e-12, 5, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    assert rc == 1 and its == 5 and res > 1e-12
+    with pytest.raises(RuntimeError):
+        ls.setup_preconditioner(7)
+
+
+def test_zero_iterations_when_already_converged(handles):
+    """if (GMRES_iter == 0) break;  (NSSolverStationary.cpp:712): a second solve from the solution."""
+    S = _S()
+    pr = problem("stokes16")
+    ls = handles("stokes16")
+    ls.setup_preconditioner(S.BLOCK_DIAGONAL, S.STATIONARY)
+    xu, xp, its, res, rc = ls.solve(S.FGMRES, 1e-9, 20000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    assert rc == 0 and its > 0
+    _, _, its2, _, rc2 = ls.solve(S.FGMRES, 1e-8, 20000, pr.rhs_u, pr.rhs_p, xu, xp)
+    assert rc2 == 0 and its2 == 0

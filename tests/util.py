@@ -1,0 +1,31 @@
+"""Shared helpers of the parity tests."""
+import functools
+
+import numpy as np
+
+from navier_stokes_solver_amd import problem as P
+
+# (nx, ny, nu, mode, state, inlet_bc, inv_dt): the reference's own CPU-runnable case
+# (-m 60,20 -r 20: Stokes systems at nu = 1/10, first one with the inlet data) and Newton systems.
+CASES = {
+    "stokes16": dict(nx=16, ny=10, nu=0.1, mode=0, state=0, inlet_bc=1),
+    "ns16": dict(nx=16, ny=10, nu=1.0 / 90.0, mode=1, state=1, inlet_bc=0),
+    "stokes60": dict(nx=60, ny=20, nu=0.1, mode=0, state=0, inlet_bc=1),
+    "ns60": dict(nx=60, ny=20, nu=1.0 / 90.0, mode=1, state=1, inlet_bc=0),
+    "unsteady16": dict(nx=16, ny=10, nu=1.0 / 91.0, mode=1, state=1, inlet_bc=0, inv_dt=100.0, U=0.3),
+}
+
+
+@functools.lru_cache(maxsize=8)
+def problem(name):
+    return P.generate(**CASES[name])
+
+
+def rng_vec(n, seed=1234):
+    return np.random.default_rng(seed).uniform(-1.0, 1.0, n)
+
+
+def rel_err(a, b):
+    d = np.abs(np.asarray(a) - np.asarray(b)).max()
+    s = np.abs(np.asarray(b)).max()
+    return d / s if s > 0 else d
