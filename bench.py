@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py — DoF·iters/s of the FGMRES + aSIMPLE velocity-pressure solve on MI355X.
+
+Metric (BASELINE.json): DoF·iters/sec (FGMRES+aSIMPLE, Re=100) at 1/2/4/8 GPUs; achieved HBM GB/s.
+Workload at N=1: BASELINE configs[2] — stationary 1200x400, Re=100 (nu=1/90, Newton system),
+FGMRES + aSIMPLE on one MI355X.  For N>1 the mesh grows along x (1200*N x 400, x-strip row
+partition, weak scaling): per-GPU work is fixed, halo exchange + all-reduce go over RCCL.
+
+A step is ONE outer FGMRES iteration: aSIMPLE apply (inner FGMRES on F with ILU(0), B, inner CG
+on S with ILU(0), B^T, D^-1) + jacobian SpMV + modified Gram-Schmidt + least squares/check.
+The timed region is `solve_system`'s solver.solve() limited to exactly K iterations (tolerance 0),
+inputs resident in HBM; preconditioner setup (diag, SpGEMM, 2x ILU(0)) is reported separately.
+
+One process per GPU: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=58)     # two full restart cycles of 29 counted iterations
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mesh", type=str, default="1200,400", help="per-GPU mesh X,Y (weak) or global (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--reynolds", type=float, default=100.0)
+    ap.add_argument("--solver", type=int, default=1)
+    ap.add_argument("--preconditioner", type=int, default=2)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--ordering", type=int, default=1, help="0 natural, 1 multicolour (triangular solves)")
+    ap.add_argument("--subdomains", type=int, default=1)
+    ap.add_argument("--profile-op", type=int, default=0, help="op sampled with HIP events for the roofline (0 = SpMV on F)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-mesh", type=str, default="300,100")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--converge", type=float, default=0.0, help="if > 0: also run a full solve to this tolerance")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, nu):
+    """Oracle (CPU restatement of the reference path, kind 'port') on a bounded sample of the same
+    workload: same solver / preconditioner / Reynolds number on a smaller mesh, a few outer iterations."""
+    import numpy as np
+    from navier_stokes_solver_amd import problem as P
+    from oracle import oracle as O
+    nx, ny = (int(v) for v in args.cpu_mesh.split(","))
+    pr = P.generate(nx, ny, nu=nu, mode=1, state=1)
+    op = O.OracleProblem.from_local(pr)
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    x0 = np.concatenate([pr.x0_u, pr.x0_p])
+    t0 = time.time()
+    _, info = op.solve(b, x0, solver=args.solver, prec=args.preconditioner, variant=args.variant, tol=0.0,
+                       max_iter=args.cpu_steps)
+    wall = time.time() - t0
+    its = max(1, info["iters"])
+    return {
+        "value": pr.n * its / info["solve_seconds"], "unit": "DoF*iters/s", "cores": 1, "kind": "port",
+        "sample": f"oracle (single-thread C restatement), stationary {nx}x{ny} Re={args.reynolds:g}, "
+                  f"{its} outer iterations, natural-order ILU(0); solve {info['solve_seconds']:.1f}s + "
+                  f"setup {info['setup_seconds']:.1f}s (wall {wall:.1f}s)",
+        "incl_setup_value": pr.n * its / (info["solve_seconds"] + info["setup_seconds"]),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the solve path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        # rendezvous / barriers / object exchange on gloo; the data path uses RCCL inside libnsk_hip.so
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from navier_stokes_solver_amd import partition as PT
+    from navier_stokes_solver_amd import problem as P
+    from navier_stokes_solver_amd import solver as S
+
+    mx, my = (int(v) for v in args.mesh.split(","))
+    nx = mx * world if args.scaling == "weak" else mx
+    ny = my
+    nu = P.reynolds_to_nu(args.reynolds, stationary=(args.variant == 0))
+    inv_dt = 0.0 if args.variant == 0 else 100.0
+
+    t0 = time.time()
+    pr = P.generate(nx, ny, nu=nu, mode=1, state=1, inv_dt=inv_dt, U=0.1 if args.variant == 0 else 0.3,
+                    nranks=world, rank=rank)
+    t_gen = time.time() - t0
+    n_global = int(pr.info["n_u_global"] + pr.info["n_p_global"])
+
+    uid = None
+    plan = None
+    if world > 1:
+        box = [S.get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+        gu, gp = [None] * world, [None] * world
+        dist.all_gather_object(gu, pr.ghost_u)
+        dist.all_gather_object(gp, pr.ghost_p)
+        plan = {S.SPACE_U: PT.build_halo_plan(rank, pr.u_ranges, gu),
+                S.SPACE_P: PT.build_halo_plan(rank, pr.p_ranges, gp)}
+
+    ls = S.LinearSolver(rank, world, local_rank, uid)
+    ls.set_option(S.OPT_TRI_ORDERING, args.ordering)
+    ls.set_option(S.OPT_SUBDOMAINS, args.subdomains)
+    t0 = time.time()
+    ls.set_problem(pr, plan)
+    t_upload = time.time() - t0
+    t0 = time.time()
+    ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
+    t_setup_first = time.time() - t0     # includes the one-off symbolic analysis
+    t0 = time.time()
+    ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
+    t_setup = time.time() - t0           # numeric refactorisation only (what every Newton step pays)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # warm-up
+    ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    ls.solve_resident(args.solver, 0.0, max(1, args.warmup))
+    # timed: exactly K outer iterations from the same initial state, fresh preconditioner object
+    ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
+    ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    ls.reset_stats()
+    ls.profile_begin(args.profile_op, 1024)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    its, res, rc = ls.solve_resident(args.solver, 0.0, args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    k_ms, k_n, k_bytes = ls.profile_end()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    st = ls.stats()
+    assert its == args.steps, (its, args.steps)
+
+    conv = None
+    if args.converge > 0:
+        ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
+        ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cits, cres, crc = ls.solve_resident(args.solver, args.converge, 20000 if args.variant == 0 else 100000)
+        torch.cuda.synchronize()
+        cdt = time.perf_counter() - t0
+        conv = {"tol": args.converge, "iters": cits, "final_res": cres, "status": crc, "seconds": cdt,
+                "dof_iters_per_s": n_global * cits / cdt}
+
+    if rank == 0:
+        value = n_global * args.steps / dt
+        achieved = (k_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
+        op_names = {0: "spmv_kernel<16,0> on F (inner FGMRES)", 5: "spmv on S", 20: "ILU(0) apply on F (all level kernels)",
+                    21: "ILU(0) apply on S"}
+        out = {
+            "metric": "DoF*iters/s (FGMRES+aSIMPLE, Re=100)", "value": value, "unit": "DoF*iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"stationary {nx}x{ny} Q3/Q2, Re={args.reynolds:g} (nu=1/{1 / nu:g}) Newton system, "
+                            f"solver {['GMRES', 'FGMRES', 'Bicgstab'][args.solver]} + "
+                            f"{['blockDiagonal', 'blockTriangular', 'aSIMPLE'][args.preconditioner]}",
+                "dofs": n_global, "n_u_local": pr.n_u, "n_p_local": pr.n_p, "nnz_F_local": pr.F.nnz,
+                "nnz_S_local": st["nnz_s"], "partition": f"x-strips x{world}",
+                "tri_ordering": ["natural", "multicolor"][args.ordering], "colors_u": st["n_colors_u"],
+                "colors_p": st["n_colors_p"], "subdomains_per_gpu": args.subdomains,
+                "inner_F_its_per_step": st["inner_u_its"] / max(1, st["prec_applies"]),
+                "inner_S_its_per_step": st["inner_p_its"] / max(1, st["prec_applies"]),
+                "residual_after_K": res,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": op_names.get(args.profile_op, f"op {args.profile_op}"),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": k_bytes, "avg_ms": k_ms, "launches_sampled": k_n,
+            },
+            "phases": {
+                "generate_s": t_gen, "upload_s": t_upload, "setup_first_s": t_setup_first, "setup_numeric_s": t_setup,
+                "solve_s": dt, "spmv_GB": st["spmv_bytes"] / 1e9, "tri_GB": st["tri_bytes"] / 1e9,
+                "blas1_GB": st["blas1_bytes"] / 1e9,
+                "algorithmic_GBps_whole_solve": (st["spmv_bytes"] + st["tri_bytes"] + st["blas1_bytes"]) / 1e9 / dt,
+                "host_syncs": st["host_syncs"], "reductions": st["reductions"],
+                "dof_iters_per_s_incl_setup": n_global * args.steps / (dt + t_setup),
+            },
+        }
+        if conv:
+            out["converged_solve"] = conv
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, nu)
+        print(json.dumps(out), flush=True)
+    ls.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

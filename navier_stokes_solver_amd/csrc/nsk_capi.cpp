@@ -24,8 +24,33 @@ double wall_ms() {
 }
 }  // namespace
 
+// HIP-event sampler: brackets launches of one operation class inside a running solve
+struct EventSampler {
+  int op = -1, cap = 0;
+  std::vector<hipEvent_t> e0, e1;
+  int used = 0;
+  void begin(int op_, int cap_) {
+    end_release();
+    op = op_;
+    cap = cap_;
+    e0.resize(cap);
+    e1.resize(cap);
+    for (int i = 0; i < cap; ++i) { (void)hipEventCreate(&e0[i]); (void)hipEventCreate(&e1[i]); }
+    used = 0;
+  }
+  bool want(int o) const { return o == op && used < cap; }
+  void end_release() {
+    for (size_t i = 0; i < e0.size(); ++i) { (void)hipEventDestroy(e0[i]); (void)hipEventDestroy(e1[i]); }
+    e0.clear();
+    e1.clear();
+    op = -1;
+    cap = used = 0;
+  }
+};
+
 struct nsk_handle_s {
   Ctx ctx;
+  EventSampler sampler;
   std::string err;
   Space sp[2];
   Csr blk[6];
@@ -65,7 +90,11 @@ struct nsk_handle_s {
   }
   void halo(int space, const DVec &x) { ctx.comm.halo_exchange(sp[space], x, s()); }
   void spmv_nohalo(Csr &A, const DVec &x, double *y, int mode = 0, const double *z = nullptr) {
+    const int op = (int)(&A - blk);
+    const bool smp = sampler.want(op);
+    if (smp) (void)hipEventRecord(sampler.e0[sampler.used], s());
     nsk::spmv(s(), A.view(), A.lpr, x.own, x.ghost, y, mode, z);
+    if (smp) (void)hipEventRecord(sampler.e1[sampler.used++], s());
     ++ctx.st.spmv_calls;
     ctx.st.spmv_bytes += (double)A.spmv_bytes() + (mode == 1 ? 8.0 * A.n_rows : 0.0);
   }
@@ -84,6 +113,12 @@ struct nsk_handle_s {
       spmv_nohalo(Bt, xp, yb, 1);
     }
     spmv_nohalo(B, xu, yb + n_u(), 0);
+  }
+  void tri_apply_sampled(TriSolve &T, int op, const double *b, double *x) {
+    const bool smp = sampler.want(op);
+    if (smp) (void)hipEventRecord(sampler.e0[sampler.used], s());
+    T.apply(b, x);
+    if (smp) (void)hipEventRecord(sampler.e1[sampler.used++], s());
   }
   std::vector<int> sub_offsets(int space) const {
     std::vector<int> off;
@@ -219,8 +254,8 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
   const DVec su = ub(src.own), spv = pb(src.own);
   const int nu = n_u(), np = n_p();
   MatVec A_F = [&](const DVec &x, double *y) { halo(0, x); spmv_nohalo(F, x, y); };
-  PrecVmult P_F = [&](DVec &d, const DVec &r) { tF.apply(r.own, d.own); };
-  PrecVmult P_P = [&](DVec &d, const DVec &r) { tP->apply(r.own, d.own); };
+  PrecVmult P_F = [&](DVec &d, const DVec &r) { tri_apply_sampled(tF, 20, r.own, d.own); };
+  PrecVmult P_P = [&](DVec &d, const DVec &r) { tri_apply_sampled(*tP, 21, r.own, d.own); };
   const int sl = ctx.alloc_slots(4);
   struct Rel { Ctx &c; int sl; ~Rel() { c.slot_top = sl; } } rel{ctx, sl};
   auto norm_of = [&](const double *v, int n) { ctx.norm2(n, v, sl); return ctx.read_slots(sl + 1, 1)[0]; };
@@ -673,6 +708,39 @@ int nsk_reset_stats(nsk_handle h) {
   NSK_TRY(h)
   h->ctx.st = Stats{};
   h->inner_u = h->inner_p = h->prec_applies = h->outer_iters = 0;
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_profile_begin(nsk_handle h, int op, int max_samples) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  if (max_samples < 1 || max_samples > 4096) throw Error(-66, "nsk_profile_begin: 1..4096 samples");
+  h->sampler.begin(op, max_samples);
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_profile_end(nsk_handle h, double *avg_ms, int *n_samples, double *bytes) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  h->ctx.sync();
+  double tot = 0.0;
+  for (int i = 0; i < h->sampler.used; ++i) {
+    float ms = 0.f;
+    NSK_HIP(hipEventElapsedTime(&ms, h->sampler.e0[i], h->sampler.e1[i]));
+    tot += ms;
+  }
+  const int op = h->sampler.op;
+  if (avg_ms) *avg_ms = h->sampler.used ? tot / h->sampler.used : 0.0;
+  if (n_samples) *n_samples = h->sampler.used;
+  if (bytes) {
+    if (op >= 0 && op <= NSK_BLK_S) *bytes = (double)h->blk[op].spmv_bytes();
+    else if (op == 20) *bytes = (double)h->tF.apply_bytes();
+    else if (op == 21 && h->tP) *bytes = (double)h->tP->apply_bytes();
+    else *bytes = 0.0;
+  }
+  h->sampler.end_release();
   return 0;
   NSK_CATCH(h)
 }

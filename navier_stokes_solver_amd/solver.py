@@ -31,7 +31,7 @@ EXPORTS = [
     "nsk_set_block_csr", "nsk_update_values", "nsk_set_option", "nsk_setup_preconditioner", "nsk_solve",
     "nsk_upload_system", "nsk_solve_resident", "nsk_download_solution", "nsk_spmv", "nsk_jacobian_vmult", "nsk_dot",
     "nsk_tri_apply", "nsk_tri_get_perm", "nsk_precond_vmult", "nsk_block_nnz", "nsk_get_block", "nsk_get_stats",
-    "nsk_reset_stats", "nsk_time_op",
+    "nsk_reset_stats", "nsk_time_op", "nsk_profile_begin", "nsk_profile_end",
 ]
 
 
@@ -95,6 +95,8 @@ def lib() -> C.CDLL:
         L.nsk_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.nsk_reset_stats.argtypes = [vp]
         L.nsk_time_op.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.nsk_profile_begin.argtypes = [vp, C.c_int, C.c_int]
+        L.nsk_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
         _LIB = L
     return _LIB
 
@@ -283,6 +285,14 @@ class LinearSolver:
 
     def reset_stats(self):
         self._ck(self.L.nsk_reset_stats(self.h))
+
+    def profile_begin(self, op, max_samples=256):
+        self._ck(self.L.nsk_profile_begin(self.h, op, max_samples))
+
+    def profile_end(self):
+        ms, n, by = C.c_double(0), C.c_int(0), C.c_double(0)
+        self._ck(self.L.nsk_profile_end(self.h, C.byref(ms), C.byref(n), C.byref(by)))
+        return ms.value, n.value, by.value
 
     def time_op(self, op, reps=10):
         ms, by = C.c_double(0), C.c_double(0)

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the CPU oracle (the reference itself cannot run here: deal.II /
+Trilinos are absent).  Inputs are seeded; outputs are what oracle/nsk_oracle.c computes.
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from navier_stokes_solver_amd import problem as P  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tests.util import CASES, rng_vec  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def make(name):
+    pr = P.generate(**CASES[name])
+    op = O.OracleProblem.from_local(pr)
+    g = {"n_u": pr.n_u, "n_p": pr.n_p}
+    xu, xp = rng_vec(pr.n_u, 101), rng_vec(pr.n_p, 102)
+    g["x_u"], g["x_p"] = xu, xp
+    g["F_x"] = O.spmv(O.CsrHolder.from_block(pr.F), xu)
+    g["Bt_x"] = O.spmv(O.CsrHolder.from_block(pr.Bt), xp)
+    g["B_x"] = O.spmv(O.CsrHolder.from_block(pr.B), xu)
+    g["Mp_x"] = O.spmv(O.CsrHolder.from_block(pr.Mp), xp)
+    g["ilu_F_x"] = O.Tri(O.CsrHolder.from_block(pr.F), kind=0).apply(xu)
+    g["sgs_F_x"] = O.Tri(O.CsrHolder.from_block(pr.F), kind=1).apply(xu)
+    g["ilu_Mp_x"] = O.Tri(O.CsrHolder.from_block(pr.Mp), kind=0).apply(xp)
+    src = np.concatenate([xu, xp])
+    src /= np.linalg.norm(src)
+    g["prec_src"] = src
+    for prec, variant in ((2, 0), (2, 1), (0, 0), (1, 1)):
+        for calls in (1, 2):
+            g[f"prec{prec}{variant}_calls{calls}"] = op.prec_apply(src, prec=prec, variant=variant, calls=calls)[0]
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    x0 = np.concatenate([pr.x0_u, pr.x0_p])
+    for solver, prec, variant, tol in ((1, 0, 0, 1e-12), (1, 2, 0, 1e-12), (1, 2, 1, 1e-12), (0, 2, 1, 1e-12)):
+        x, info = op.solve(b, x0, solver=solver, prec=prec, variant=variant, tol=tol)
+        assert info["status"] == 0
+        g[f"solve_s{solver}p{prec}v{variant}_x"] = x
+        g[f"solve_s{solver}p{prec}v{variant}_iters"] = info["iters"]
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **g)
+    print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in g.items() if "iters" in k})
+
+
+if __name__ == "__main__":
+    for name in ("stokes16", "ns16", "unsteady16"):
+        make(name)

@@ -1,0 +1,141 @@
+"""The CPU oracle against ground truth that does not depend on it: sparse-direct solves (scipy splu),
+scipy products / triangular solves, and the defining property of ILU(0)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+from oracle import oracle as O
+from tests.util import problem, rel_err, rng_vec
+
+
+def _sys(name):
+    pr = problem(name)
+    J = pr.jacobian_scipy().tocsc()
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    x0 = np.concatenate([pr.x0_u, pr.x0_p])
+    return pr, J, b, x0
+
+
+def test_spmv_and_spgemm_against_scipy():
+    pr = problem("ns16")
+    for blk in (pr.F, pr.Bt, pr.B, pr.Mp):
+        x = rng_vec(blk.cols, 3)
+        assert rel_err(O.spmv(O.CsrHolder.from_block(blk), x), blk.to_scipy() @ x) <= 1e-14
+    F, B, Bt = pr.F.to_scipy(), pr.B.to_scipy(), pr.Bt.to_scipy()
+    dinv = 1.0 / F.diagonal()
+    rp, col, val = O.spgemm_adb(O.CsrHolder.from_block(pr.B), dinv, O.CsrHolder.from_block(pr.Bt))
+    S = sp.csr_matrix((val, col, rp), shape=(pr.n_p, pr.n_p))
+    Sref = (B @ sp.diags(dinv) @ Bt).tocsr()
+    assert abs(S - Sref).max() <= 1e-13 * abs(Sref).max()
+    # structural product pattern (nnz S = 37 488 at 16x10)
+    assert len(val) == 37488
+
+
+@pytest.mark.parametrize("perm_seed", [None, 7])
+def test_ilu0_defining_property_and_apply(perm_seed):
+    """(L U)_ij = A_ij on the pattern of A; apply equals two scipy triangular solves."""
+    pr = problem("ns16")
+    A = pr.F.to_scipy().tocsr()
+    n = A.shape[0]
+    perm = None if perm_seed is None else np.random.default_rng(perm_seed).permutation(n).astype(np.int32)
+    tri = O.Tri(O.CsrHolder.from_block(pr.F), kind=0, perm=perm)
+    rp, col, val = tri.export()
+    M = sp.csr_matrix((val, col, rp), shape=(n, n))
+    L = sp.tril(M, -1) + sp.identity(n)
+    U = sp.triu(M, 0)
+    Ap = A if perm is None else A[perm][:, perm]
+    mask = sp.csr_matrix((np.ones(len(col)), col, rp), shape=(n, n))
+    diff = (L @ U - Ap).multiply(mask)
+    assert abs(diff).max() <= 1e-12 * abs(Ap).max()
+    b = rng_vec(n, 1)
+    bp = b if perm is None else b[perm]
+    y = spl.spsolve_triangular(L.tocsr(), bp, lower=True, unit_diagonal=True)
+    xp = spl.spsolve_triangular(U.tocsr(), y, lower=False)
+    x = xp
+    if perm is not None:
+        x = np.empty(n)
+        x[perm] = xp
+    assert rel_err(tri.apply(b), x) <= 1e-11
+
+
+def test_block_jacobi_shards_drop_couplings():
+    """Ifpack additive Schwarz overlap 0: ILU of each rank-local diagonal block."""
+    pr = problem("ns16")
+    A = pr.F.to_scipy().tocsr()
+    n = A.shape[0]
+    off = np.array([0, (n // 3) & ~1, (2 * n // 3) & ~1, n], np.int32)
+    tri = O.Tri(O.CsrHolder.from_block(pr.F), kind=0, shard_off=off)
+    b = rng_vec(n, 2)
+    x = tri.apply(b)
+    for s in range(3):
+        sl = slice(off[s], off[s + 1])
+        sub = O.Tri(O.CsrHolder.from_scipy(A[sl][:, sl]), kind=0)
+        assert rel_err(x[sl], sub.apply(b[sl])) <= 1e-13
+
+
+def test_sgs_is_two_triangular_solves():
+    pr = problem("stokes16")
+    A = pr.F.to_scipy().tocsr()
+    D = sp.diags(A.diagonal())
+    b = rng_vec(A.shape[0], 4)
+    y = spl.spsolve_triangular((sp.tril(A, -1) + D).tocsr(), b, lower=True)
+    x = spl.spsolve_triangular((sp.triu(A, 1) + D).tocsr(), D @ y, lower=False)
+    assert rel_err(O.Tri(O.CsrHolder.from_block(pr.F), kind=1).apply(b), x) <= 1e-12
+
+
+FGMRES_CASES = [("stokes16", 0, 0), ("ns16", 0, 0), ("ns16", 1, 0), ("ns16", 2, 0),
+                ("unsteady16", 0, 1), ("unsteady16", 1, 1), ("unsteady16", 2, 1)]
+
+
+@pytest.mark.parametrize("name,prec,variant", FGMRES_CASES)
+def test_fgmres_reaches_the_direct_solution(name, prec, variant):
+    pr, J, b, x0 = _sys(name)
+    xs = spl.splu(J).solve(b)
+    x, info = O.OracleProblem.from_local(pr).solve(b, x0, solver=1, prec=prec, variant=variant, tol=1e-12)
+    assert info["status"] == 0
+    true_res = np.linalg.norm(b - J @ x)
+    assert true_res <= 1.05e-12                # FGMRES' estimate tracks the true residual norm
+    assert rel_err(x, xs) <= 1e-8
+
+
+def test_gmres_and_bicgstab_with_a_fixed_preconditioner():
+    pr, J, b, x0 = _sys("unsteady16")
+    xs = spl.splu(J).solve(b)
+    op = O.OracleProblem.from_local(pr)
+    x, info = op.solve(b, x0, solver=0, prec=2, variant=1, tol=1e-12)
+    assert info["status"] == 0 and rel_err(x, xs) <= 1e-8
+    x, info = op.solve(b, x0, solver=2, prec=2, variant=1, tol=1e-4)
+    assert info["status"] == 0 and np.linalg.norm(b - J @ x) <= 1e-4
+
+
+def test_bicgstab_absolute_breakdown_threshold_is_restated():
+    """deal.II's breakdown = 1e-10 is absolute: once |r.rbar| < 1e-10 every restart breaks down again,
+    so tolerances below ~1e-5 cannot be met (status 2 = breakdown restarts exhausted)."""
+    pr, J, b, x0 = _sys("unsteady16")
+    _, info = O.OracleProblem.from_local(pr).solve(b, x0, solver=2, prec=2, variant=1, tol=1e-10)
+    assert info["status"] == 2 and 1e-10 < info["final_res"] < 1e-3
+
+
+def test_left_gmres_unsteady_block_diagonal_quirk():
+    """NSSolver.hpp:159-169: absolute inner tolerance 1e-1 => for ||r|| < 0.1 the preconditioner returns 0,
+    the preconditioned residual is 0 and SolverGMRES reports success after 0 steps."""
+    pr, J, b, x0 = _sys("unsteady16")
+    assert np.linalg.norm(b) < 0.1
+    x, info = O.OracleProblem.from_local(pr).solve(b, x0, solver=0, prec=0, variant=1, tol=1e-10)
+    assert info["status"] == 0 and info["iters"] == 0 and np.array_equal(x, x0)
+
+
+def test_max_iter_stops_like_solver_control():
+    pr, J, b, x0 = _sys("ns16")
+    _, info = O.OracleProblem.from_local(pr).solve(b, x0, solver=1, prec=2, variant=0, tol=0.0, max_iter=7)
+    assert info["status"] == 1 and info["iters"] == 7
+
+
+def test_asimple_apply_keeps_stale_delta_p():
+    pr = problem("ns16")
+    op = O.OracleProblem.from_local(pr)
+    src = rng_vec(pr.n, 31)
+    one, _ = op.prec_apply(src, prec=2, variant=0, calls=1)
+    two, _ = op.prec_apply(src, prec=2, variant=0, calls=2)
+    assert rel_err(two, one) > 1e-6   # the second call starts from alpha * delta_p and the previous dst

@@ -1,0 +1,111 @@
+"""The synthetic hand-off producer: known answers from the reference repo and an independent
+NumPy assembly (oracle/fe_numpy.py)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from navier_stokes_solver_amd import problem as P
+from tests.util import CASES, problem
+
+# SURVEY Appendix B (derived from the mesh rule; 154 244 is the reference's own figure,
+# performance_analysis.ipynb cell 1: "mesh size: 100x70 => 7000 cells => 154244 degrees of freedom")
+TABLE = {
+    (16, 10): dict(cells=158, removed=2, n_u=3018, n_p=690, F=143940, B=38874, Mp=10344),
+    (60, 20): dict(cells=1188, removed=12, n_u=21906, n_p=4926, F=1074420, B=289410, Mp=76728),
+    (100, 70): dict(cells=6942, removed=58, n_u=126096, n_p=28148, F=6259200, B=1684144, Mp=445808),
+}
+
+
+@pytest.mark.parametrize("mesh", sorted(TABLE))
+def test_dof_and_nnz_known_answers(mesh):
+    t = TABLE[mesh]
+    pr = P.generate(*mesh, nu=1.0 / 90.0)
+    i = pr.info
+    assert (i["n_cells"], i["n_removed"]) == (t["cells"], t["removed"])
+    assert (i["n_u_global"], i["n_p_global"]) == (t["n_u"], t["n_p"])
+    assert (pr.F.nnz, pr.Bt.nnz, pr.B.nnz, pr.Mp.nnz) == (t["F"], t["B"], t["B"], t["Mp"])
+    if mesh == (100, 70):
+        assert i["n_u_global"] + i["n_p_global"] == 154244
+
+
+def test_large_mesh_counts_only():
+    i = P.mesh_info(300, 100)
+    assert (i["n_cells"], i["n_removed"], i["n_u_global"], i["n_p_global"]) == (29738, 262, 537912, 119828)
+    i = P.mesh_info(1200, 400)
+    assert (i["n_cells"], i["n_removed"], i["n_u_global"], i["n_p_global"]) == (475828, 4172, 8575416, 1906816)
+
+
+def test_reynolds_ladder():
+    # NSSolverStationary.cpp:662-665: levels 10, 30, ..., <= Re ; NSSolver.cpp:684: 1, 11, ...
+    assert P.reynolds_to_nu(100) == pytest.approx(1 / 90)
+    assert P.reynolds_to_nu(200) == pytest.approx(1 / 190)
+    assert P.reynolds_to_nu(20) == pytest.approx(1 / 10)
+    assert P.reynolds_to_nu(100, stationary=False) == pytest.approx(1 / 91)
+
+
+@pytest.mark.parametrize("name", ["stokes16", "ns16", "unsteady16"])
+def test_against_independent_numpy_assembly(name):
+    from oracle import fe_numpy
+    kw = dict(CASES[name])
+    nx, ny = kw.pop("nx"), kw.pop("ny")
+    ref = fe_numpy.assemble(nx, ny, **kw)
+    pr = problem(name)
+    J = pr.jacobian_scipy()
+    scale = abs(ref["J"]).max()
+    assert abs(J - ref["J"]).max() <= 1e-12 * scale
+    assert abs(pr.Mp.to_scipy() - ref["Mp"]).max() <= 1e-12 * abs(ref["Mp"]).max()
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    assert np.abs(b - ref["rhs"]).max() <= 1e-12 * max(1.0, np.abs(ref["rhs"]).max())
+    x0 = np.concatenate([pr.x0_u, pr.x0_p])
+    assert np.array_equal(x0 != 0, ref["x0"] != 0)
+    assert np.allclose(x0, ref["x0"], rtol=1e-13, atol=0)
+    assert np.array_equal(pr.dirichlet_u.astype(bool), ref["dirichlet"])
+
+
+def test_block_structure_signs():
+    """Appendix C: Stokes mode is symmetric on free rows with both off-diagonal blocks negative;
+    Newton mode flips the (1,0) block."""
+    st, ns = problem("stokes16"), problem("ns16")
+    free = st.dirichlet_u == 0
+    assert abs((st.Bt.to_scipy() - st.B.to_scipy().T).tocsr()[free]).max() == 0.0
+    assert abs((ns.Bt.to_scipy() + ns.B.to_scipy().T).tocsr()[free]).max() == 0.0
+    Ff = st.F.to_scipy().tocsr()[free][:, free]
+    assert abs(Ff - Ff.T).max() <= 1e-14 * abs(Ff).max()
+    # Dirichlet rows: only the diagonal, equal to |first non-zero diagonal| of the uncleared matrix
+    Fd = st.F.to_scipy().tocsr()[~free]
+    assert Fd.nnz > 0 and np.count_nonzero(Fd.data) == int((~free).sum())
+    assert np.unique(Fd.data[Fd.data != 0]).size == 1
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_strip_partition_stitches_to_global(nranks):
+    """Local blocks (owned-first / ghosts-appended columns) reproduce the one-rank matrices."""
+    kw = CASES["ns16"]
+    glob = problem("ns16")
+    parts = [P.generate(**kw, nranks=nranks, rank=r) for r in range(nranks)]
+    assert parts[0].u_ranges[-1] == glob.n_u and parts[0].p_ranges[-1] == glob.n_p
+
+    def to_global(pr, blk, colspace, nrows_cols):
+        cb = pr.info[f"{colspace}_begin"]
+        n_own = pr.info[f"{colspace}_end"] - cb
+        ghosts = getattr(pr, f"ghost_{colspace}")
+        gcol = blk.col + cb
+        g = blk.col >= n_own
+        if g.any():
+            gcol = gcol.copy()
+            gcol[g] = ghosts[blk.col[g] - n_own]
+        return sp.csr_matrix((blk.val, gcol, blk.rowptr), shape=(blk.rows, nrows_cols))
+
+    for name, colspace in (("F", "u"), ("Bt", "p"), ("B", "u"), ("Mp", "p")):
+        ncols = glob.n_u if colspace == "u" else glob.n_p
+        A = sp.vstack([to_global(pr, getattr(pr, name), colspace, ncols) for pr in parts]).tocsr()
+        G = getattr(glob, name).to_scipy()
+        assert A.shape == G.shape and abs(A - G).max() == 0.0, name
+    assert np.array_equal(np.concatenate([p.rhs_u for p in parts]), glob.rhs_u)
+    assert np.array_equal(np.concatenate([p.rhs_p for p in parts]), glob.rhs_p)
+    # ghost rows of (0,1): exactly the global rows of the ghost velocity DoFs
+    Btg = glob.Bt.to_scipy().tocsr()
+    for pr in parts:
+        assert len(pr.ghost_u) > 0
+        A = to_global(pr, pr.Bt_ghost, "p", glob.n_p)
+        assert abs(A - Btg[pr.ghost_u]).max() == 0.0
