@@ -56,7 +56,10 @@ struct nsk_handle_s {
   Csr blk[6];
   VecPool pool_u, pool_p, pool_b;
   bool pools_ready = false;
-  int tri_ordering = ORDER_NATURAL, subdomains = 1, fuse_block_row = 1;
+  int tri_ordering = ORDER_NATURAL, subdomains = 1, fuse_block_row = 1, use_stream = 1;
+  DBuf<int> jrow_blk;  // row runs of the fused (F | Bt) block row
+  int jrow_nblk = 0;
+  bool jrow_ok = false;
 
   int prec_type = -1, variant = 0;
   double alpha = 0.5;
@@ -93,7 +96,10 @@ struct nsk_handle_s {
     const int op = (int)(&A - blk);
     const bool smp = sampler.want(op);
     if (smp) (void)hipEventRecord(sampler.e0[sampler.used], s());
-    nsk::spmv(s(), A.view(), A.lpr, x.own, x.ghost, y, mode, z);
+    if (A.stream_ok && use_stream)
+      nsk::spmv_stream(s(), A.view(), A.rowblk.p, A.nblk, A.even_rows, x.own, x.ghost, y, mode, z);
+    else
+      nsk::spmv(s(), A.view(), A.lpr, x.own, x.ghost, y, mode, z);
     if (smp) (void)hipEventRecord(sampler.e1[sampler.used++], s());
     ++ctx.st.spmv_calls;
     ctx.st.spmv_bytes += (double)A.spmv_bytes() + (mode == 1 ? 8.0 * A.n_rows : 0.0);
@@ -104,7 +110,20 @@ struct nsk_handle_s {
     halo(0, xu);
     halo(1, xp);
     Csr &F = blk[NSK_BLK_F], &Bt = blk[NSK_BLK_BT], &B = blk[NSK_BLK_B];
-    if (fuse_block_row) {
+    if (fuse_block_row && use_stream && !jrow_ok && jrow_nblk == 0 && F.even_rows) {
+      std::vector<int> rb;
+      if (build_rowblocks(F.h_rowptr.data(), Bt.h_rowptr.data(), F.n_rows, kStreamNnz, nullptr, rb)) {
+        jrow_nblk = (int)rb.size() - 1;
+        jrow_blk.upload(rb, s());
+        ctx.sync();
+        jrow_ok = true;
+      } else jrow_nblk = -1;
+    }
+    if (fuse_block_row && use_stream && jrow_ok) {
+      nsk::spmv2_stream(s(), F.view(), xu.own, xu.ghost, Bt.view(), xp.own, xp.ghost, jrow_blk.p, jrow_nblk, yb);
+      ctx.st.spmv_calls += 2;
+      ctx.st.spmv_bytes += (double)F.spmv_bytes() + (double)Bt.spmv_bytes() - 8.0 * F.n_rows - 4.0 * (F.n_rows + 1);
+    } else if (fuse_block_row) {
       nsk::spmv2(s(), F.view(), xu.own, xu.ghost, Bt.view(), xp.own, xp.ghost, yb, F.lpr);
       ctx.st.spmv_calls += 2;
       ctx.st.spmv_bytes += (double)F.spmv_bytes() + (double)Bt.spmv_bytes() - 8.0 * F.n_rows - 4.0 * (F.n_rows + 1);
@@ -185,6 +204,7 @@ void H::schur_symbolic() {
   S.val.alloc((size_t)S.nnz);
   S.lpr = pick_lpr(S.nnz, S.n_rows);
   S.present = true;
+  S.build_stream_plan(s());
   ctx.sync();
   s_symbolic = true;
 }
@@ -471,7 +491,9 @@ int nsk_set_block_csr(nsk_handle h, int b, int n_rows, int n_cols, const int32_t
   A.val.upload(val, (size_t)nnz, h->s());
   A.lpr = pick_lpr(nnz, n_rows);
   A.present = true;
+  A.build_stream_plan(h->s());
   h->ctx.sync();
+  if (b == NSK_BLK_F || b == NSK_BLK_BT) { h->jrow_ok = false; h->jrow_nblk = 0; }
   // a new pattern invalidates cached symbolic data
   if (b == NSK_BLK_F) h->tF_ok = false;
   if (b == NSK_BLK_MP) h->tMp_ok = false;
@@ -497,6 +519,7 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
     case NSK_OPT_TRI_ORDERING: h->tri_ordering = v != 0.0 ? ORDER_MULTICOLOR : ORDER_NATURAL; break;
     case NSK_OPT_SUBDOMAINS: h->subdomains = std::max(1, (int)v); break;
     case NSK_OPT_FUSE_BLOCK_ROW: h->fuse_block_row = v != 0.0; break;
+    case NSK_OPT_STREAM_KERNELS: h->use_stream = v != 0.0; h->tF.use_stream = h->tMp.use_stream = h->tS.use_stream = h->use_stream; break;
     default: throw Error(-61, "nsk_set_option: unknown option");
   }
   return 0;

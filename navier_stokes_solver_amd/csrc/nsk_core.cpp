@@ -3,6 +3,8 @@
 
 #include <rccl/rccl.h>
 
+#include <algorithm>
+
 namespace nsk {
 
 #define NSK_NCCL(call)                                                                     \
@@ -131,9 +133,40 @@ void Ctx::cg_update(int n, SRef a, const double *d, const double *h, double *x, 
 
 void Ctx::spmv(Csr &A, Space &colspace, const DVec &x, double *y, int mode, const double *z) {
   comm.halo_exchange(colspace, x, stream);
-  nsk::spmv(stream, A.view(), A.lpr, x.own, x.ghost, y, mode, z);
+  if (A.stream_ok) nsk::spmv_stream(stream, A.view(), A.rowblk.p, A.nblk, A.even_rows, x.own, x.ghost, y, mode, z);
+  else nsk::spmv(stream, A.view(), A.lpr, x.own, x.ghost, y, mode, z);
   ++st.spmv_calls;
   st.spmv_bytes += (double)A.spmv_bytes() + (mode ? 8.0 * A.n_rows : 0.0);
+}
+
+bool build_rowblocks(const int *ra, const int *rb, int n_rows, int max_nnz, const std::vector<int> *cuts,
+                     std::vector<int> &rowblk) {
+  rowblk.clear();
+  rowblk.push_back(0);
+  size_t ci = 0;
+  int r0 = 0;
+  auto nnz_of = [&](int a, int b) { return (ra[b] - ra[a]) + (rb ? rb[b] - rb[a] : 0); };
+  while (r0 < n_rows) {
+    while (cuts && ci < cuts->size() && (*cuts)[ci] <= r0) ++ci;
+    const int limit = (cuts && ci < cuts->size()) ? std::min(n_rows, (*cuts)[ci]) : n_rows;
+    int r1 = r0 + 1;
+    if (nnz_of(r0, r1) > max_nnz) return false;
+    while (r1 < limit && r1 - r0 < 1024 && nnz_of(r0, r1 + 1) <= max_nnz) ++r1;
+    rowblk.push_back(r1);
+    r0 = r1;
+  }
+  return true;
+}
+
+void Csr::build_stream_plan(hipStream_t s) {
+  std::vector<int> rb;
+  stream_ok = n_rows > 0 && build_rowblocks(h_rowptr.data(), nullptr, n_rows, kStreamNnz, nullptr, rb);
+  if (!stream_ok) { nblk = 0; return; }
+  nblk = (int)rb.size() - 1;
+  even_rows = true;
+  for (int i = 0; i <= n_rows; ++i)
+    if (h_rowptr[i] & 1) { even_rows = false; break; }
+  rowblk.upload(rb, s);
 }
 
 double *VecPool::get(bool zero) {

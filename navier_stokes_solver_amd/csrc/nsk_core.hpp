@@ -93,13 +93,24 @@ struct Csr {  // device CSR block with host copy of the pattern
   std::vector<int> h_rowptr, h_col;  // host pattern (symbolic phases)
   DBuf<int> rowptr, col;
   DBuf<double> val;
-  int lpr = 16;  // lanes per row chosen from the mean row length
+  int lpr = 16;  // lanes per row chosen from the mean row length (CSR-vector fallback kernel)
   bool present = false;
+  // CSR-stream plan: workgroup b owns rows [rowblk[b], rowblk[b+1])
+  DBuf<int> rowblk;
+  int nblk = 0;
+  bool stream_ok = false, even_rows = false;
+  void build_stream_plan(hipStream_t s);
   CsrView view() const { return CsrView{n_rows, n_own_cols, rowptr.p, col.p, val.p}; }
   size_t spmv_bytes() const {  // 12 nnz + 4 (rows+1) + 8 rows + 8 cols
     return (size_t)12 * nnz + 4 * ((size_t)n_rows + 1) + 8 * (size_t)n_rows + 8 * (size_t)n_cols;
   }
 };
+
+// Greedy runs of whole rows with at most max_nnz non-zeros (counted over rowptr_a [+ rowptr_b]);
+// `cuts` (ascending row ids, may be null) are boundaries no run may cross.  Returns false when a
+// single row exceeds max_nnz.
+bool build_rowblocks(const int *rowptr_a, const int *rowptr_b, int n_rows, int max_nnz, const std::vector<int> *cuts,
+                     std::vector<int> &rowblk);
 
 inline int pick_lpr(int64_t nnz, int n_rows) {
   const double mean = n_rows > 0 ? (double)nnz / n_rows : 0.0;

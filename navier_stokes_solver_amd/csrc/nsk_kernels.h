@@ -40,6 +40,16 @@ void spmv(hipStream_t s, const CsrView &A, int lanes_per_row, const double *x_ow
 void spmv2(hipStream_t s, const CsrView &A, const double *xa_own, const double *xa_ghost, const CsrView &B,
            const double *xb_own, const double *xb_ghost, double *y, int lanes_per_row);
 
+// LDS-staged "CSR-stream" SpMV: each 256-thread workgroup owns a run of whole rows holding at most
+// kStreamNnz non-zeros (rowblk[b]..rowblk[b+1]); it streams val/col fully coalesced, stages the
+// products val*x[col] in LDS and then reduces them per row.  even_rows: every rowptr entry is even,
+// which allows 16-byte value / 8-byte index loads.
+constexpr int kStreamNnz = 2048;
+void spmv_stream(hipStream_t s, const CsrView &A, const int *rowblk, int nblk, int even_rows, const double *x_own,
+                 const double *x_ghost, double *y, int mode, const double *z);
+void spmv2_stream(hipStream_t s, const CsrView &A, const double *xa_own, const double *xa_ghost, const CsrView &B,
+                  const double *xb_own, const double *xb_ghost, const int *rowblk, int nblk, double *y);
+
 // ---- BLAS-1 with device scalars ----
 void vec_set(hipStream_t s, int n, double *y, double v);
 void vec_copy(hipStream_t s, int n, const double *x, double *y);
@@ -85,6 +95,19 @@ void tri_lower_serial(hipStream_t s, const TriView &T, int kind, const int *lvl_
                       const double *rhs, double *y);
 void tri_upper_serial(hipStream_t s, const TriView &T, int kind, const int *lvl_ptr, const int *rows, int l0, int l1,
                       double *y, double *out);
+// Streamed level of a triangular solve on split factors: M = strict-lower or strict-upper CSR in the
+// permuted ordering with the rows of one level contiguous; blocks [b0, b1) of rowblk cover the level.
+//   lower: y[r] = (rhs[perm[r]] - sum) * (kind ? dinv[r] : 1)
+//   upper: x = kind ? y[r] - sum*dinv[r] : (y[r] - sum)*dinv[r];  y[r] = x;  out[perm[r]] = x
+struct TriHalf {
+  const int *rowptr;
+  const int *col;
+  const double *val;
+  const int *rowblk;
+};
+void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, const double *dinv,
+                      const int *perm, const double *rhs, double *y, double *out);
+
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,
                        const int *col, double *val, int max_row_nnz);

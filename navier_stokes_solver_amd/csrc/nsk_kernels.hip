@@ -92,6 +92,111 @@ __global__ __launch_bounds__(BLK) void spmv2_kernel(CsrView A, const double *__r
   if (lane == 0 && row < A.n_rows) y[row] = s;
 }
 
+// ------------------------------------------------------------------ LDS-staged CSR-stream kernels
+// Workgroup = a run of whole rows with <= kStreamNnz non-zeros.  Phase 1 streams val/col with every
+// lane busy (no per-row divergence) and parks the products in LDS; phase 2 sums each row's slice
+// with RG lanes.  HBM sees one coalesced pass over the matrix.
+constexpr int RG = 4;  // lanes cooperating on one row in the reduce phase
+
+template <int VEC>
+__device__ __forceinline__ void stream_products(const int *__restrict__ col, const double *__restrict__ val, int k0,
+                                                int k1, int n_own, const double *__restrict__ xo,
+                                                const double *__restrict__ xg, double *prod) {
+  if (VEC == 2) {
+    for (int k = k0 + 2 * (int)threadIdx.x; k < k1; k += 2 * BLK) {
+      const int2 c = *reinterpret_cast<const int2 *>(col + k);
+      const double2 v = *reinterpret_cast<const double2 *>(val + k);
+      const double x0 = c.x < n_own ? xo[c.x] : xg[c.x - n_own];
+      const double x1 = c.y < n_own ? xo[c.y] : xg[c.y - n_own];
+      prod[k - k0] = v.x * x0;
+      prod[k - k0 + 1] = v.y * x1;
+    }
+  } else {
+    for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK) {
+      const int c = col[k];
+      prod[k - k0] = val[k] * (c < n_own ? xo[c] : xg[c - n_own]);
+    }
+  }
+}
+
+__device__ __forceinline__ double row_sum_lds(const double *prod, int b, int e, int lane) {
+  double s = 0.0;
+  for (int j = b + lane; j < e; j += RG) s += prod[j];
+  return subwave_sum<RG>(s);
+}
+
+template <int VEC, int MODE>
+__global__ __launch_bounds__(BLK) void spmv_stream_kernel(CsrView A, const int *__restrict__ rowblk,
+                                                          const double *__restrict__ xo,
+                                                          const double *__restrict__ xg, double *__restrict__ y,
+                                                          const double *__restrict__ z) {
+  __shared__ double prod[kStreamNnz];
+  const int r0 = rowblk[blockIdx.x], r1 = rowblk[blockIdx.x + 1];
+  const int k0 = A.rowptr[r0], k1 = A.rowptr[r1];
+  stream_products<VEC>(A.col, A.val, k0, k1, A.n_own_cols, xo, xg, prod);
+  __syncthreads();
+  const int lane = threadIdx.x % RG;
+  for (int r = r0 + threadIdx.x / RG; r < r1; r += BLK / RG) {
+    const double sum = row_sum_lds(prod, A.rowptr[r] - k0, A.rowptr[r + 1] - k0, lane);
+    if (lane == 0) {
+      if (MODE == 0) y[r] = sum;
+      else if (MODE == 1) y[r] += sum;
+      else y[r] = z[r] - sum;
+    }
+  }
+}
+
+// y = A xa + B xb over the same rows; rowblk bounds the combined non-zeros of both matrices
+template <int VECA>
+__global__ __launch_bounds__(BLK) void spmv2_stream_kernel(CsrView A, const double *__restrict__ xao,
+                                                           const double *__restrict__ xag, CsrView B,
+                                                           const double *__restrict__ xbo,
+                                                           const double *__restrict__ xbg,
+                                                           const int *__restrict__ rowblk, double *__restrict__ y) {
+  __shared__ double prod[kStreamNnz];
+  const int r0 = rowblk[blockIdx.x], r1 = rowblk[blockIdx.x + 1];
+  const int a0 = A.rowptr[r0], a1 = A.rowptr[r1], b0 = B.rowptr[r0], b1 = B.rowptr[r1];
+  stream_products<VECA>(A.col, A.val, a0, a1, A.n_own_cols, xao, xag, prod);
+  double *prodB = prod + (a1 - a0);
+  stream_products<1>(B.col, B.val, b0, b1, B.n_own_cols, xbo, xbg, prodB);
+  __syncthreads();
+  const int lane = threadIdx.x % RG;
+  for (int r = r0 + threadIdx.x / RG; r < r1; r += BLK / RG) {
+    double sum = 0.0;
+    for (int j = A.rowptr[r] - a0 + lane; j < A.rowptr[r + 1] - a0; j += RG) sum += prod[j];
+    for (int j = B.rowptr[r] - b0 + lane; j < B.rowptr[r + 1] - b0; j += RG) sum += prodB[j];
+    sum = subwave_sum<RG>(sum);
+    if (lane == 0) y[r] = sum;
+  }
+}
+
+template <int LOWER, int KIND>
+__global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, const double *__restrict__ dinv,
+                                                         const int *__restrict__ perm,
+                                                         const double *__restrict__ rhs, double *__restrict__ y,
+                                                         double *__restrict__ out) {
+  __shared__ double prod[kStreamNnz];
+  const int blk = b0 + blockIdx.x;
+  const int r0 = M.rowblk[blk], r1 = M.rowblk[blk + 1];
+  const int k0 = M.rowptr[r0], k1 = M.rowptr[r1];
+  for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK) prod[k - k0] = M.val[k] * y[M.col[k]];
+  __syncthreads();
+  const int lane = threadIdx.x % RG;
+  for (int r = r0 + threadIdx.x / RG; r < r1; r += BLK / RG) {
+    const double sum = row_sum_lds(prod, M.rowptr[r] - k0, M.rowptr[r + 1] - k0, lane);
+    if (lane == 0) {
+      if (LOWER) {
+        const double b = rhs[perm ? perm[r] : r];
+        y[r] = KIND == 0 ? (b - sum) : (b - sum) * dinv[r];
+      } else {
+        const double x = KIND == 0 ? (y[r] - sum) * dinv[r] : y[r] - sum * dinv[r];
+        y[r] = x;
+        out[perm ? perm[r] : r] = x;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ element-wise
 template <class F>
 __global__ __launch_bounds__(BLK) void ew_kernel(int n, F f) {
@@ -358,6 +463,34 @@ void spmv2(hipStream_t s, const CsrView &A, const double *xao, const double *xag
   if (L == 32) hipLaunchKernelGGL((spmv2_kernel<32>), dim3(grid), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, y);
   else if (L == 16) hipLaunchKernelGGL((spmv2_kernel<16>), dim3(grid), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, y);
   else hipLaunchKernelGGL((spmv2_kernel<8>), dim3(grid), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, y);
+}
+
+void spmv_stream(hipStream_t s, const CsrView &A, const int *rowblk, int nblk, int even_rows, const double *xo,
+                 const double *xg, double *y, int mode, const double *z) {
+  if (nblk <= 0) return;
+#define NSK_SS(V, M) hipLaunchKernelGGL((spmv_stream_kernel<V, M>), dim3(nblk), dim3(BLK), 0, s, A, rowblk, xo, xg, y, z)
+  if (even_rows) {
+    if (mode == 0) NSK_SS(2, 0); else if (mode == 1) NSK_SS(2, 1); else NSK_SS(2, 2);
+  } else {
+    if (mode == 0) NSK_SS(1, 0); else if (mode == 1) NSK_SS(1, 1); else NSK_SS(1, 2);
+  }
+#undef NSK_SS
+}
+
+void spmv2_stream(hipStream_t s, const CsrView &A, const double *xao, const double *xag, const CsrView &B,
+                  const double *xbo, const double *xbg, const int *rowblk, int nblk, double *y) {
+  if (nblk <= 0) return;
+  hipLaunchKernelGGL((spmv2_stream_kernel<2>), dim3(nblk), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, rowblk, y);
+}
+
+void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, const double *dinv,
+                      const int *perm, const double *rhs, double *y, double *out) {
+  const int nb = b1 - b0;
+  if (nb <= 0) return;
+#define NSK_TS(L, K) hipLaunchKernelGGL((tri_stream_kernel<L, K>), dim3(nb), dim3(BLK), 0, s, M, b0, dinv, perm, rhs, y, out)
+  if (lower) { if (kind == 0) NSK_TS(1, 0); else NSK_TS(1, 1); }
+  else { if (kind == 0) NSK_TS(0, 0); else NSK_TS(0, 1); }
+#undef NSK_TS
 }
 
 #define NSK_EW(n, ...)                                                                       \

@@ -188,6 +188,48 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   lpr = mean_half <= 6 ? 4 : (mean_half <= 14 ? 8 : (mean_half <= 48 ? 16 : 32));
 
   hipStream_t s = ctx->stream;
+  stream_ready = false;
+  if (!perm.empty()) {
+    // strict-lower / strict-upper CSR halves with every colour a contiguous run of rows
+    std::vector<int> lrp(n + 1, 0), urp(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+      lrp[i + 1] = lrp[i] + (pdiag[i] - prp[i]);
+      urp[i + 1] = urp[i] + (prp[i + 1] - pdiag[i] - 1);
+    }
+    nnzL = lrp[n];
+    nnzU = urp[n];
+    std::vector<int> lcol((size_t)nnzL), lsrc((size_t)nnzL), ucol((size_t)nnzU), usrc((size_t)nnzU);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+      int w = lrp[i];
+      for (int k = prp[i]; k < pdiag[i]; ++k, ++w) { lcol[w] = pcol[k]; lsrc[w] = k; }
+      w = urp[i];
+      for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k, ++w) { ucol[w] = pcol[k]; usrc[w] = k; }
+    }
+    std::vector<int> cuts(hLp.begin() + 1, hLp.end());  // colour boundaries (levL = colour, rows ascending)
+    std::vector<int> lb, ub;
+    if (build_rowblocks(lrp.data(), nullptr, n, kStreamNnz, &cuts, lb) &&
+        build_rowblocks(urp.data(), nullptr, n, kStreamNnz, &cuts, ub)) {
+      auto first_block_of = [&](const std::vector<int> &blk, std::vector<int> &out) {
+        out.assign(n_colors + 1, 0);
+        size_t b = 0;
+        for (int c = 0; c <= n_colors; ++c) {
+          const int row = c < n_colors ? hLp[c] : n;
+          while (b + 1 < blk.size() && blk[b] < row) ++b;
+          out[c] = (int)b;
+        }
+      };
+      first_block_of(lb, LB);
+      first_block_of(ub, UB);
+      Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Lblk.upload(lb, s);
+      Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Ublk.upload(ub, s);
+      Lval.alloc((size_t)nnzL);
+      Uval.alloc((size_t)nnzU);
+      dinv.alloc((size_t)n);
+      ctx->sync();
+      stream_ready = true;
+    }
+  }
   rowptr.upload(prp, s);
   col.upload(pcol, s);
   srcpos.upload(psrc, s);
@@ -205,15 +247,30 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
 void TriSolve::numeric(const double *a_val_dev) {
   hipStream_t s = ctx->stream;
   vec_gather(s, (int)nnz, srcpos.p, a_val_dev, val.p);
-  if (kind != 0) return;
-  for (const Step &st : schedL) {
-    if (st.serial) ilu0_factor_serial(s, lvlL_ptr.p, lvlL_rows.p, st.l0, st.l1, rowptr.p, diag.p, col.p, val.p, max_row_nnz);
-    else ilu0_factor_level(s, st.nrows, lvlL_rows.p + st.row_off, rowptr.p, diag.p, col.p, val.p, max_row_nnz);
+  if (kind == 0) {
+    for (const Step &st : schedL) {
+      if (st.serial) ilu0_factor_serial(s, lvlL_ptr.p, lvlL_rows.p, st.l0, st.l1, rowptr.p, diag.p, col.p, val.p, max_row_nnz);
+      else ilu0_factor_level(s, st.nrows, lvlL_rows.p + st.row_off, rowptr.p, diag.p, col.p, val.p, max_row_nnz);
+    }
+  }
+  if (stream_ready) {
+    vec_gather(s, (int)nnzL, Lsrc.p, val.p, Lval.p);
+    vec_gather(s, (int)nnzU, Usrc.p, val.p, Uval.p);
+    vec_gather(s, n, diag.p, val.p, dinv.p);
+    vec_recip(s, n, dinv.p, dinv.p);
   }
 }
 
 void TriSolve::apply(const double *b, double *x) {
   hipStream_t s = ctx->stream;
+  if (stream_ready && use_stream) {
+    const TriHalf L{Lrp.p, Lcol.p, Lval.p, Lblk.p}, U{Urp.p, Ucol.p, Uval.p, Ublk.p};
+    for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, dinv.p, d_perm.p, b, y.p, nullptr);
+    for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, dinv.p, d_perm.p, nullptr, y.p, x);
+    ++ctx->st.tri_applies;
+    ctx->st.tri_bytes += (double)apply_bytes();
+    return;
+  }
   const TriView T = view();
   for (const Step &st : schedL) {
     if (st.serial) tri_lower_serial(s, T, kind, lvlL_ptr.p, lvlL_rows.p, st.l0, st.l1, b, y.p);

@@ -39,6 +39,13 @@ struct TriSolve {
   };
   std::vector<Step> schedL, schedU;
 
+  // split factors for the streamed kernels (multicolour ordering: one colour = one contiguous level)
+  bool use_stream = true, stream_ready = false;
+  DBuf<int> Lrp, Lcol, Lsrc, Lblk, Urp, Ucol, Usrc, Ublk;
+  DBuf<double> Lval, Uval, dinv;
+  std::vector<int> LB, UB;  // per colour: first workgroup of that colour in Lblk / Ublk (n_colors + 1)
+  int64_t nnzL = 0, nnzU = 0;
+
   // A: host pattern of the local block (columns >= A.n_rows, i.e. ghosts, are dropped);
   // sub_off: optional n_sub+1 offsets of emulated MPI ranks inside this GPU (block Jacobi)
   void analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off);

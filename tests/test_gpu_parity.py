@@ -232,3 +232,38 @@ def test_zero_iterations_when_already_converged(handles):
     assert rc == 0 and its > 0
     _, _, its2, _, rc2 = ls.solve(S.FGMRES, 1e-8, 20000, pr.rhs_u, pr.rhs_p, xu, xp)
     assert rc2 == 0 and its2 == 0
+
+
+@pytest.mark.parametrize("stream", [0, 1])
+def test_both_kernel_families(stream):
+    """CSR-vector (sub-wavefront per row) and LDS-staged CSR-stream kernels give the same results."""
+    S, O = _S(), _O()
+    pr = problem("ns60")
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr)
+        ls.set_option(S.OPT_TRI_ORDERING, 1)
+        ls.set_option(S.OPT_STREAM_KERNELS, stream)
+        for blk, csr in ((S.BLK_F, pr.F), (S.BLK_BT, pr.Bt), (S.BLK_B, pr.B), (S.BLK_MP, pr.Mp)):
+            x = rng_vec(csr.cols, 40 + blk)
+            assert rel_err(ls.spmv(blk, x), O.spmv(O.CsrHolder.from_block(csr), x)) <= 1e-13
+        xu, xp = rng_vec(pr.n_u, 1), rng_vec(pr.n_p, 2)
+        yu, yp = ls.jacobian_vmult(xu, xp)
+        assert rel_err(np.concatenate([yu, yp]), pr.jacobian_scipy() @ np.concatenate([xu, xp])) <= 1e-13
+        ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+        rp, col, val = ls.get_block(S.BLK_S)
+        import scipy.sparse as sp
+        Sm = sp.csr_matrix((val, col, rp), shape=(pr.n_p, pr.n_p))
+        for which, A, n in ((S.TRI_VELOCITY, O.CsrHolder.from_block(pr.F), pr.n_u),
+                            (S.TRI_PRESSURE, O.CsrHolder.from_scipy(Sm), pr.n_p)):
+            b = rng_vec(n, 50 + which)
+            ref = O.Tri(A, kind=0, perm=ls.tri_perm(which)).apply(b)
+            assert rel_err(ls.tri_apply(which, b), ref) <= 1e-11
+        xs = rng_vec(pr.n_p, 9)
+        assert rel_err(ls.spmv(S.BLK_S, xs), Sm @ xs) <= 1e-13
+        ls.setup_preconditioner(S.BLOCK_DIAGONAL, S.STATIONARY)
+        b = rng_vec(pr.n_u, 60)
+        ref = O.Tri(O.CsrHolder.from_block(pr.F), kind=1, perm=ls.tri_perm(S.TRI_VELOCITY)).apply(b)
+        assert rel_err(ls.tri_apply(S.TRI_VELOCITY, b), ref) <= 1e-11
+    finally:
+        ls.close()
