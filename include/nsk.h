@@ -74,6 +74,11 @@ typedef struct {
 /* 128-byte RCCL unique id, produced on rank 0 and distributed by the caller (e.g. MPI_Bcast). */
 int nsk_get_unique_id(void *out128);
 
+/* Test/development transport: a 128-byte pseudo id that makes the nranks handles created with it in
+ * ONE process (one thread per rank) talk through host barriers and device-to-device copies instead
+ * of RCCL (which refuses two ranks on one device).  Same data path otherwise. */
+int nsk_local_group_id(int nranks, void *out128);
+
 /* One handle per rank.  unique_id may be NULL when nranks == 1. */
 nsk_handle nsk_create(int rank, int nranks, int device_id, const void *rccl_unique_id);
 void nsk_destroy(nsk_handle h);

@@ -403,6 +403,12 @@ int nsk_get_unique_id(void *out128) {
   return 0;
 }
 
+int nsk_local_group_id(int nranks, void *out128) {
+  if (nranks < 1 || !out128) return -1;
+  make_local_group(nranks, out128);
+  return 0;
+}
+
 nsk_handle nsk_create(int rank, int nranks, int device_id, const void *uid) {
   H *h = new H();
   try {

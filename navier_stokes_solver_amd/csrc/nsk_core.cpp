@@ -4,6 +4,10 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
 
 namespace nsk {
 
@@ -14,35 +18,140 @@ namespace nsk {
       throw ::nsk::Error(-20, std::string(#call) + ": " + ncclGetErrorString(r__));        \
   } while (0)
 
+// ---------------------------------------------------------------- local group (threads of one process)
+struct LocalGroup {
+  int n = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int waiting = 0;
+  long generation = 0;
+  std::vector<Comm *> members;
+  std::vector<double> scratch;  // n * kCap
+  static constexpr int kCap = 64;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    const long gen = generation;
+    if (++waiting == n) {
+      waiting = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+namespace {
+std::mutex g_groups_mutex;
+std::map<int, std::shared_ptr<LocalGroup>> g_groups;
+int g_next_group = 1;
+constexpr char kLocalMagic[8] = {'N', 'S', 'K', 'L', 'O', 'C', 'A', 'L'};
+}  // namespace
+
+int make_local_group(int nranks, void *out128) {
+  std::lock_guard<std::mutex> lk(g_groups_mutex);
+  auto g = std::make_shared<LocalGroup>();
+  g->n = nranks;
+  g->members.assign(nranks, nullptr);
+  g->scratch.assign((size_t)nranks * LocalGroup::kCap, 0.0);
+  const int id = g_next_group++;
+  g_groups[id] = g;
+  std::memset(out128, 0, 128);
+  std::memcpy(out128, kLocalMagic, 8);
+  std::memcpy((char *)out128 + 8, &id, sizeof(int));
+  std::memcpy((char *)out128 + 12, &nranks, sizeof(int));
+  return id;
+}
+
 void Comm::init(int rank_, int nranks_, const void *unique_id) {
   rank = rank_;
   nranks = nranks_;
   comm = nullptr;
-  if (nranks > 1) {
-    if (!unique_id) throw Error(-21, "nranks > 1 needs an RCCL unique id");
-    ncclUniqueId id;
-    static_assert(sizeof(ncclUniqueId) == 128, "unique id size");
-    std::memcpy(&id, unique_id, sizeof(id));
-    ncclComm_t c;
-    NSK_NCCL(ncclCommInitRank(&c, nranks, id, rank));
-    comm = c;
+  local = nullptr;
+  if (nranks <= 1) return;
+  if (!unique_id) throw Error(-21, "nranks > 1 needs an RCCL unique id");
+  if (std::memcmp(unique_id, kLocalMagic, 8) == 0) {
+    int id = 0, n = 0;
+    std::memcpy(&id, (const char *)unique_id + 8, sizeof(int));
+    std::memcpy(&n, (const char *)unique_id + 12, sizeof(int));
+    std::shared_ptr<LocalGroup> g;
+    {
+      std::lock_guard<std::mutex> lk(g_groups_mutex);
+      auto it = g_groups.find(id);
+      if (it == g_groups.end() || n != nranks) throw Error(-22, "unknown local group");
+      g = it->second;
+    }
+    local = g.get();
+    local->members[rank] = this;
+    NSK_HIP(hipHostMalloc((void **)&h_tmp, sizeof(double) * LocalGroup::kCap, hipHostMallocDefault));
+    local->barrier();
+    return;
   }
+  ncclUniqueId id;
+  static_assert(sizeof(ncclUniqueId) == 128, "unique id size");
+  std::memcpy(&id, unique_id, sizeof(id));
+  ncclComm_t c;
+  NSK_NCCL(ncclCommInitRank(&c, nranks, id, rank));
+  comm = c;
 }
 
 void Comm::destroy() {
   if (comm) ncclCommDestroy((ncclComm_t)comm);
   comm = nullptr;
+  if (h_tmp) (void)hipHostFree(h_tmp);
+  h_tmp = nullptr;
+  local = nullptr;
 }
 
 void Comm::allreduce_sum(double *d, int count, hipStream_t s) {
   if (nranks <= 1) return;
+  if (local) {
+    if (count > LocalGroup::kCap) throw Error(-23, "local allreduce: too many values");
+    NSK_HIP(hipMemcpyAsync(h_tmp, d, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
+    NSK_HIP(hipStreamSynchronize(s));
+    std::memcpy(&local->scratch[(size_t)rank * LocalGroup::kCap], h_tmp, sizeof(double) * (size_t)count);
+    local->barrier();
+    for (int i = 0; i < count; ++i) {
+      double sum = 0.0;
+      for (int r = 0; r < nranks; ++r) sum += local->scratch[(size_t)r * LocalGroup::kCap + i];  // rank order: every rank gets the same bits
+      h_tmp[i] = sum;
+    }
+    local->barrier();
+    NSK_HIP(hipMemcpyAsync(d, h_tmp, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s));
+    NSK_HIP(hipStreamSynchronize(s));
+    return;
+  }
   NSK_NCCL(ncclAllReduce(d, d, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)comm, s));
 }
 
 // SpMV ghost import (Epetra_Import equivalent): pack owned boundary entries, grouped
 // send/recv with each strip neighbour, ghosts land directly in the vector's ghost tail.
 void Comm::halo_exchange(Space &sp, const DVec &x, hipStream_t s) {
-  if (nranks <= 1 || sp.peers.empty()) return;
+  if (nranks <= 1) return;
+  if (local) {
+    // every rank of the group enters, also one without neighbours in this space
+    if (sp.n_send > 0) halo_pack(s, sp.n_send, sp.d_send_idx.p, x.own, sp.d_send_buf.p);
+    NSK_HIP(hipStreamSynchronize(s));
+    pub_buf = sp.d_send_buf.p;
+    pub_peers = &sp.peers;
+    pub_send_ptr = &sp.send_ptr;
+    local->barrier();
+    for (size_t k = 0; k < sp.peers.size(); ++k) {
+      const int nr = sp.recv_ptr[k + 1] - sp.recv_ptr[k];
+      if (nr <= 0) continue;
+      const Comm *peer = local->members[sp.peers[k]];
+      int idx = -1;
+      for (size_t q = 0; q < peer->pub_peers->size(); ++q)
+        if ((*peer->pub_peers)[q] == rank) idx = (int)q;
+      if (idx < 0 || (*peer->pub_send_ptr)[idx + 1] - (*peer->pub_send_ptr)[idx] != nr)
+        throw Error(-24, "local halo exchange: plans of the two ranks do not match");
+      NSK_HIP(hipMemcpyAsync(x.ghost + sp.recv_ptr[k], peer->pub_buf + (*peer->pub_send_ptr)[idx],
+                             sizeof(double) * (size_t)nr, hipMemcpyDeviceToDevice, s));
+    }
+    NSK_HIP(hipStreamSynchronize(s));
+    local->barrier();
+    return;
+  }
+  if (sp.peers.empty()) return;
   if (sp.n_send > 0) halo_pack(s, sp.n_send, sp.d_send_idx.p, x.own, sp.d_send_buf.p);
   NSK_NCCL(ncclGroupStart());
   for (size_t k = 0; k < sp.peers.size(); ++k) {

@@ -122,14 +122,27 @@ inline int pick_lpr(int64_t nnz, int n_rows) {
 }
 
 // RCCL over xGMI: one communicator per handle, everything on the compute stream.
+// A second transport, "local group", joins several handles of ONE process (one thread per rank, all
+// on GPUs this process can reach): collectives go through host barriers and device-to-device copies.
+// It exists so that the whole multi-rank data path can be exercised on a single-GPU box, where RCCL
+// refuses two ranks on one device; production multi-GPU runs use RCCL.
+struct LocalGroup;
 struct Comm {
   int rank = 0, nranks = 1;
   ncclComm *comm = nullptr;
+  LocalGroup *local = nullptr;
+  // what this rank currently offers to its peers in a local-group halo exchange
+  const double *pub_buf = nullptr;
+  const std::vector<int> *pub_peers = nullptr, *pub_send_ptr = nullptr;
+  double *h_tmp = nullptr;
   void init(int rank, int nranks, const void *unique_id);
   void destroy();
   void allreduce_sum(double *d, int count, hipStream_t s);
   void halo_exchange(Space &sp, const DVec &x, hipStream_t s);
 };
+
+// 128-byte pseudo unique id that makes nsk_create join an in-process group instead of RCCL
+int make_local_group(int nranks, void *out128);
 
 struct Stats {
   double setup_ms = 0, solve_ms = 0;

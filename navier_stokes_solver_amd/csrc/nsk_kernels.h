@@ -95,10 +95,12 @@ void tri_lower_serial(hipStream_t s, const TriView &T, int kind, const int *lvl_
                       const double *rhs, double *y);
 void tri_upper_serial(hipStream_t s, const TriView &T, int kind, const int *lvl_ptr, const int *rows, int l0, int l1,
                       double *y, double *out);
-// Streamed level of a triangular solve on split factors: M = strict-lower or strict-upper CSR in the
-// permuted ordering with the rows of one level contiguous; blocks [b0, b1) of rowblk cover the level.
-//   lower: y[r] = (rhs[perm[r]] - sum) * (kind ? dinv[r] : 1)
-//   upper: x = kind ? y[r] - sum*dinv[r] : (y[r] - sum)*dinv[r];  y[r] = x;  out[perm[r]] = x
+// Streamed level of a triangular solve on split factors: M = strict-lower or strict-upper CSR whose
+// ROWS are in the permuted (colour) order, one level = one contiguous run of rows covered by
+// workgroups [b0, b1) of rowblk, while COLUMN ids and the vector x stay in the caller's numbering
+// (i = perm[r]):
+//   lower: x[i] = (rhs[i] - sum) * (kind ? dinv[r] : 1)
+//   upper: x[i] = kind ? x[i] - sum*dinv[r] : (x[i] - sum)*dinv[r]
 struct TriHalf {
   const int *rowptr;
   const int *col;
@@ -106,7 +108,7 @@ struct TriHalf {
   const int *rowblk;
 };
 void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, const double *dinv,
-                      const int *perm, const double *rhs, double *y, double *out);
+                      const int *perm, const double *rhs, double *x);
 
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,

@@ -170,28 +170,31 @@ __global__ __launch_bounds__(BLK) void spmv2_stream_kernel(CsrView A, const doub
   }
 }
 
+// Streamed level of a triangular solve.  Rows r of the level are contiguous in the permuted
+// (colour) order, but the solution vector x and the column ids stay in the CALLER's (lattice)
+// numbering: the gathers x[col] of one row then fall into a few runs of neighbouring entries, like
+// the x-gathers of the SpMV, instead of one cache line per entry.
 template <int LOWER, int KIND>
 __global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, const double *__restrict__ dinv,
                                                          const int *__restrict__ perm,
-                                                         const double *__restrict__ rhs, double *__restrict__ y,
-                                                         double *__restrict__ out) {
+                                                         const double *__restrict__ rhs, double *__restrict__ x) {
   __shared__ double prod[kStreamNnz];
   const int blk = b0 + blockIdx.x;
   const int r0 = M.rowblk[blk], r1 = M.rowblk[blk + 1];
   const int k0 = M.rowptr[r0], k1 = M.rowptr[r1];
-  for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK) prod[k - k0] = M.val[k] * y[M.col[k]];
+  for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK) prod[k - k0] = M.val[k] * x[M.col[k]];
   __syncthreads();
   const int lane = threadIdx.x % RG;
   for (int r = r0 + threadIdx.x / RG; r < r1; r += BLK / RG) {
     const double sum = row_sum_lds(prod, M.rowptr[r] - k0, M.rowptr[r + 1] - k0, lane);
     if (lane == 0) {
+      const int i = perm[r];
       if (LOWER) {
-        const double b = rhs[perm ? perm[r] : r];
-        y[r] = KIND == 0 ? (b - sum) : (b - sum) * dinv[r];
+        const double b = rhs[i];
+        x[i] = KIND == 0 ? (b - sum) : (b - sum) * dinv[r];
       } else {
-        const double x = KIND == 0 ? (y[r] - sum) * dinv[r] : y[r] - sum * dinv[r];
-        y[r] = x;
-        out[perm ? perm[r] : r] = x;
+        const double y = x[i];
+        x[i] = KIND == 0 ? (y - sum) * dinv[r] : y - sum * dinv[r];
       }
     }
   }
@@ -484,10 +487,10 @@ void spmv2_stream(hipStream_t s, const CsrView &A, const double *xao, const doub
 }
 
 void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, const double *dinv,
-                      const int *perm, const double *rhs, double *y, double *out) {
+                      const int *perm, const double *rhs, double *x) {
   const int nb = b1 - b0;
   if (nb <= 0) return;
-#define NSK_TS(L, K) hipLaunchKernelGGL((tri_stream_kernel<L, K>), dim3(nb), dim3(BLK), 0, s, M, b0, dinv, perm, rhs, y, out)
+#define NSK_TS(L, K) hipLaunchKernelGGL((tri_stream_kernel<L, K>), dim3(nb), dim3(BLK), 0, s, M, b0, dinv, perm, rhs, x)
   if (lower) { if (kind == 0) NSK_TS(1, 0); else NSK_TS(1, 1); }
   else { if (kind == 0) NSK_TS(0, 0); else NSK_TS(0, 1); }
 #undef NSK_TS

@@ -199,12 +199,23 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     nnzL = lrp[n];
     nnzU = urp[n];
     std::vector<int> lcol((size_t)nnzL), lsrc((size_t)nnzL), ucol((size_t)nnzU), usrc((size_t)nnzU);
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < n; ++i) {
-      int w = lrp[i];
-      for (int k = prp[i]; k < pdiag[i]; ++k, ++w) { lcol[w] = pcol[k]; lsrc[w] = k; }
-      w = urp[i];
-      for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k, ++w) { ucol[w] = pcol[k]; usrc[w] = k; }
+    // column ids go back to the caller's numbering, sorted, so that a row's gathers are runs of neighbours
+#pragma omp parallel
+    {
+      std::vector<std::pair<int, int>> buf;
+#pragma omp for schedule(static)
+      for (int i = 0; i < n; ++i) {
+        buf.clear();
+        for (int k = prp[i]; k < pdiag[i]; ++k) buf.emplace_back(perm[pcol[k]], k);
+        std::sort(buf.begin(), buf.end());
+        int w = lrp[i];
+        for (auto &e : buf) { lcol[w] = e.first; lsrc[w] = e.second; ++w; }
+        buf.clear();
+        for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k) buf.emplace_back(perm[pcol[k]], k);
+        std::sort(buf.begin(), buf.end());
+        w = urp[i];
+        for (auto &e : buf) { ucol[w] = e.first; usrc[w] = e.second; ++w; }
+      }
     }
     std::vector<int> cuts(hLp.begin() + 1, hLp.end());  // colour boundaries (levL = colour, rows ascending)
     std::vector<int> lb, ub;
@@ -265,8 +276,9 @@ void TriSolve::apply(const double *b, double *x) {
   hipStream_t s = ctx->stream;
   if (stream_ready && use_stream) {
     const TriHalf L{Lrp.p, Lcol.p, Lval.p, Lblk.p}, U{Urp.p, Ucol.p, Uval.p, Ublk.p};
-    for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, dinv.p, d_perm.p, b, y.p, nullptr);
-    for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, dinv.p, d_perm.p, nullptr, y.p, x);
+    // x doubles as the intermediate vector: rows not yet solved hold L^-1 b, solved rows hold the result
+    for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, dinv.p, d_perm.p, b, x);
+    for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, dinv.p, d_perm.p, nullptr, x);
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
     return;

@@ -27,7 +27,7 @@ OPT_TRI_ORDERING, OPT_SUBDOMAINS, OPT_FUSE_BLOCK_ROW, OPT_STREAM_KERNELS = 0, 1,
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
 
 EXPORTS = [
-    "nsk_get_unique_id", "nsk_create", "nsk_destroy", "nsk_last_error", "nsk_set_partition", "nsk_set_halo_plan",
+    "nsk_get_unique_id", "nsk_local_group_id", "nsk_create", "nsk_destroy", "nsk_last_error", "nsk_set_partition", "nsk_set_halo_plan",
     "nsk_set_block_csr", "nsk_update_values", "nsk_set_option", "nsk_setup_preconditioner", "nsk_solve",
     "nsk_upload_system", "nsk_solve_resident", "nsk_download_solution", "nsk_spmv", "nsk_jacobian_vmult", "nsk_dot",
     "nsk_tri_apply", "nsk_tri_get_perm", "nsk_precond_vmult", "nsk_block_nnz", "nsk_get_block", "nsk_get_stats",
@@ -67,6 +67,7 @@ def lib() -> C.CDLL:
         L = C.CDLL(path, mode=C.RTLD_GLOBAL)
         vp, i32p, f64p = C.c_void_p, C.c_void_p, C.c_void_p
         L.nsk_get_unique_id.argtypes = [vp]
+        L.nsk_local_group_id.argtypes = [C.c_int, vp]
         L.nsk_create.restype = vp
         L.nsk_create.argtypes = [C.c_int, C.c_int, C.c_int, vp]
         L.nsk_destroy.argtypes = [vp]
@@ -114,6 +115,14 @@ def get_unique_id() -> bytes:
     rc = lib().nsk_get_unique_id(buf)
     if rc != 0:
         raise RuntimeError(f"nsk_get_unique_id failed: {rc}")
+    return buf.raw
+
+
+def local_group_id(nranks: int) -> bytes:
+    """Pseudo unique id for `nranks` handles living in threads of this process (test transport)."""
+    buf = C.create_string_buffer(128)
+    if lib().nsk_local_group_id(nranks, buf) != 0:
+        raise RuntimeError("nsk_local_group_id failed")
     return buf.raw
 
 

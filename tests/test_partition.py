@@ -1,0 +1,155 @@
+"""Row partition, halo plans and the multi-rank data path.
+
+CPU: plan logic in one process; the whole N>1 sequence over gloo with world size 2 and 3.
+GPU: the same sequence on the HIP path with N rank threads in one process (local-group transport,
+because RCCL refuses two ranks on one device); RCCL itself runs at round end on the 8-GPU node."""
+import os
+import socket
+import tempfile
+import threading
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from navier_stokes_solver_amd import partition as PT
+from navier_stokes_solver_amd import problem as P
+from tests.util import CASES, problem, rel_err, rng_vec
+
+CASE = CASES["unsteady16"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 4])
+def test_halo_plans_move_the_right_entries(nranks):
+    parts = [P.generate(**CASE, nranks=nranks, rank=r) for r in range(nranks)]
+    for space, ranges, key in (("u", parts[0].u_ranges, "ghost_u"), ("p", parts[0].p_ranges, "ghost_p")):
+        ghosts = [getattr(p, key) for p in parts]
+        plans = [PT.build_halo_plan(r, ranges, ghosts) for r in range(nranks)]
+        n_glob = int(ranges[-1])
+        xg = rng_vec(n_glob, 5)
+        for r, pl in enumerate(plans):
+            assert pl["recv_ptr"][-1] == len(ghosts[r])
+            got = np.full(len(ghosts[r]), np.nan)
+            for k, q in enumerate(pl["peers"]):
+                qp = plans[q]
+                kk = list(qp["peers"]).index(r)
+                sent = xg[ranges[q]:ranges[q + 1]][qp["send_idx"][qp["send_ptr"][kk]:qp["send_ptr"][kk + 1]]]
+                assert len(sent) == pl["recv_ptr"][k + 1] - pl["recv_ptr"][k]
+                got[pl["recv_ptr"][k]:pl["recv_ptr"][k + 1]] = sent
+            assert np.array_equal(got, xg[ghosts[r]])
+            # strips only talk to their neighbours
+            assert set(pl["peers"]) <= {r - 1, r + 1}
+
+
+def test_plan_rejects_bad_input():
+    with pytest.raises(ValueError):
+        PT.build_halo_plan(0, np.array([0, 4, 8]), [np.array([5, 4]), np.array([1])])
+    with pytest.raises(ValueError):
+        PT.build_halo_plan(0, np.array([0, 4, 8]), [np.array([2]), np.array([1])])
+
+
+def _reference_pieces(world):
+    """One-process oracle with `world` emulated ranks (block-Jacobi ILU on the strip blocks)."""
+    from oracle import oracle as O
+    pr = problem("unsteady16")
+    parts0 = P.generate(**CASE, nranks=world, rank=0)
+    J = pr.jacobian_scipy()
+    xu = np.random.default_rng(1).uniform(-1, 1, pr.n_u)
+    xp = np.random.default_rng(2).uniform(-1, 1, pr.n_p)
+    y = J @ np.concatenate([xu, xp])
+    op = O.OracleProblem.from_local(pr, u_shard_off=parts0.u_ranges, p_shard_off=parts0.p_ranges)
+    dst, rc = op.prec_apply(np.concatenate([xu, xp]), prec=2, variant=1, alpha=0.5)
+    assert rc == 0
+    F, B, Bt = pr.F.to_scipy(), pr.B.to_scipy(), pr.Bt.to_scipy()
+    S = (B @ sp.diags(1.0 / F.diagonal()) @ Bt).tocsr()
+    return dict(y=y, dot=float(np.dot(np.concatenate([xu, xp]), y)), dst=dst, sy=S @ xp, xu=xu, xp=xp, pr=pr)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_path_over_gloo(world):
+    import torch.multiprocessing as mp
+    from tests import dist_cpu_worker
+    ref = _reference_pieces(world)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "out.npz")
+        mp.spawn(dist_cpu_worker.worker, args=(world, _free_port(), CASE, out), nprocs=world, join=True)
+        got = np.load(out)
+        n_u = ref["pr"].n_u
+        assert rel_err(np.concatenate([got["yu"], got["yp"]]), ref["y"]) <= 1e-13
+        assert abs(got["dot"][0] - ref["dot"]) <= 1e-12 * abs(ref["dot"])
+        assert rel_err(got["sy"], ref["sy"]) <= 1e-12
+        assert rel_err(np.concatenate([got["du"], got["dp"]]), ref["dst"]) <= 1e-10
+        assert got["u_ranges"][-1] == n_u
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,prec,variant,ordering", [(2, 2, 1, 0), (3, 2, 1, 1), (2, 2, 0, 1), (2, 0, 0, 0)])
+def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering):
+    """N rank threads on one GPU: ghost import, global reductions, D^-1 halo, SpGEMM with imported
+    (0,1) rows, rank-local ILU, full FGMRES solve — against the oracle with N emulated ranks."""
+    import scipy.sparse.linalg as spl
+    from navier_stokes_solver_amd import solver as S
+    from oracle import oracle as O
+    name = "unsteady16" if variant == 1 else "ns16"
+    case = CASES[name]
+    pr = problem(name)
+    parts = [P.generate(**case, nranks=world, rank=r) for r in range(world)]
+    plans = [{S.SPACE_U: PT.build_halo_plan(r, parts[0].u_ranges, [p.ghost_u for p in parts]),
+              S.SPACE_P: PT.build_halo_plan(r, parts[0].p_ranges, [p.ghost_p for p in parts])} for r in range(world)]
+    uid = S.local_group_id(world)
+    xu = rng_vec(pr.n_u, 1)
+    xp = rng_vec(pr.n_p, 2)
+    res, errs = [None] * world, []
+
+    def run(r):
+        try:
+            ls = S.LinearSolver(r, world, 0, uid)
+            p = parts[r]
+            ls.set_option(S.OPT_TRI_ORDERING, ordering)
+            ls.set_problem(p, plans[r])
+            ur, prg = p.u_ranges, p.p_ranges
+            yu, yp = ls.jacobian_vmult(xu[ur[r]:ur[r + 1]], xp[prg[r]:prg[r + 1]])
+            ls.setup_preconditioner(prec, variant, 0.5)
+            perm_u, perm_p = ls.tri_perm(S.TRI_VELOCITY), ls.tri_perm(S.TRI_PRESSURE)
+            du, dp, rc = ls.precond_vmult(xu[ur[r]:ur[r + 1]], xp[prg[r]:prg[r + 1]])
+            ls.setup_preconditioner(prec, variant, 0.5)
+            su, spp, its, fres, src = ls.solve(S.FGMRES, 1e-12, 100000, p.rhs_u, p.rhs_p, p.x0_u, p.x0_p)
+            res[r] = dict(yu=yu, yp=yp, du=du, dp=dp, rc=rc, su=su, sp=spp, its=its, src=src, perm_u=perm_u, perm_p=perm_p)
+            ls.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(600) for t in th]
+    assert not errs, errs
+    assert all(r is not None for r in res)
+    J = pr.jacobian_scipy().tocsc()
+    y = J @ np.concatenate([xu, xp])
+    cat = lambda k: np.concatenate([r[k] for r in res])  # noqa: E731
+    assert rel_err(np.concatenate([cat("yu"), cat("yp")]), y) <= 1e-13
+    kw = dict(u_shard_off=parts[0].u_ranges, p_shard_off=parts[0].p_ranges)
+    if ordering:
+        # rank-local permutations stitched into one global permutation of the block-diagonal matrix
+        kw["perm_F"] = np.concatenate([r["perm_u"] + parts[0].u_ranges[k] for k, r in enumerate(res)])
+        pk = "perm_S" if prec == 2 else "perm_Mp"
+        kw[pk] = np.concatenate([r["perm_p"] + parts[0].p_ranges[k] for k, r in enumerate(res)])
+    op = O.OracleProblem.from_local(pr, **kw)
+    dst, rc = op.prec_apply(np.concatenate([xu, xp]), prec=prec, variant=variant, alpha=0.5)
+    assert rc == 0 and all(r["rc"] == 0 for r in res)
+    tol = 1e-10 if (prec, variant) == (2, 1) else 1e-7
+    assert rel_err(np.concatenate([cat("du"), cat("dp")]), dst) <= tol
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    x = np.concatenate([cat("su"), cat("sp")])
+    assert all(r["src"] == 0 for r in res) and len({r["its"] for r in res}) == 1
+    assert np.linalg.norm(b - J @ x) <= 1.05e-12
+    assert rel_err(x, spl.splu(J).solve(b)) <= 1e-7
+    xo, info = op.solve(b, np.concatenate([pr.x0_u, pr.x0_p]), solver=1, prec=prec, variant=variant, tol=1e-12)
+    assert info["status"] == 0 and rel_err(x, xo) <= 1e-7
+    assert abs(res[0]["its"] - info["iters"]) <= max(3, 0.2 * info["iters"])
