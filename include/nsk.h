@@ -60,7 +60,10 @@ enum {
   NSK_OPT_TRI_ORDERING = 0, /* 0 natural (default), 1 rank-local multicolour permutation */
   NSK_OPT_SUBDOMAINS = 1,   /* emulated MPI ranks per GPU for the block-Jacobi ILU/SGS (default 1) */
   NSK_OPT_FUSE_BLOCK_ROW = 2, /* 1 (default): F x_u + Bt x_p in one kernel */
-  NSK_OPT_STREAM_KERNELS = 3  /* 1 (default): LDS-staged CSR-stream kernels; 0: CSR-vector kernels */
+  NSK_OPT_STREAM_KERNELS = 3, /* 1 (default): LDS-staged CSR-stream kernels; 0: CSR-vector kernels */
+  NSK_OPT_INNER_FUSED_GS = 4, /* 1 (default): inner FGMRES (on F) orthogonalises with fused classical Gram-Schmidt
+                                 (two sweeps, 8 vectors per pass); 0: deal.II's modified Gram-Schmidt (add_and_dot) */
+  NSK_OPT_OUTER_FUSED_GS = 5  /* same for the outer FGMRES; default 0 (modified Gram-Schmidt, as deal.II) */
 };
 
 typedef struct {

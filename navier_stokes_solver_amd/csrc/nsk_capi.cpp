@@ -57,6 +57,7 @@ struct nsk_handle_s {
   VecPool pool_u, pool_p, pool_b;
   bool pools_ready = false;
   int tri_ordering = ORDER_NATURAL, subdomains = 1, fuse_block_row = 1, use_stream = 1;
+  bool inner_fused_gs = true, outer_fused_gs = false;
   DBuf<int> jrow_blk;  // row runs of the fused (F | Bt) block row
   int jrow_nblk = 0;
   bool jrow_ok = false;
@@ -295,6 +296,7 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
     SolverControl cu(max_u, tol_u), cp(max_p, tol_p);
     try {
       SolverFGMRES sv(ctx, pool_u, cu);
+      sv.fused_gs = inner_fused_gs;
       sv.solve(A_F, du, su, P_F);
       inner_u += cu.last_step();
       if (prec_type == 0) {
@@ -321,6 +323,7 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
     try {
       SolverControl cF(100000, 1e-1 * norm_of(su.own, nu));
       SolverFGMRES sF(ctx, pool_u, cF);
+      sF.fused_gs = inner_fused_gs;
       sF.solve(A_F, du, su, P_F);                       // F u~ = src_u
       inner_u += cF.last_step();
       halo(0, du);
@@ -367,7 +370,7 @@ int H::solve_resident(int solver, double tol, int max_iter, int *iters, double *
   const int slot_mark = ctx.slot_top;
   try {
     if (solver == 0) { SolverGMRES sv(ctx, pool_b, control); sv.solve(A, x, b, P); }
-    else if (solver == 1) { SolverFGMRES sv(ctx, pool_b, control); sv.solve(A, x, b, P); }
+    else if (solver == 1) { SolverFGMRES sv(ctx, pool_b, control); sv.fused_gs = outer_fused_gs; sv.solve(A, x, b, P); }
     else { SolverBicgstab sv(ctx, pool_b, control); sv.solve(A, x, b, P); }
   } catch (NoConvergence &e) {
     rc = e.code;
@@ -526,6 +529,8 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
     case NSK_OPT_SUBDOMAINS: h->subdomains = std::max(1, (int)v); break;
     case NSK_OPT_FUSE_BLOCK_ROW: h->fuse_block_row = v != 0.0; break;
     case NSK_OPT_STREAM_KERNELS: h->use_stream = v != 0.0; h->tF.use_stream = h->tMp.use_stream = h->tS.use_stream = h->use_stream; break;
+    case NSK_OPT_INNER_FUSED_GS: h->inner_fused_gs = v != 0.0; break;
+    case NSK_OPT_OUTER_FUSED_GS: h->outer_fused_gs = v != 0.0; break;
     default: throw Error(-61, "nsk_set_option: unknown option");
   }
   return 0;

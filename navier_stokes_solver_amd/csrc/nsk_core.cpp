@@ -169,7 +169,7 @@ void Ctx::init(int device_id) {
   device = device_id;
   NSK_HIP(hipSetDevice(device));
   NSK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  ws_partials.alloc((size_t)kMaxReduceBlocks * 2);
+  ws_partials.alloc((size_t)kMaxReduceBlocks * kMaxReduceOut);
   ws_ticket.alloc(1);
   NSK_HIP(hipMemsetAsync(ws_ticket.p, 0, sizeof(unsigned), stream));
   ws.partials = ws_partials.p;
@@ -240,6 +240,26 @@ void Ctx::cg_update(int n, SRef a, const double *d, const double *h, double *x, 
   st.blas1_bytes += 48.0 * n;
 }
 
+void Ctx::multi_dot(int n, const double *w, double *const *v, int m, int so) {
+  VecPack P{};
+  for (int k = 0; k < m; ++k) P.v[k] = v[k];
+  vec_multi_dot(stream, ws, n, w, P, m, slot(so));
+  comm.allreduce_sum(slot(so), m, stream);
+  ++st.reductions;
+  st.blas1_bytes += 8.0 * n * (m + 1);
+}
+void Ctx::multi_axpy(int n, double *w, double *const *v, int m, int coef_slot, int norm_slot) {
+  VecPack P{};
+  for (int k = 0; k < m; ++k) P.v[k] = v[k];
+  vec_multi_axpy(stream, ws, n, w, P, m, slot(coef_slot), norm_slot >= 0 ? slot(norm_slot) : nullptr);
+  if (norm_slot >= 0 && comm.nranks > 1) {
+    comm.allreduce_sum(slot(norm_slot), 1, stream);
+    scalar_sqrt(stream, slot(norm_slot), slot(norm_slot) + 1);
+  }
+  if (norm_slot >= 0) ++st.reductions;
+  st.blas1_bytes += 8.0 * n * (m + 2);
+}
+
 void Ctx::spmv(Csr &A, Space &colspace, const DVec &x, double *y, int mode, const double *z) {
   comm.halo_exchange(colspace, x, stream);
   if (A.stream_ok) nsk::spmv_stream(stream, A.view(), A.rowblk.p, A.nblk, A.even_rows, x.own, x.ghost, y, mode, z);
@@ -260,7 +280,7 @@ bool build_rowblocks(const int *ra, const int *rb, int n_rows, int max_nnz, cons
     const int limit = (cuts && ci < cuts->size()) ? std::min(n_rows, (*cuts)[ci]) : n_rows;
     int r1 = r0 + 1;
     if (nnz_of(r0, r1) > max_nnz) return false;
-    while (r1 < limit && r1 - r0 < 1024 && nnz_of(r0, r1 + 1) <= max_nnz) ++r1;
+    while (r1 < limit && r1 - r0 < kStreamRows && nnz_of(r0, r1 + 1) <= max_nnz) ++r1;
     rowblk.push_back(r1);
     r0 = r1;
   }

@@ -183,6 +183,9 @@ struct Ctx {
   void norm2(int n, const double *x, int slot_out);  // slot_out = sum of squares, slot_out+1 = norm
   void axpy_dot(int n, SRef a, const double *x, double *y, const double *w, int slot_out);
   void axpy_norm2(int n, SRef a, const double *x, double *y, int slot_out);
+  // fused classical Gram-Schmidt: slots[so..so+m) = w . v[k] ; w -= sum slot[coef+k] v[k] (+ norm)
+  void multi_dot(int n, const double *w, double *const *v, int m, int slot_out);
+  void multi_axpy(int n, double *w, double *const *v, int m, int coef_slot, int norm_slot);
   void cg_update(int n, SRef a, const double *d, const double *h, double *x, double *g, int slot_out);
   void spmv(Csr &A, Space &colspace, const DVec &x, double *y, int mode = 0, const double *z = nullptr);
 };

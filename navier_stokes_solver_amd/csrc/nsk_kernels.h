@@ -20,10 +20,11 @@ inline SRef sref(double c, const double *num, const double *den) { return SRef{c
 
 // workspace of the grid-wide reductions (one per stream)
 struct ReduceWs {
-  double *partials;   // >= kMaxReduceBlocks * 2
+  double *partials;   // >= kMaxReduceBlocks * kMaxReduceOut
   unsigned *ticket;   // zero-initialised, reset by the last block
 };
-constexpr int kMaxReduceBlocks = 1024;
+constexpr int kMaxReduceBlocks = 2048;
+constexpr int kMaxReduceOut = 8;
 
 // ---- CSR SpMV: y = A x | y += A x.  Columns >= n_own read x_ghost[col - n_own]. ----
 struct CsrView {
@@ -45,6 +46,7 @@ void spmv2(hipStream_t s, const CsrView &A, const double *xa_own, const double *
 // products val*x[col] in LDS and then reduces them per row.  even_rows: every rowptr entry is even,
 // which allows 16-byte value / 8-byte index loads.
 constexpr int kStreamNnz = 2048;
+constexpr int kStreamRows = 64;  // rows per run = workgroup size / lanes per row in the reduce phase
 void spmv_stream(hipStream_t s, const CsrView &A, const int *rowblk, int nblk, int even_rows, const double *x_own,
                  const double *x_ghost, double *y, int mode, const double *z);
 void spmv2_stream(hipStream_t s, const CsrView &A, const double *xa_own, const double *xa_ghost, const CsrView &B,
@@ -70,6 +72,15 @@ void vec_axpy_dot(hipStream_t s, const ReduceWs &ws, int n, SRef a, const double
 // CG update: x += a d ; g += a h ; out = g.g, out[1] = sqrt
 void vec_cg_update(hipStream_t s, const ReduceWs &ws, int n, SRef a, const double *d, const double *h, double *x,
                    double *g, double *out);
+// Fused classical Gram-Schmidt building blocks (up to 8 basis vectors per pass):
+//   multi_dot : out[k] = w . v[k]                      (w read once)
+//   multi_axpy: w -= sum_k h[k] v[k] ; if norm_out: norm_out[0] = w.w, norm_out[1] = sqrt
+struct VecPack {
+  const double *v[8];
+};
+void vec_multi_dot(hipStream_t s, const ReduceWs &ws, int n, const double *w, const VecPack &P, int m, double *out);
+void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const VecPack &P, int m, const double *h,
+                    double *norm_out);
 void scalar_sqrt(hipStream_t s, const double *in, double *out);                         // out = sqrt(|in|)
 void vec_gather(hipStream_t s, int n, const int *idx, const double *x, double *y);      // y[i] = x[idx[i]]
 void extract_diag(hipStream_t s, const CsrView &A, double *d, double *dinv);

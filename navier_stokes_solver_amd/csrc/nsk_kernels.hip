@@ -125,6 +125,9 @@ __device__ __forceinline__ double row_sum_lds(const double *prod, int b, int e, 
   return subwave_sum<RG>(s);
 }
 
+// A run holds at most kStreamRows = BLK/RG rows, so the reduce phase is ONE pass: lane group t/RG owns
+// row r0 + t/RG, and its row bounds (and, in the triangular kernels, perm / rhs / diagonal) are
+// loaded BEFORE the streaming phase so their latency hides behind it.
 template <int VEC, int MODE>
 __global__ __launch_bounds__(BLK) void spmv_stream_kernel(CsrView A, const int *__restrict__ rowblk,
                                                           const double *__restrict__ xo,
@@ -133,16 +136,23 @@ __global__ __launch_bounds__(BLK) void spmv_stream_kernel(CsrView A, const int *
   __shared__ double prod[kStreamNnz];
   const int r0 = rowblk[blockIdx.x], r1 = rowblk[blockIdx.x + 1];
   const int k0 = A.rowptr[r0], k1 = A.rowptr[r1];
+  const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
+  const bool have = r < r1;
+  int jb = 0, je = 0;
+  double zv = 0.0;
+  if (have) {
+    jb = A.rowptr[r] - k0;
+    je = A.rowptr[r + 1] - k0;
+    if (MODE == 1) zv = y[r];
+    if (MODE == 2) zv = z[r];
+  }
   stream_products<VEC>(A.col, A.val, k0, k1, A.n_own_cols, xo, xg, prod);
   __syncthreads();
-  const int lane = threadIdx.x % RG;
-  for (int r = r0 + threadIdx.x / RG; r < r1; r += BLK / RG) {
-    const double sum = row_sum_lds(prod, A.rowptr[r] - k0, A.rowptr[r + 1] - k0, lane);
-    if (lane == 0) {
-      if (MODE == 0) y[r] = sum;
-      else if (MODE == 1) y[r] += sum;
-      else y[r] = z[r] - sum;
-    }
+  const double sum = row_sum_lds(prod, jb, je, lane);
+  if (have && lane == 0) {
+    if (MODE == 0) y[r] = sum;
+    else if (MODE == 1) y[r] = zv + sum;
+    else y[r] = zv - sum;
   }
 }
 
@@ -156,18 +166,22 @@ __global__ __launch_bounds__(BLK) void spmv2_stream_kernel(CsrView A, const doub
   __shared__ double prod[kStreamNnz];
   const int r0 = rowblk[blockIdx.x], r1 = rowblk[blockIdx.x + 1];
   const int a0 = A.rowptr[r0], a1 = A.rowptr[r1], b0 = B.rowptr[r0], b1 = B.rowptr[r1];
+  const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
+  const bool have = r < r1;
+  int ab = 0, ae = 0, bb = 0, be = 0;
+  if (have) {
+    ab = A.rowptr[r] - a0; ae = A.rowptr[r + 1] - a0;
+    bb = B.rowptr[r] - b0; be = B.rowptr[r + 1] - b0;
+  }
   stream_products<VECA>(A.col, A.val, a0, a1, A.n_own_cols, xao, xag, prod);
   double *prodB = prod + (a1 - a0);
   stream_products<1>(B.col, B.val, b0, b1, B.n_own_cols, xbo, xbg, prodB);
   __syncthreads();
-  const int lane = threadIdx.x % RG;
-  for (int r = r0 + threadIdx.x / RG; r < r1; r += BLK / RG) {
-    double sum = 0.0;
-    for (int j = A.rowptr[r] - a0 + lane; j < A.rowptr[r + 1] - a0; j += RG) sum += prod[j];
-    for (int j = B.rowptr[r] - b0 + lane; j < B.rowptr[r + 1] - b0; j += RG) sum += prodB[j];
-    sum = subwave_sum<RG>(sum);
-    if (lane == 0) y[r] = sum;
-  }
+  double sum = 0.0;
+  for (int j = ab + lane; j < ae; j += RG) sum += prod[j];
+  for (int j = bb + lane; j < be; j += RG) sum += prodB[j];
+  sum = subwave_sum<RG>(sum);
+  if (have && lane == 0) y[r] = sum;
 }
 
 // Streamed level of a triangular solve.  Rows r of the level are contiguous in the permuted
@@ -175,28 +189,36 @@ __global__ __launch_bounds__(BLK) void spmv2_stream_kernel(CsrView A, const doub
 // numbering: the gathers x[col] of one row then fall into a few runs of neighbouring entries, like
 // the x-gathers of the SpMV, instead of one cache line per entry.
 template <int LOWER, int KIND>
-__global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, const double *__restrict__ dinv,
+__global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int nb, const double *__restrict__ dinv,
                                                          const int *__restrict__ perm,
                                                          const double *__restrict__ rhs, double *__restrict__ x) {
   __shared__ double prod[kStreamNnz];
-  const int blk = b0 + blockIdx.x;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the k-th
+  // contiguous eighth of the level's row runs.  Neighbouring rows then share one L2, and the same
+  // slice of x is touched by the same XCD level after level (speed only, never correctness).
+  const int per = (int)gridDim.x >> 3;  // the grid is padded to a multiple of 8
+  const int mapped = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (mapped >= nb) return;
+  const int blk = b0 + mapped;
   const int r0 = M.rowblk[blk], r1 = M.rowblk[blk + 1];
   const int k0 = M.rowptr[r0], k1 = M.rowptr[r1];
+  const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
+  const bool have = r < r1;
+  int jb = 0, je = 0, i = 0;
+  double own = 0.0, dv = 1.0;
+  if (have) {
+    jb = M.rowptr[r] - k0;
+    je = M.rowptr[r + 1] - k0;
+    i = perm[r];
+    own = LOWER ? rhs[i] : x[i];  // x[i] of this level's own rows is not written by anyone else
+    if (KIND == 1 || !LOWER) dv = dinv[r];
+  }
   for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK) prod[k - k0] = M.val[k] * x[M.col[k]];
   __syncthreads();
-  const int lane = threadIdx.x % RG;
-  for (int r = r0 + threadIdx.x / RG; r < r1; r += BLK / RG) {
-    const double sum = row_sum_lds(prod, M.rowptr[r] - k0, M.rowptr[r + 1] - k0, lane);
-    if (lane == 0) {
-      const int i = perm[r];
-      if (LOWER) {
-        const double b = rhs[i];
-        x[i] = KIND == 0 ? (b - sum) : (b - sum) * dinv[r];
-      } else {
-        const double y = x[i];
-        x[i] = KIND == 0 ? (y - sum) * dinv[r] : y - sum * dinv[r];
-      }
-    }
+  const double sum = row_sum_lds(prod, jb, je, lane);
+  if (have && lane == 0) {
+    if (LOWER) x[i] = KIND == 0 ? (own - sum) : (own - sum) * dv;
+    else x[i] = KIND == 0 ? (own - sum) * dv : own - sum * dv;
   }
 }
 
@@ -262,9 +284,50 @@ __device__ __forceinline__ void reduce_finish(double (&v)[NOUT], ReduceWs ws, do
 
 template <class F>
 __global__ __launch_bounds__(BLK) void reduce1_kernel(int n, F f, ReduceWs ws, double *out, int want_sqrt) {
-  double v[1] = {0.0};
-  for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) v[0] += f((int)i);
+  // four independent accumulation chains per thread keep enough loads in flight
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const long stride = (long)gridDim.x * BLK;
+  long i = (long)blockIdx.x * BLK + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    a0 += f((int)i);
+    a1 += f((int)(i + stride));
+    a2 += f((int)(i + 2 * stride));
+    a3 += f((int)(i + 3 * stride));
+  }
+  for (; i < n; i += stride) a0 += f((int)i);
+  double v[1] = {(a0 + a1) + (a2 + a3)};
   reduce_finish<1>(v, ws, out, want_sqrt);
+}
+
+template <int M>
+__global__ __launch_bounds__(BLK) void multi_dot_kernel(int n, const double *__restrict__ w, VecPack P, ReduceWs ws,
+                                                        double *out) {
+  double acc[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) acc[k] = 0.0;
+  for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+    const double wi = w[i];
+#pragma unroll
+    for (int k = 0; k < M; ++k) acc[k] += wi * P.v[k][i];
+  }
+  reduce_finish<M>(acc, ws, out, 0);
+}
+
+template <int M, bool NORM>
+__global__ __launch_bounds__(BLK) void multi_axpy_kernel(int n, double *__restrict__ w, VecPack P,
+                                                         const double *__restrict__ h, ReduceWs ws, double *out) {
+  double hk[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) hk[k] = h[k];
+  double acc[1] = {0.0};
+  for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+    double wi = w[i];
+#pragma unroll
+    for (int k = 0; k < M; ++k) wi -= hk[k] * P.v[k][i];
+    w[i] = wi;
+    if (NORM) acc[0] += wi * wi;
+  }
+  if (NORM) reduce_finish<1>(acc, ws, out, 1);
 }
 
 // ------------------------------------------------------------------ triangular solves
@@ -490,7 +553,8 @@ void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower
                       const int *perm, const double *rhs, double *x) {
   const int nb = b1 - b0;
   if (nb <= 0) return;
-#define NSK_TS(L, K) hipLaunchKernelGGL((tri_stream_kernel<L, K>), dim3(nb), dim3(BLK), 0, s, M, b0, dinv, perm, rhs, x)
+  const int grid = ((nb + 7) / 8) * 8;
+#define NSK_TS(L, K) hipLaunchKernelGGL((tri_stream_kernel<L, K>), dim3(grid), dim3(BLK), 0, s, M, b0, nb, dinv, perm, rhs, x)
   if (lower) { if (kind == 0) NSK_TS(1, 0); else NSK_TS(1, 1); }
   else { if (kind == 0) NSK_TS(0, 0); else NSK_TS(0, 1); }
 #undef NSK_TS
@@ -585,6 +649,22 @@ void vec_cg_update(hipStream_t s, const ReduceWs &ws, int n, SRef a, const doubl
     g[i] = v;
     return v * v;
   });
+}
+
+void vec_multi_dot(hipStream_t s, const ReduceWs &ws, int n, const double *w, const VecPack &P, int m, double *out) {
+#define NSK_MD(M) case M: hipLaunchKernelGGL((multi_dot_kernel<M>), dim3(red_grid(n)), dim3(BLK), 0, s, n, w, P, ws, out); break;
+  switch (m) { NSK_MD(1) NSK_MD(2) NSK_MD(3) NSK_MD(4) NSK_MD(5) NSK_MD(6) NSK_MD(7) NSK_MD(8) default: break; }
+#undef NSK_MD
+}
+void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const VecPack &P, int m, const double *h,
+                    double *norm_out) {
+#define NSK_MA(M)                                                                                                \
+  case M:                                                                                                        \
+    if (norm_out) hipLaunchKernelGGL((multi_axpy_kernel<M, true>), dim3(red_grid(n)), dim3(BLK), 0, s, n, w, P, h, ws, norm_out); \
+    else hipLaunchKernelGGL((multi_axpy_kernel<M, false>), dim3(red_grid(n)), dim3(BLK), 0, s, n, w, P, h, ws, norm_out);         \
+    break;
+  switch (m) { NSK_MA(1) NSK_MA(2) NSK_MA(3) NSK_MA(4) NSK_MA(5) NSK_MA(6) NSK_MA(7) NSK_MA(8) default: break; }
+#undef NSK_MA
 }
 
 void tri_lower_level(hipStream_t s, const TriView &T, int kind, int lpr, const int *rows, int nrows, const double *rhs,

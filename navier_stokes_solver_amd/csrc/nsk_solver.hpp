@@ -7,6 +7,7 @@
 // reference's duck-typed templates; a failed solve throws NoConvergence, which the
 // C ABI turns into status 1/2/3.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <functional>
 #include <limits>
@@ -144,6 +145,7 @@ struct SolverFGMRES : SolverBase {
   using SolverBase::SolverBase;
   static constexpr int kBasis = 30;
   int iterations = 0;
+  bool fused_gs = false;  // inner solves: fused classical Gram-Schmidt instead of modified
   void solve(const MatVec &A, DVec &x, const DVec &b, const PrecVmult &P) {
     std::vector<double *> v(kBasis, nullptr), z(kBasis, nullptr);
     double *auxp = pool.get(false);
@@ -183,11 +185,20 @@ struct SolverFGMRES : SolverBase {
         else vec_set(s(), n, vj.own, 0.0);
         P(zj, vj);
         A(zj, aux.own);
-        // modified Gram-Schmidt with add_and_dot; all coefficients stay on the device
-        ctx.dot(n, aux.own, v[0], HS);
-        for (int i = 1; i <= j; ++i)
-          ctx.axpy_dot(n, sref(-1.0, ctx.slot(HS + i - 1)), v[i - 1], aux.own, v[i], HS + i);
-        ctx.axpy_norm2(n, sref(-1.0, ctx.slot(HS + j)), v[j], aux.own, HS + j + 1);
+        if (fused_gs) {
+          // classical Gram-Schmidt in two fused sweeps: all h(i,j) from one read of aux (8 basis vectors
+          // per pass), then aux -= sum h(i,j) v_i and ||aux||.  Same Arnoldi relation as deal.II's
+          // modified Gram-Schmidt in exact arithmetic; ~2.5x fewer bytes and 4 launches instead of j+2.
+          for (int i0 = 0; i0 <= j; i0 += 8) ctx.multi_dot(n, aux.own, &v[i0], std::min(8, j + 1 - i0), HS + i0);
+          for (int i0 = 0; i0 <= j; i0 += 8)
+            ctx.multi_axpy(n, aux.own, &v[i0], std::min(8, j + 1 - i0), HS + i0, i0 + 8 > j ? HS + j + 1 : -1);
+        } else {
+          // modified Gram-Schmidt with add_and_dot; all coefficients stay on the device
+          ctx.dot(n, aux.own, v[0], HS);
+          for (int i = 1; i <= j; ++i)
+            ctx.axpy_dot(n, sref(-1.0, ctx.slot(HS + i - 1)), v[i - 1], aux.own, v[i], HS + i);
+          ctx.axpy_norm2(n, sref(-1.0, ctx.slot(HS + j)), v[j], aux.own, HS + j + 1);
+        }
         const double *h = ctx.read_slots(HS, j + 3);
         for (int i = 0; i <= j; ++i) H[i * kBasis + j] = h[i];
         H[(j + 1) * kBasis + j] = a = h[j + 2];
