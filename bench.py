@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--subdomains", type=int, default=1)
     ap.add_argument("--profile-op", type=int, default=0, help="op sampled with HIP events for the roofline (0 = SpMV on F)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-mesh", type=str, default="300,100")
+    ap.add_argument("--cpu-mesh", type=str, default="200,66")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--converge", type=float, default=0.0, help="if > 0: also run a full solve to this tolerance")
     return ap.parse_args()
@@ -176,8 +176,17 @@ def main():
     if rank == 0:
         value = n_global * args.steps / dt
         achieved = (k_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
-        op_names = {0: "spmv_kernel<16,0> on F (inner FGMRES)", 5: "spmv on S", 20: "ILU(0) apply on F (all level kernels)",
-                    21: "ILU(0) apply on S"}
+        op_names = {0: "spmv_stream_kernel<2,0> on F (SpMV of the inner FGMRES; largest single kernel)",
+                    5: "spmv_stream_kernel<1,0> on S", 20: "ILU(0) apply on F (tri_stream_kernel, all levels)",
+                    21: "ILU(0) apply on S (tri_stream_kernel, all levels)"}
+        # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside this
+        # process); only quoted when it was measured on this very workload
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_1200x400.json")
+        if args.profile_op == 0 and (nx, ny, world) == (1200, 400, 1) and os.path.exists(pmc):
+            k = json.load(open(pmc))["kernels"].get("spmv_stream_kernel<2,0> on F")
+            if k:
+                traffic, traffic_src = k["traffic_bytes_corrected"], "profiles/r01_pmc_traffic_1200x400.json"
         out = {
             "metric": "DoF*iters/s (FGMRES+aSIMPLE, Re=100)", "value": value, "unit": "DoF*iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -198,7 +207,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": op_names.get(args.profile_op, f"op {args.profile_op}"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                "traffic_source": traffic_src,
                 "bytes_per_launch": k_bytes, "avg_ms": k_ms, "launches_sampled": k_n,
             },
             "phases": {

@@ -1,0 +1,174 @@
+"""Command-line drivers with the reference's flag surface.
+
+    python -m navier_stokes_solver_amd.cli StationaryNSSolver -m 60,20 -r 20 -s 1 -p 0
+    python -m navier_stokes_solver_amd.cli NSSolver -T 5,0.01 -m 600,200 -r 100
+
+Flags, defaults, help text and the configuration echo follow `lab_new/src/testStationary.cpp:7-123`
+and `lab_new/src/test.cpp:8-146` (getopt string "M:m:r:s:t:p:h" / "T:M:m:r:s:t:p:h", so `-M` swallows
+the next token exactly as in the reference).  What runs is the hot path only: for every continuation
+level the reference would visit (`NSSolverStationary.cpp:662-665`, `NSSolver.cpp:684`) the driver
+hands `solve_system()` one system — the first level gets the reference's own first system (Stokes
+with the inlet data, `.cpp:685-689`); later levels get the Newton system linearised about the
+synthetic state (inlet profile extended along x), because the Newton/line-search loop and the FE
+assembly for arbitrary states are outside this path.  `-M` (gmsh meshes) is rejected.
+"""
+from __future__ import annotations
+
+import getopt
+import sys
+import time
+
+SOLVERS = {0: "GMRES", 1: "FGMRES", 2: "Bicgstab"}
+PRECS = {0: "blockDiagonal", 1: "blockTriangular", 2: "aSIMPLE"}
+
+
+def print_help(unsteady: bool):
+    out = "Usage: ./NSSolver [options]\n\nOptions:\n"
+    if unsteady:
+        out += "  -T, --timespan-step T,dt  Set time span and time step (two floating point values separated by a comma)\n"
+    out += ("  -M, --read-mesh-from-file  Read mesh from file instead or generate it inside the program\n"
+            "  -m, --mesh-size X,Y       Set mesh size (two integers separated by a comma)\n"
+            "  -r, --reynolds N         Set Reynolds number (floating point value)\n"
+            "  -s, --solver N            Select solver (valid values: 0: GMRES, 1: FGMRES, 2: Bicgstab)\n"
+            "  -t, --tolerance D         Set tolerance (floating point value)\n"
+            "  -p, --preconditioner N    Select preconditioner (valid values: 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE)\n"
+            "  -h, --help                Display this help message\n")
+    sys.stdout.write(out)
+
+
+def parse(argv, unsteady: bool):
+    cfg = dict(read_mesh=False, Re=100.0, mx=100, my=100, solver=1, tol=1e-6, prec=0, T=1.0, dt=0.01)
+    short = ("T:" if unsteady else "") + "M:m:r:s:t:p:h"
+    longs = (["timespan-step="] if unsteady else []) + ["read-mesh-from-file", "mesh-size=", "reynolds=", "solver=",
+                                                          "tolerance=", "preconditioner=", "help"]
+    try:
+        opts, _ = getopt.getopt(argv, short, longs)
+    except getopt.GetoptError:
+        print_help(unsteady)
+        return None, 1
+    for o, a in opts:
+        if o in ("-T", "--timespan-step"):
+            if "," not in a:
+                sys.stderr.write("Error: timespan-step requires two values separated by comma\n")
+                return None, 1
+            cfg["T"], cfg["dt"] = (float(v) for v in a.split(",", 1))
+        elif o in ("-M", "--read-mesh-from-file"):
+            cfg["read_mesh"] = True
+        elif o in ("-m", "--mesh-size"):
+            if "," not in a:
+                sys.stderr.write("Error: mesh-size requires two values separated by comma\n")
+                return None, 1
+            cfg["mx"], cfg["my"] = (int(v) for v in a.split(",", 1))
+        elif o in ("-r", "--reynolds"):
+            cfg["Re"] = float(a)
+        elif o in ("-s", "--solver"):
+            cfg["solver"] = int(a)
+        elif o in ("-t", "--tolerance"):
+            cfg["tol"] = float(a)
+        elif o in ("-p", "--preconditioner"):
+            cfg["prec"] = int(a)
+        elif o in ("-h", "--help"):
+            print_help(unsteady)
+            return None, 0
+    if cfg["tol"] <= 0 or (unsteady and (cfg["dt"] <= 0 or cfg["T"] <= 0)):
+        sys.stderr.write("Error: time_step, time_span, and tolerance must be positive\n" if unsteady
+                         else "Error: tolerance must be positive\n")
+        return None, 1
+    return cfg, 0
+
+
+def echo(cfg, unsteady: bool):
+    p = sys.stdout.write
+    p("--------- CONFIGURATION PARAMETERS --------- \n")
+    if unsteady:
+        p(f"Time span: {cfg['T']:g}\nTime step: {cfg['dt']:g}\n")
+    p(f"Mesh size: {cfg['mx']}x{cfg['my']}\nReynolds number: {cfg['Re']:g}\n")
+    p("Solver type: " + (SOLVERS.get(cfg["solver"], "") + "\n" if cfg["solver"] in SOLVERS else ""))
+    p(f"Tolerance: {cfg['tol']:g}\n")
+    p("Preconditioner: " + (PRECS.get(cfg["prec"], "") + "\n" if cfg["prec"] in PRECS else ""))
+    p("-----------------------------------------------\n")
+
+
+def run(cfg, unsteady: bool) -> int:
+    import numpy as np
+
+    from . import problem as P
+    from . import solver as S
+    if cfg["read_mesh"]:
+        sys.stderr.write("-M (gmsh P2/P1 mesh from file) is outside the accelerated path; generated meshes only\n")
+        return 1
+    if cfg["prec"] not in PRECS:
+        raise ValueError("Invalid preconditioner type. Use 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE.")
+    nx, ny = cfg["mx"], cfg["my"]
+    info = P.mesh_info(nx, ny)
+    print(f"  Number of elements = {info['n_cells']}")
+    print("Initializing the finite element space\n  Velocity degree:           = 3\n  Pressure degree:           = 2\n"
+          "  DoFs per cell              = 41\n  Quadrature points per cell = 16\n  Quadrature points per face = 4")
+    print("-----------------------------------------------\nInitializing the DoF handler\n  Number of DoFs: ")
+    print(f"    velocity = {info['n_u_global']}\n    pressure = {info['n_p_global']}\n"
+          f"    total    = {info['n_u_global'] + info['n_p_global']}")
+    print("-----------------------------------------------")
+    first, step = (1.0, 10.0) if unsteady else (10.0, 20.0)
+    levels = []
+    re = first
+    while re <= cfg["Re"]:
+        levels.append(re)
+        re += step
+    print("===============================================")
+    print(f"Target Re = {cfg['Re']:g}")
+    ls = S.LinearSolver()
+    variant = S.UNSTEADY if unsteady else S.STATIONARY
+    U = 0.3 if unsteady else 0.1
+    inv_dt = 1.0 / cfg["dt"] if unsteady else 0.0
+    total_its, n_solves, t_solve = 0, 0, 0.0
+    n_steps = max(1, int(round(cfg["T"] / cfg["dt"]))) if unsteady else 1
+    n_steps = min(n_steps, 1)  # the time loop is a caller of the path; one representative step
+    for _ in range(n_steps):
+        for li, re in enumerate(levels):
+            nu = 1.0 / re
+            print("===============================================")
+            print(f"Solving for nu = {nu:g}")
+            stokes = (li == 0)
+            pr = P.generate(nx, ny, nu=nu, mode=0 if stokes else 1, state=0 if stokes else 1,
+                            inlet_bc=1 if stokes else 0, inv_dt=inv_dt, U=U)
+            print("Solving Stokes adding BCs" if stokes else "Solving NS")
+            if li == 0:
+                ls.set_problem(pr)
+            else:
+                for blk, csr in ((S.BLK_F, pr.F), (S.BLK_BT, pr.Bt), (S.BLK_B, pr.B), (S.BLK_MP, pr.Mp)):
+                    ls.update_values(blk, csr.val)
+            rnorm = float(np.sqrt(np.dot(pr.rhs_u, pr.rhs_u) + np.dot(pr.rhs_p, pr.rhs_p)))
+            sys.stdout.write(f"Newton iteration 0/{10 if unsteady else 15} - ||r|| = {rnorm:.6e}")
+            sys.stdout.flush()
+            if unsteady:
+                print(f"\nSolver tolerance: {cfg['tol']:g}")
+            du, dp = pr.x0_u.copy(), pr.x0_p.copy()
+            t0 = time.time()
+            its = ls.solve_system(cfg["solver"], cfg["prec"], cfg["tol"], pr.rhs_u, pr.rhs_p, du, dp, variant=variant)
+            t_solve += time.time() - t0
+            print(f"   {its} {'iterations' if unsteady else 'solver iterations'}")
+            total_its += its
+            n_solves += 1
+    n = info["n_u_global"] + info["n_p_global"]
+    print("===============================================")
+    print(f"[nsk] {n_solves} solve_system() calls, {total_its} outer iterations, {t_solve:.3f} s in solve_system "
+          f"(setup + solve) -> {n * total_its / max(t_solve, 1e-12):.4g} DoF*iters/s")
+    ls.close()
+    return 0
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv or argv[0] not in ("StationaryNSSolver", "NSSolver"):
+        sys.stderr.write("usage: python -m navier_stokes_solver_amd.cli {StationaryNSSolver|NSSolver} [options]\n")
+        return 2
+    unsteady = argv[0] == "NSSolver"
+    cfg, rc = parse(argv[1:], unsteady)
+    if cfg is None:
+        return rc
+    echo(cfg, unsteady)
+    return run(cfg, unsteady)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
