@@ -41,7 +41,6 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--ordering", type=int, default=1, help="0 natural, 1 multicolour (triangular solves)")
     ap.add_argument("--subdomains", type=int, default=1)
-    ap.add_argument("--profile-op", type=int, default=0, help="op sampled with HIP events for the roofline (0 = SpMV on F)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mesh", type=str, default="200,66")
     ap.add_argument("--cpu-steps", type=int, default=4)
@@ -82,6 +81,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
+        # torch.distributed.run pins OMP_NUM_THREADS=1; the host-side hand-off generation and the one-off
+        # symbolic analysis are OpenMP loops, so give every rank its share of the cores (set before any
+        # OpenMP runtime is loaded)
+        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // world))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -145,7 +149,9 @@ def main():
     ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
     ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
     ls.reset_stats()
-    ls.profile_begin(args.profile_op, 1024)
+    aS = args.preconditioner == 2
+    for op in (20, 0, 21) + ((5,) if aS else (3,)):
+        ls.profile_begin(op, 1024)     # HIP events around every launch of these ops inside the timed solve
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -153,7 +159,8 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    k_ms, k_n, k_bytes = ls.profile_end()
+    prof = {op: ls.profile_read(op) for op in (20, 0, 21) + ((5,) if aS else (3,))}
+    ls.profile_end()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -175,18 +182,28 @@ def main():
 
     if rank == 0:
         value = n_global * args.steps / dt
-        achieved = (k_bytes / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0
-        op_names = {0: "spmv_stream_kernel<2,0> on F (SpMV of the inner FGMRES; largest single kernel)",
-                    5: "spmv_stream_kernel<1,0> on S", 20: "ILU(0) apply on F (tri_stream_kernel, all levels)",
-                    21: "ILU(0) apply on S (tri_stream_kernel, all levels)"}
-        # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc cannot run inside this
-        # process); only quoted when it was measured on this very workload
+        names = {0: "spmv_stream_kernel<2,0>: SpMV with F (inner FGMRES)",
+                 3: "spmv_stream_kernel<1,0>: SpMV with Mp (inner CG)", 5: "spmv_stream_kernel<1,0>: SpMV with S (inner CG)",
+                 20: "tri_stream_kernel: ILU(0)/SGS apply on F (all level launches of one apply)",
+                 21: "tri_stream_kernel: ILU(0)/SGS apply on the pressure block (all level launches of one apply)"}
+        klass = {}
+        for op, (ms, cnt, by, ncalls) in prof.items():
+            klass[op] = dict(kernel=names[op], avg_ms=ms, launches_sampled=cnt, calls=ncalls, bytes_per_launch=by,
+                             achieved=(by / 1e9) / (ms / 1e3) if ms > 0 else 0.0,
+                             time_share=ncalls * ms / 1e3 / dt)   # share of the timed solve spent in this class
+        dom = max(klass, key=lambda o: klass[o]["time_share"])
+        k_ms, k_n, k_bytes, achieved = (klass[dom]["avg_ms"], klass[dom]["launches_sampled"],
+                                        klass[dom]["bytes_per_launch"], klass[dom]["achieved"])
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_1200x400.json")
-        if args.profile_op == 0 and (nx, ny, world) == (1200, 400, 1) and os.path.exists(pmc):
-            k = json.load(open(pmc))["kernels"].get("spmv_stream_kernel<2,0> on F")
-            if k:
-                traffic, traffic_src = k["traffic_bytes_corrected"], "profiles/r01_pmc_traffic_1200x400.json"
+        if (nx, ny, world) == (1200, 400, 1) and os.path.exists(pmc):
+            kk = json.load(open(pmc))["kernels"]
+            if dom == 0 and "spmv_stream_kernel<2,0> on F" in kk:
+                traffic = kk["spmv_stream_kernel<2,0> on F"]["traffic_bytes_corrected"]
+            if dom == 20 and "ILU(F) apply, lower levels (36 launches)" in kk:
+                traffic = (kk["ILU(F) apply, lower levels (36 launches)"]["traffic_bytes_corrected_per_apply"] +
+                           kk["ILU(F) apply, upper levels (36 launches)"]["traffic_bytes_corrected_per_apply"])
+            traffic_src = "profiles/r01_pmc_traffic_1200x400.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None
         out = {
             "metric": "DoF*iters/s (FGMRES+aSIMPLE, Re=100)", "value": value, "unit": "DoF*iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -205,12 +222,13 @@ def main():
                 "residual_after_K": res,
             },
             "roofline": {
-                "bound": "hbm", "kernel": op_names.get(args.profile_op, f"op {args.profile_op}"),
+                "bound": "hbm", "kernel": klass[dom]["kernel"], "time_share": klass[dom]["time_share"],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                 "traffic_source": traffic_src,
                 "bytes_per_launch": k_bytes, "avg_ms": k_ms, "launches_sampled": k_n,
             },
+            "kernel_classes": [dict(klass[o], frac=klass[o]["achieved"] / HBM_PEAK_GBS) for o in sorted(klass)],
             "phases": {
                 "generate_s": t_gen, "upload_s": t_upload, "setup_first_s": t_setup_first, "setup_numeric_s": t_setup,
                 "solve_s": dt, "spmv_GB": st["spmv_bytes"] / 1e9, "tri_GB": st["tri_bytes"] / 1e9,

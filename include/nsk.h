@@ -146,11 +146,13 @@ int nsk_reset_stats(nsk_handle h);
  * Returns average milliseconds per repetition and the algorithmic bytes of one repetition. */
 int nsk_time_op(nsk_handle h, int op, int reps, double *avg_ms, double *bytes);
 
-/* HIP-event sampling of one operation class INSIDE the following solves: every launch of the
- * op (same ids as nsk_time_op: 0..5 SpMV of that block, 20/21 triangular applies) is bracketed
- * by events on the library's stream until max_samples are taken. */
+/* HIP-event sampling of operation classes INSIDE the following solves: every launch of a sampled op
+ * (same ids as nsk_time_op: 0..5 SpMV of that block, 20/21 triangular applies; up to four ops at once)
+ * is bracketed by events on the library's stream until max_samples are taken. */
 int nsk_profile_begin(nsk_handle h, int op, int max_samples);
-int nsk_profile_end(nsk_handle h, double *avg_ms, int *n_samples, double *bytes_per_launch);
+int nsk_profile_read(nsk_handle h, int op, double *avg_ms, int *n_samples, double *bytes_per_launch,
+                     int64_t *n_calls);
+int nsk_profile_end(nsk_handle h);
 
 #ifdef __cplusplus
 }

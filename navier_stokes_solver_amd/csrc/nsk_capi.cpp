@@ -24,27 +24,44 @@ double wall_ms() {
 }
 }  // namespace
 
-// HIP-event sampler: brackets launches of one operation class inside a running solve
+// HIP-event sampler: brackets launches of up to four operation classes inside a running solve
 struct EventSampler {
-  int op = -1, cap = 0;
-  std::vector<hipEvent_t> e0, e1;
-  int used = 0;
-  void begin(int op_, int cap_) {
-    end_release();
-    op = op_;
-    cap = cap_;
-    e0.resize(cap);
-    e1.resize(cap);
-    for (int i = 0; i < cap; ++i) { (void)hipEventCreate(&e0[i]); (void)hipEventCreate(&e1[i]); }
-    used = 0;
+  struct Slot {
+    int op = -1, cap = 0, used = 0;
+    long seen = 0;  // every call of the op while sampling is on, also beyond the cap
+    std::vector<hipEvent_t> e0, e1;
+  };
+  Slot slots[4];
+  int n = 0;
+  void add(int op, int cap) {
+    if (n >= 4) throw Error(-67, "profile: at most four ops");
+    Slot &S = slots[n++];
+    S.op = op;
+    S.cap = cap;
+    S.used = 0;
+    S.e0.resize(cap);
+    S.e1.resize(cap);
+    for (int i = 0; i < cap; ++i) { (void)hipEventCreate(&S.e0[i]); (void)hipEventCreate(&S.e1[i]); }
   }
-  bool want(int o) const { return o == op && used < cap; }
-  void end_release() {
-    for (size_t i = 0; i < e0.size(); ++i) { (void)hipEventDestroy(e0[i]); (void)hipEventDestroy(e1[i]); }
-    e0.clear();
-    e1.clear();
-    op = -1;
-    cap = used = 0;
+  Slot *want(int o) {
+    for (int k = 0; k < n; ++k)
+      if (slots[k].op == o) {
+        ++slots[k].seen;
+        return slots[k].used < slots[k].cap ? &slots[k] : nullptr;
+      }
+    return nullptr;
+  }
+  Slot *find(int o) {
+    for (int k = 0; k < n; ++k)
+      if (slots[k].op == o) return &slots[k];
+    return nullptr;
+  }
+  void release() {
+    for (int k = 0; k < n; ++k) {
+      for (size_t i = 0; i < slots[k].e0.size(); ++i) { (void)hipEventDestroy(slots[k].e0[i]); (void)hipEventDestroy(slots[k].e1[i]); }
+      slots[k] = Slot{};
+    }
+    n = 0;
   }
 };
 
@@ -95,13 +112,13 @@ struct nsk_handle_s {
   void halo(int space, const DVec &x) { ctx.comm.halo_exchange(sp[space], x, s()); }
   void spmv_nohalo(Csr &A, const DVec &x, double *y, int mode = 0, const double *z = nullptr) {
     const int op = (int)(&A - blk);
-    const bool smp = sampler.want(op);
-    if (smp) (void)hipEventRecord(sampler.e0[sampler.used], s());
+    EventSampler::Slot *smp = sampler.want(op);
+    if (smp) (void)hipEventRecord(smp->e0[smp->used], s());
     if (A.stream_ok && use_stream)
       nsk::spmv_stream(s(), A.view(), A.rowblk.p, A.nblk, A.even_rows, x.own, x.ghost, y, mode, z);
     else
       nsk::spmv(s(), A.view(), A.lpr, x.own, x.ghost, y, mode, z);
-    if (smp) (void)hipEventRecord(sampler.e1[sampler.used++], s());
+    if (smp) (void)hipEventRecord(smp->e1[smp->used++], s());
     ++ctx.st.spmv_calls;
     ctx.st.spmv_bytes += (double)A.spmv_bytes() + (mode == 1 ? 8.0 * A.n_rows : 0.0);
   }
@@ -135,10 +152,10 @@ struct nsk_handle_s {
     spmv_nohalo(B, xu, yb + n_u(), 0);
   }
   void tri_apply_sampled(TriSolve &T, int op, const double *b, double *x) {
-    const bool smp = sampler.want(op);
-    if (smp) (void)hipEventRecord(sampler.e0[sampler.used], s());
+    EventSampler::Slot *smp = sampler.want(op);
+    if (smp) (void)hipEventRecord(smp->e0[smp->used], s());
     T.apply(b, x);
-    if (smp) (void)hipEventRecord(sampler.e1[sampler.used++], s());
+    if (smp) (void)hipEventRecord(smp->e1[smp->used++], s());
   }
   std::vector<int> sub_offsets(int space) const {
     std::vector<int> off;
@@ -345,11 +362,11 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
     return;
   }
   // unsteady aSIMPLE (NSSolver.hpp:294-350): ILU applies only
-  tF.apply(su.own, du.own);
+  tri_apply_sampled(tF, 20, su.own, du.own);
   halo(0, du);
   vec_copy(s(), np, spv.own, tmp_p);
   spmv_nohalo(B, du, tmp_p, 1);                          // tmp_p = src_p + B~ u   (vmult_add)
-  tP->apply(tmp_p, dp.own);
+  tri_apply_sampled(*tP, 21, tmp_p, dp.own);
   vec_mul(s(), nu, D, du.own);                           // u .*= D
   vec_scale(s(), np, sref(1.0 / alpha), dp.own);         // p /= alpha
   halo(1, dp);
@@ -750,31 +767,41 @@ int nsk_profile_begin(nsk_handle h, int op, int max_samples) {
   NSK_TRY(h)
   (void)hipSetDevice(h->ctx.device);
   if (max_samples < 1 || max_samples > 4096) throw Error(-66, "nsk_profile_begin: 1..4096 samples");
-  h->sampler.begin(op, max_samples);
+  h->sampler.add(op, max_samples);
   return 0;
   NSK_CATCH(h)
 }
 
-int nsk_profile_end(nsk_handle h, double *avg_ms, int *n_samples, double *bytes) {
+int nsk_profile_read(nsk_handle h, int op, double *avg_ms, int *n_samples, double *bytes, int64_t *n_calls) {
   NSK_TRY(h)
   (void)hipSetDevice(h->ctx.device);
   h->ctx.sync();
+  EventSampler::Slot *S = h->sampler.find(op);
+  if (!S) throw Error(-68, "nsk_profile_read: op was not being sampled");
   double tot = 0.0;
-  for (int i = 0; i < h->sampler.used; ++i) {
+  for (int i = 0; i < S->used; ++i) {
     float ms = 0.f;
-    NSK_HIP(hipEventElapsedTime(&ms, h->sampler.e0[i], h->sampler.e1[i]));
+    NSK_HIP(hipEventElapsedTime(&ms, S->e0[i], S->e1[i]));
     tot += ms;
   }
-  const int op = h->sampler.op;
-  if (avg_ms) *avg_ms = h->sampler.used ? tot / h->sampler.used : 0.0;
-  if (n_samples) *n_samples = h->sampler.used;
+  if (avg_ms) *avg_ms = S->used ? tot / S->used : 0.0;
+  if (n_samples) *n_samples = S->used;
+  if (n_calls) *n_calls = S->seen;
   if (bytes) {
     if (op >= 0 && op <= NSK_BLK_S) *bytes = (double)h->blk[op].spmv_bytes();
     else if (op == 20) *bytes = (double)h->tF.apply_bytes();
     else if (op == 21 && h->tP) *bytes = (double)h->tP->apply_bytes();
     else *bytes = 0.0;
   }
-  h->sampler.end_release();
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_profile_end(nsk_handle h) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  h->ctx.sync();
+  h->sampler.release();
   return 0;
   NSK_CATCH(h)
 }

@@ -32,7 +32,7 @@ EXPORTS = [
     "nsk_set_block_csr", "nsk_update_values", "nsk_set_option", "nsk_setup_preconditioner", "nsk_solve",
     "nsk_upload_system", "nsk_solve_resident", "nsk_download_solution", "nsk_spmv", "nsk_jacobian_vmult", "nsk_dot",
     "nsk_tri_apply", "nsk_tri_get_perm", "nsk_precond_vmult", "nsk_block_nnz", "nsk_get_block", "nsk_get_stats",
-    "nsk_reset_stats", "nsk_time_op", "nsk_profile_begin", "nsk_profile_end",
+    "nsk_reset_stats", "nsk_time_op", "nsk_profile_begin", "nsk_profile_read", "nsk_profile_end",
 ]
 
 
@@ -98,7 +98,9 @@ def lib() -> C.CDLL:
         L.nsk_reset_stats.argtypes = [vp]
         L.nsk_time_op.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.nsk_profile_begin.argtypes = [vp, C.c_int, C.c_int]
-        L.nsk_profile_end.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.nsk_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_int64)]
+        L.nsk_profile_end.argtypes = [vp]
         _LIB = L
     return _LIB
 
@@ -299,10 +301,13 @@ class LinearSolver:
     def profile_begin(self, op, max_samples=256):
         self._ck(self.L.nsk_profile_begin(self.h, op, max_samples))
 
+    def profile_read(self, op):
+        ms, n, by, calls = C.c_double(0), C.c_int(0), C.c_double(0), C.c_int64(0)
+        self._ck(self.L.nsk_profile_read(self.h, op, C.byref(ms), C.byref(n), C.byref(by), C.byref(calls)))
+        return ms.value, n.value, by.value, calls.value
+
     def profile_end(self):
-        ms, n, by = C.c_double(0), C.c_int(0), C.c_double(0)
-        self._ck(self.L.nsk_profile_end(self.h, C.byref(ms), C.byref(n), C.byref(by)))
-        return ms.value, n.value, by.value
+        self._ck(self.L.nsk_profile_end(self.h))
 
     def time_op(self, op, reps=10):
         ms, by = C.c_double(0), C.c_double(0)
