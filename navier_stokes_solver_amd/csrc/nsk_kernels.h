@@ -23,7 +23,7 @@ struct ReduceWs {
   double *partials;   // >= kMaxReduceBlocks * kMaxReduceOut
   unsigned *ticket;   // zero-initialised, reset by the last block
 };
-constexpr int kMaxReduceBlocks = 2048;
+constexpr int kMaxReduceBlocks = 512;
 constexpr int kMaxReduceOut = 8;
 
 // ---- CSR SpMV: y = A x | y += A x.  Columns >= n_own read x_ghost[col - n_own]. ----
@@ -116,7 +116,7 @@ struct TriHalf {
   const int *rowptr;
   const int *col;
   const double *val;
-  const int *rowblk;
+  const int4 *desc;  // per workgroup: {first row, end row, first nnz, end nnz} — one load instead of a chain
 };
 void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, const double *dinv,
                       const int *perm, const double *rhs, double *x);

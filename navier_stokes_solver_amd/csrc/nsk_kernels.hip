@@ -35,8 +35,12 @@ inline int ew_grid(int n) {
   if (b > 2048) b = 2048;
   return (int)b;
 }
+// Reductions use 1024-thread workgroups and at most kMaxReduceBlocks (512) of them: the last-block
+// hand-off costs one device-scope atomic per workgroup on a single address (~12 ns each, serialised),
+// so few fat workgroups beat many thin ones.
+constexpr int RBLK = 1024;
 inline int red_grid(int n) {
-  long b = ((long)n + BLK * 8 - 1) / (BLK * 8);
+  long b = ((long)n + RBLK * 4 - 1) / (RBLK * 4);
   if (b < 1) b = 1;
   if (b > kMaxReduceBlocks) b = kMaxReduceBlocks;
   return (int)b;
@@ -199,9 +203,8 @@ __global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int 
   const int per = (int)gridDim.x >> 3;  // the grid is padded to a multiple of 8
   const int mapped = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   if (mapped >= nb) return;
-  const int blk = b0 + mapped;
-  const int r0 = M.rowblk[blk], r1 = M.rowblk[blk + 1];
-  const int k0 = M.rowptr[r0], k1 = M.rowptr[r1];
+  const int4 d = M.desc[b0 + mapped];
+  const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
   const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
   const bool have = r < r1;
   int jb = 0, je = 0, i = 0;
@@ -213,7 +216,10 @@ __global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int 
     own = LOWER ? rhs[i] : x[i];  // x[i] of this level's own rows is not written by anyone else
     if (KIND == 1 || !LOWER) dv = dinv[r];
   }
-  for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK) prod[k - k0] = M.val[k] * x[M.col[k]];
+  // the factor is streamed once per apply: non-temporal loads keep it from evicting the x lines the
+  // gathers want to find in L2 again
+  for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK)
+    prod[k - k0] = __builtin_nontemporal_load(M.val + k) * x[__builtin_nontemporal_load(M.col + k)];
   __syncthreads();
   const double sum = row_sum_lds(prod, jb, je, lane);
   if (have && lane == 0) {
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(BLK) void ew_kernel(int n, F f) {
 // ------------------------------------------------------------------ grid-wide deterministic reduction
 template <int NOUT>
 __device__ __forceinline__ void reduce_finish(double (&v)[NOUT], ReduceWs ws, double *out, int want_sqrt) {
-  __shared__ double wsum[NOUT][BLK / 64];
+  __shared__ double wsum[NOUT][RBLK / 64];
   __shared__ int is_last;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -244,7 +250,7 @@ __device__ __forceinline__ void reduce_finish(double (&v)[NOUT], ReduceWs ws, do
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
       double s = 0.0;
-      for (int i = 0; i < BLK / 64; ++i) s += wsum[o][i];
+      for (int i = 0; i < RBLK / 64; ++i) s += wsum[o][i];
       __hip_atomic_store(&ws.partials[o * kMaxReduceBlocks + blockIdx.x], s, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -259,7 +265,7 @@ __device__ __forceinline__ void reduce_finish(double (&v)[NOUT], ReduceWs ws, do
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
       acc[o] = 0.0;
-      for (int i = threadIdx.x; i < (int)gridDim.x; i += BLK)
+      for (int i = threadIdx.x; i < (int)gridDim.x; i += RBLK)
         acc[o] += __hip_atomic_load(&ws.partials[o * kMaxReduceBlocks + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       acc[o] = subwave_sum<64>(acc[o]);
     }
@@ -273,7 +279,7 @@ __device__ __forceinline__ void reduce_finish(double (&v)[NOUT], ReduceWs ws, do
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) {
         double s = 0.0;
-        for (int i = 0; i < BLK / 64; ++i) s += wsum[o][i];
+        for (int i = 0; i < RBLK / 64; ++i) s += wsum[o][i];
         out[o] = s;
       }
       if (want_sqrt) out[NOUT] = sqrt(fabs(out[0]));
@@ -283,11 +289,11 @@ __device__ __forceinline__ void reduce_finish(double (&v)[NOUT], ReduceWs ws, do
 }
 
 template <class F>
-__global__ __launch_bounds__(BLK) void reduce1_kernel(int n, F f, ReduceWs ws, double *out, int want_sqrt) {
+__global__ __launch_bounds__(RBLK) void reduce1_kernel(int n, F f, ReduceWs ws, double *out, int want_sqrt) {
   // four independent accumulation chains per thread keep enough loads in flight
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  const long stride = (long)gridDim.x * BLK;
-  long i = (long)blockIdx.x * BLK + threadIdx.x;
+  const long stride = (long)gridDim.x * RBLK;
+  long i = (long)blockIdx.x * RBLK + threadIdx.x;
   for (; i + 3 * stride < n; i += 4 * stride) {
     a0 += f((int)i);
     a1 += f((int)(i + stride));
@@ -300,12 +306,12 @@ __global__ __launch_bounds__(BLK) void reduce1_kernel(int n, F f, ReduceWs ws, d
 }
 
 template <int M>
-__global__ __launch_bounds__(BLK) void multi_dot_kernel(int n, const double *__restrict__ w, VecPack P, ReduceWs ws,
+__global__ __launch_bounds__(RBLK) void multi_dot_kernel(int n, const double *__restrict__ w, VecPack P, ReduceWs ws,
                                                         double *out) {
   double acc[M];
 #pragma unroll
   for (int k = 0; k < M; ++k) acc[k] = 0.0;
-  for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+  for (long i = (long)blockIdx.x * RBLK + threadIdx.x; i < n; i += (long)gridDim.x * RBLK) {
     const double wi = w[i];
 #pragma unroll
     for (int k = 0; k < M; ++k) acc[k] += wi * P.v[k][i];
@@ -314,13 +320,13 @@ __global__ __launch_bounds__(BLK) void multi_dot_kernel(int n, const double *__r
 }
 
 template <int M, bool NORM>
-__global__ __launch_bounds__(BLK) void multi_axpy_kernel(int n, double *__restrict__ w, VecPack P,
+__global__ __launch_bounds__(RBLK) void multi_axpy_kernel(int n, double *__restrict__ w, VecPack P,
                                                          const double *__restrict__ h, ReduceWs ws, double *out) {
   double hk[M];
 #pragma unroll
   for (int k = 0; k < M; ++k) hk[k] = h[k];
   double acc[1] = {0.0};
-  for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+  for (long i = (long)blockIdx.x * RBLK + threadIdx.x; i < n; i += (long)gridDim.x * RBLK) {
     double wi = w[i];
 #pragma unroll
     for (int k = 0; k < M; ++k) wi -= hk[k] * P.v[k][i];
@@ -616,7 +622,7 @@ void extract_diag(hipStream_t s, const CsrView &A, double *d, double *dinv) {
 #define NSK_RED(n, ...)                                                                                  \
   do {                                                                                                   \
     auto f__ = __VA_ARGS__;                                                                              \
-    hipLaunchKernelGGL((reduce1_kernel<decltype(f__)>), dim3(red_grid(n)), dim3(BLK), 0, s, n, f__, ws, out, \
+    hipLaunchKernelGGL((reduce1_kernel<decltype(f__)>), dim3(red_grid(n)), dim3(RBLK), 0, s, n, f__, ws, out, \
                        want_sqrt);                                                                       \
   } while (0)
 
@@ -652,7 +658,7 @@ void vec_cg_update(hipStream_t s, const ReduceWs &ws, int n, SRef a, const doubl
 }
 
 void vec_multi_dot(hipStream_t s, const ReduceWs &ws, int n, const double *w, const VecPack &P, int m, double *out) {
-#define NSK_MD(M) case M: hipLaunchKernelGGL((multi_dot_kernel<M>), dim3(red_grid(n)), dim3(BLK), 0, s, n, w, P, ws, out); break;
+#define NSK_MD(M) case M: hipLaunchKernelGGL((multi_dot_kernel<M>), dim3(red_grid(n)), dim3(RBLK), 0, s, n, w, P, ws, out); break;
   switch (m) { NSK_MD(1) NSK_MD(2) NSK_MD(3) NSK_MD(4) NSK_MD(5) NSK_MD(6) NSK_MD(7) NSK_MD(8) default: break; }
 #undef NSK_MD
 }
@@ -660,8 +666,8 @@ void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const V
                     double *norm_out) {
 #define NSK_MA(M)                                                                                                \
   case M:                                                                                                        \
-    if (norm_out) hipLaunchKernelGGL((multi_axpy_kernel<M, true>), dim3(red_grid(n)), dim3(BLK), 0, s, n, w, P, h, ws, norm_out); \
-    else hipLaunchKernelGGL((multi_axpy_kernel<M, false>), dim3(red_grid(n)), dim3(BLK), 0, s, n, w, P, h, ws, norm_out);         \
+    if (norm_out) hipLaunchKernelGGL((multi_axpy_kernel<M, true>), dim3(red_grid(n)), dim3(RBLK), 0, s, n, w, P, h, ws, norm_out); \
+    else hipLaunchKernelGGL((multi_axpy_kernel<M, false>), dim3(red_grid(n)), dim3(RBLK), 0, s, n, w, P, h, ws, norm_out);         \
     break;
   switch (m) { NSK_MA(1) NSK_MA(2) NSK_MA(3) NSK_MA(4) NSK_MA(5) NSK_MA(6) NSK_MA(7) NSK_MA(8) default: break; }
 #undef NSK_MA

@@ -232,8 +232,13 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       };
       first_block_of(lb, LB);
       first_block_of(ub, UB);
-      Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Lblk.upload(lb, s);
-      Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Ublk.upload(ub, s);
+      auto make_desc = [](const std::vector<int> &blk, const std::vector<int> &rp_) {
+        std::vector<int4> d(blk.size() - 1);
+        for (size_t b = 0; b + 1 < blk.size(); ++b) d[b] = make_int4(blk[b], blk[b + 1], rp_[blk[b]], rp_[blk[b + 1]]);
+        return d;
+      };
+      Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Ldesc.upload(make_desc(lb, lrp), s);
+      Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Udesc.upload(make_desc(ub, urp), s);
       Lval.alloc((size_t)nnzL);
       Uval.alloc((size_t)nnzU);
       dinv.alloc((size_t)n);
@@ -275,7 +280,7 @@ void TriSolve::numeric(const double *a_val_dev) {
 void TriSolve::apply(const double *b, double *x) {
   hipStream_t s = ctx->stream;
   if (stream_ready && use_stream) {
-    const TriHalf L{Lrp.p, Lcol.p, Lval.p, Lblk.p}, U{Urp.p, Ucol.p, Uval.p, Ublk.p};
+    const TriHalf L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
     // x doubles as the intermediate vector: rows not yet solved hold L^-1 b, solved rows hold the result
     for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, dinv.p, d_perm.p, b, x);
     for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, dinv.p, d_perm.p, nullptr, x);

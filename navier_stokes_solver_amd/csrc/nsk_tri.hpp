@@ -41,7 +41,8 @@ struct TriSolve {
 
   // split factors for the streamed kernels (multicolour ordering: one colour = one contiguous level)
   bool use_stream = true, stream_ready = false;
-  DBuf<int> Lrp, Lcol, Lsrc, Lblk, Urp, Ucol, Usrc, Ublk;
+  DBuf<int> Lrp, Lcol, Lsrc, Urp, Ucol, Usrc;
+  DBuf<int4> Ldesc, Udesc;
   DBuf<double> Lval, Uval, dinv;
   std::vector<int> LB, UB;  // per colour: first workgroup of that colour in Lblk / Ublk (n_colors + 1)
   int64_t nnzL = 0, nnzU = 0;

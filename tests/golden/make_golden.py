@@ -47,6 +47,20 @@ def make(name):
     print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in g.items() if "iters" in k})
 
 
+def make_north_star_60x20():
+    """FGMRES + aSIMPLE to the north-star tolerance 1e-10 on the 60x20 Newton system (about 3 minutes)."""
+    pr = P.generate(**CASES["ns60"])
+    op = O.OracleProblem.from_local(pr)
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    x0 = np.concatenate([pr.x0_u, pr.x0_p])
+    x, info = op.solve(b, x0, solver=1, prec=2, variant=0, tol=1e-10)
+    assert info["status"] == 0
+    np.savez_compressed(os.path.join(OUT, "ns60_north_star.npz"), x=x, iters=info["iters"], final_res=info["final_res"],
+                        inner_u_its=info["inner_u_its"], inner_p_its=info["inner_p_its"])
+    print("ns60 north star", info["iters"], info["final_res"])
+
+
 if __name__ == "__main__":
     for name in ("stokes16", "ns16", "unsteady16"):
         make(name)
+    make_north_star_60x20()

@@ -1,0 +1,74 @@
+"""BASELINE-size cases on the GPU, checked through size-independent properties (the oracle would take
+hours at these sizes): linearity of the SpMV, consistency of the fused block row with the single
+blocks, FGMRES's residual estimate against the true residual recomputed with the library's own J*x,
+and that iterating reduces the residual."""
+import numpy as np
+import pytest
+
+from navier_stokes_solver_amd import problem as P
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+
+
+@pytest.fixture(scope="module")
+def big():
+    from navier_stokes_solver_amd import solver as S
+    pr = P.generate(1200, 400, nu=1.0 / 90.0)         # BASELINE configs[2]
+    ls = S.LinearSolver()
+    ls.set_option(S.OPT_TRI_ORDERING, 1)
+    ls.set_problem(pr)
+    yield pr, ls, S
+    ls.close()
+
+
+def test_sizes_match_survey(big):
+    pr, ls, S = big
+    assert (pr.n_u, pr.n_p) == (8575416, 1906816)
+    assert pr.F.nnz == 428350320
+
+
+def test_spmv_linearity_and_block_row_consistency(big):
+    pr, ls, S = big
+    rng = np.random.default_rng(3)
+    x, y = rng.uniform(-1, 1, pr.n_u), rng.uniform(-1, 1, pr.n_u)
+    a, b = 0.37, -1.9
+    lhs = ls.spmv(S.BLK_F, a * x + b * y)
+    rhs = a * ls.spmv(S.BLK_F, x) + b * ls.spmv(S.BLK_F, y)
+    assert np.abs(lhs - rhs).max() <= 1e-12 * np.abs(rhs).max()
+    xp = rng.uniform(-1, 1, pr.n_p)
+    yu, yp = ls.jacobian_vmult(x, xp)
+    ref_u = ls.spmv(S.BLK_F, x) + ls.spmv(S.BLK_BT, xp)
+    assert np.abs(yu - ref_u).max() <= 1e-12 * np.abs(ref_u).max()
+    assert np.abs(yp - ls.spmv(S.BLK_B, x)).max() <= 1e-13 * np.abs(yp).max()
+    # one row against NumPy on the host copy of the CSR
+    for r in (0, 12345, pr.n_u - 1):
+        sl = slice(pr.F.rowptr[r], pr.F.rowptr[r + 1])
+        assert abs(ls.spmv(S.BLK_F, x)[r] - np.dot(pr.F.val[sl], x[pr.F.col[sl]])) <= 1e-12 * np.abs(x).max() * np.abs(pr.F.val[sl]).sum()
+
+
+def test_fgmres_asimple_residual_is_the_true_residual(big):
+    pr, ls, S = big
+    ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+    st = ls.stats()
+    assert 30 <= st["n_colors_u"] <= 40 and st["nnz_s"] > 1.2e8
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    r0 = np.linalg.norm(b)                              # x0 = 0 on free rows; Dirichlet values are 0 here
+    xu, xp, its, res, rc = ls.solve(S.FGMRES, 0.0, 3, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    assert rc == 1 and its == 3
+    yu, yp = ls.jacobian_vmult(xu, xp)
+    true_res = np.linalg.norm(b - np.concatenate([yu, yp]))
+    assert abs(true_res - res) <= 1e-8 * r0            # least-squares estimate == true residual (right preconditioning)
+    assert res < r0
+
+
+def test_ilu_apply_inverts_its_own_factors(big):
+    """x = U^-1 L^-1 b  =>  the multicolour ILU(0) apply is linear and idempotent under refactorisation."""
+    pr, ls, S = big
+    ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+    rng = np.random.default_rng(5)
+    b1, b2 = rng.uniform(-1, 1, pr.n_u), rng.uniform(-1, 1, pr.n_u)
+    x1, x2 = ls.tri_apply(S.TRI_VELOCITY, b1), ls.tri_apply(S.TRI_VELOCITY, b2)
+    x12 = ls.tri_apply(S.TRI_VELOCITY, 2.0 * b1 - 3.0 * b2)
+    assert np.abs(x12 - (2.0 * x1 - 3.0 * x2)).max() <= 1e-11 * np.abs(x12).max()
+    ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+    assert np.array_equal(ls.tri_apply(S.TRI_VELOCITY, b1), x1)    # same values -> bitwise the same factors

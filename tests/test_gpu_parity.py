@@ -267,3 +267,24 @@ def test_both_kernel_families(stream):
         assert rel_err(ls.tri_apply(S.TRI_VELOCITY, b), ref) <= 1e-11
     finally:
         ls.close()
+
+
+def test_north_star_tolerance_on_60x20(handles):
+    """FGMRES + aSIMPLE to the north-star tolerance 1e-10 on the 60x20 Newton system: final residual
+    <= 1e-10 and solution against the oracle's (committed fixture: the oracle needs ~3 minutes here)
+    and the sparse-direct solution."""
+    import os
+    S = _S()
+    pr = problem("ns60")
+    ls = handles("ns60", 1)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ns60_north_star.npz"))
+    J = pr.jacobian_scipy().tocsc()
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+    xu, xp, its, res, rc = ls.solve(S.FGMRES, 1e-10, 20000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    assert rc == 0 and res <= 1e-10 and float(g["final_res"]) <= 1e-10
+    x = np.concatenate([xu, xp])
+    assert np.linalg.norm(b - J @ x) <= 1.05e-10
+    assert rel_err(x, g["x"]) <= 1e-6 and rel_err(x, spl.splu(J).solve(b)) <= 1e-6
+    # the fixture used natural-order ILU(0), the GPU run the multicolour ordering: counts are close, not equal
+    assert 0.5 * int(g["iters"]) <= its <= 1.5 * int(g["iters"]), (its, int(g["iters"]))
