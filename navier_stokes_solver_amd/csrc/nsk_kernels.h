@@ -118,8 +118,10 @@ struct TriHalf {
   const double *val;
   const int4 *desc;  // per workgroup: {first row, end row, first nnz, end nnz} — one load instead of a chain
 };
-void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, const double *dinv,
-                      const int *perm, const double *rhs, double *x);
+// permx = 1: w is an internal colour-ordered vector and M.col holds colour-order ids; the lower solve gathers
+// rhs through perm, the upper solve also scatters its result to out[perm[r]].
+void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx,
+                      const double *dinv, const int *perm, const double *rhs, double *w, double *out);
 
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,

@@ -192,10 +192,16 @@ __global__ __launch_bounds__(BLK) void spmv2_stream_kernel(CsrView A, const doub
 // (colour) order, but the solution vector x and the column ids stay in the CALLER's (lattice)
 // numbering: the gathers x[col] of one row then fall into a few runs of neighbouring entries, like
 // the x-gathers of the SpMV, instead of one cache line per entry.
-template <int LOWER, int KIND>
+// PERMX = 0: w is the caller-order vector x (i = perm[r]), column ids are caller-order ids.
+// PERMX = 1: w is an internal colour-ordered vector (i = r), column ids are colour-order ids; the lower
+//            solve gathers rhs through perm and the upper solve scatters the result to `out`.  A level
+//            then only touches the segments of the colours it depends on (fewer bytes per level), at
+//            the price of one cache line per gathered entry.
+template <int LOWER, int KIND, int PERMX>
 __global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int nb, const double *__restrict__ dinv,
                                                          const int *__restrict__ perm,
-                                                         const double *__restrict__ rhs, double *__restrict__ x) {
+                                                         const double *__restrict__ rhs, double *__restrict__ w,
+                                                         double *__restrict__ out) {
   __shared__ double prod[kStreamNnz];
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the k-th
   // contiguous eighth of the level's row runs.  Neighbouring rows then share one L2, and the same
@@ -207,24 +213,28 @@ __global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int 
   const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
   const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
   const bool have = r < r1;
-  int jb = 0, je = 0, i = 0;
+  int jb = 0, je = 0, i = 0, ip = 0;
   double own = 0.0, dv = 1.0;
   if (have) {
     jb = M.rowptr[r] - k0;
     je = M.rowptr[r + 1] - k0;
-    i = perm[r];
-    own = LOWER ? rhs[i] : x[i];  // x[i] of this level's own rows is not written by anyone else
+    ip = perm[r];
+    i = PERMX ? r : ip;
+    own = LOWER ? rhs[ip] : w[i];  // w[i] of this level's own rows is not written by anyone else
     if (KIND == 1 || !LOWER) dv = dinv[r];
   }
-  // the factor is streamed once per apply: non-temporal loads keep it from evicting the x lines the
+  // the factor is streamed once per apply: non-temporal loads keep it from evicting the lines the
   // gathers want to find in L2 again
   for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK)
-    prod[k - k0] = __builtin_nontemporal_load(M.val + k) * x[__builtin_nontemporal_load(M.col + k)];
+    prod[k - k0] = __builtin_nontemporal_load(M.val + k) * w[__builtin_nontemporal_load(M.col + k)];
   __syncthreads();
   const double sum = row_sum_lds(prod, jb, je, lane);
   if (have && lane == 0) {
-    if (LOWER) x[i] = KIND == 0 ? (own - sum) : (own - sum) * dv;
-    else x[i] = KIND == 0 ? (own - sum) * dv : own - sum * dv;
+    double v;
+    if (LOWER) v = KIND == 0 ? (own - sum) : (own - sum) * dv;
+    else v = KIND == 0 ? (own - sum) * dv : own - sum * dv;
+    w[i] = v;
+    if (PERMX && !LOWER) out[ip] = v;
   }
 }
 
@@ -555,14 +565,19 @@ void spmv2_stream(hipStream_t s, const CsrView &A, const double *xao, const doub
   hipLaunchKernelGGL((spmv2_stream_kernel<2>), dim3(nblk), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, rowblk, y);
 }
 
-void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, const double *dinv,
-                      const int *perm, const double *rhs, double *x) {
+void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx,
+                      const double *dinv, const int *perm, const double *rhs, double *w, double *out) {
   const int nb = b1 - b0;
   if (nb <= 0) return;
   const int grid = ((nb + 7) / 8) * 8;
-#define NSK_TS(L, K) hipLaunchKernelGGL((tri_stream_kernel<L, K>), dim3(grid), dim3(BLK), 0, s, M, b0, nb, dinv, perm, rhs, x)
-  if (lower) { if (kind == 0) NSK_TS(1, 0); else NSK_TS(1, 1); }
-  else { if (kind == 0) NSK_TS(0, 0); else NSK_TS(0, 1); }
+#define NSK_TS(L, K, P) hipLaunchKernelGGL((tri_stream_kernel<L, K, P>), dim3(grid), dim3(BLK), 0, s, M, b0, nb, dinv, perm, rhs, w, out)
+  if (permx) {
+    if (lower) { if (kind == 0) NSK_TS(1, 0, 1); else NSK_TS(1, 1, 1); }
+    else { if (kind == 0) NSK_TS(0, 0, 1); else NSK_TS(0, 1, 1); }
+  } else {
+    if (lower) { if (kind == 0) NSK_TS(1, 0, 0); else NSK_TS(1, 1, 0); }
+    else { if (kind == 0) NSK_TS(0, 0, 0); else NSK_TS(0, 1, 0); }
+  }
 #undef NSK_TS
 }
 

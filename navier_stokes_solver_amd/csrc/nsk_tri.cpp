@@ -206,12 +206,12 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
 #pragma omp for schedule(static)
       for (int i = 0; i < n; ++i) {
         buf.clear();
-        for (int k = prp[i]; k < pdiag[i]; ++k) buf.emplace_back(perm[pcol[k]], k);
+        for (int k = prp[i]; k < pdiag[i]; ++k) buf.emplace_back(x_layout ? pcol[k] : perm[pcol[k]], k);
         std::sort(buf.begin(), buf.end());
         int w = lrp[i];
         for (auto &e : buf) { lcol[w] = e.first; lsrc[w] = e.second; ++w; }
         buf.clear();
-        for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k) buf.emplace_back(perm[pcol[k]], k);
+        for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k) buf.emplace_back(x_layout ? pcol[k] : perm[pcol[k]], k);
         std::sort(buf.begin(), buf.end());
         w = urp[i];
         for (auto &e : buf) { ucol[w] = e.first; usrc[w] = e.second; ++w; }
@@ -281,9 +281,14 @@ void TriSolve::apply(const double *b, double *x) {
   hipStream_t s = ctx->stream;
   if (stream_ready && use_stream) {
     const TriHalf L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
-    // x doubles as the intermediate vector: rows not yet solved hold L^-1 b, solved rows hold the result
-    for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, dinv.p, d_perm.p, b, x);
-    for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, dinv.p, d_perm.p, nullptr, x);
+    if (x_layout == 0) {
+      // x doubles as the intermediate vector: rows not yet solved hold L^-1 b, solved rows hold the result
+      for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, 0, dinv.p, d_perm.p, b, x, nullptr);
+      for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, 0, dinv.p, d_perm.p, nullptr, x, nullptr);
+    } else {
+      for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, 1, dinv.p, d_perm.p, b, y.p, nullptr);
+      for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, 1, dinv.p, d_perm.p, nullptr, y.p, x);
+    }
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
     return;

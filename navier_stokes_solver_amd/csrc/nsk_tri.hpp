@@ -41,6 +41,7 @@ struct TriSolve {
 
   // split factors for the streamed kernels (multicolour ordering: one colour = one contiguous level)
   bool use_stream = true, stream_ready = false;
+  int x_layout = 0;  // 0: solve in the caller's (lattice) order; 1: internal colour-ordered vector
   DBuf<int> Lrp, Lcol, Lsrc, Urp, Ucol, Usrc;
   DBuf<int4> Ldesc, Udesc;
   DBuf<double> Lval, Uval, dinv;

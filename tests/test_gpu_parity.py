@@ -288,3 +288,27 @@ def test_north_star_tolerance_on_60x20(handles):
     assert rel_err(x, g["x"]) <= 1e-6 and rel_err(x, spl.splu(J).solve(b)) <= 1e-6
     # the fixture used natural-order ILU(0), the GPU run the multicolour ordering: counts are close, not equal
     assert 0.5 * int(g["iters"]) <= its <= 1.5 * int(g["iters"]), (its, int(g["iters"]))
+
+
+def test_tri_x_layouts_agree():
+    """Triangular solves on the caller-order vector and on the internal colour-ordered vector are the
+    same arithmetic (only the summation order inside a row differs)."""
+    S, O = _S(), _O()
+    pr = problem("ns60")
+    out = []
+    for layout in (0, 1):
+        ls = S.LinearSolver()
+        try:
+            ls.set_problem(pr)
+            ls.set_option(S.OPT_TRI_ORDERING, 1)
+            ls.set_option(S.OPT_TRI_X_LAYOUT, layout)
+            ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+            b = rng_vec(pr.n_u, 70)
+            x = ls.tri_apply(S.TRI_VELOCITY, b)
+            ref = O.Tri(O.CsrHolder.from_block(pr.F), kind=0, perm=ls.tri_perm(S.TRI_VELOCITY)).apply(b)
+            assert rel_err(x, ref) <= 1e-11
+            bp = rng_vec(pr.n_p, 71)
+            out.append((x, ls.tri_apply(S.TRI_PRESSURE, bp)))
+        finally:
+            ls.close()
+    assert rel_err(out[0][0], out[1][0]) <= 1e-12 and rel_err(out[0][1], out[1][1]) <= 1e-12
