@@ -205,7 +205,9 @@ def main():
                            kk["ILU(F) apply, upper levels (36 launches)"]["traffic_bytes_corrected_per_apply"])
             traffic_src = "profiles/r01_pmc_traffic_1200x400.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None
         out = {
-            "metric": "DoF*iters/s (FGMRES+aSIMPLE, Re=100)", "value": value, "unit": "DoF*iters/s",
+            "metric": f"DoF*iters/s ({['GMRES', 'FGMRES', 'Bicgstab'][args.solver]}+"
+                      f"{['blockDiagonal', 'blockTriangular', 'aSIMPLE'][args.preconditioner]}, Re={args.reynolds:g})",
+            "value": value, "unit": "DoF*iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",

@@ -1,0 +1,93 @@
+"""Error behaviour at the C ABI: usage errors come back as negative codes with a message, never as
+exceptions or crashes; solver failures come back as the positive status codes of nsk.h."""
+import numpy as np
+import pytest
+
+from tests.util import problem
+
+pytestmark = pytest.mark.gpu
+
+
+def test_usage_errors_are_reported():
+    from navier_stokes_solver_amd import solver as S
+    pr = problem("stokes16")
+    ls = S.LinearSolver()
+    try:
+        with pytest.raises(RuntimeError, match="call nsk_setup_preconditioner first|set blocks"):
+            ls.solve(S.FGMRES, 1e-8, 10, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+        ls.set_partition(S.SPACE_U, 0, pr.n_u, [])
+        ls.set_partition(S.SPACE_P, 0, pr.n_p, [])
+        bad = type(pr.F)(rows=pr.F.rows - 2, cols=pr.F.cols, rowptr=pr.F.rowptr[:-2], col=pr.F.col, val=pr.F.val)
+        with pytest.raises(RuntimeError, match="row count"):
+            ls.set_block(S.BLK_F, bad)
+        col = pr.F.col.copy()
+        col[5] = pr.F.cols + 3
+        with pytest.raises(RuntimeError, match="column id out of range"):
+            ls.set_block(S.BLK_F, type(pr.F)(rows=pr.F.rows, cols=pr.F.cols, rowptr=pr.F.rowptr, col=col, val=pr.F.val))
+        ls.set_problem(pr)
+        with pytest.raises(RuntimeError, match="Invalid preconditioner type. Use 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE."):
+            ls.setup_preconditioner(3)
+        with pytest.raises(RuntimeError, match="unknown option"):
+            ls.set_option(99, 1.0)
+        ls.setup_preconditioner(S.BLOCK_DIAGONAL, S.STATIONARY)
+        with pytest.raises(RuntimeError, match="Invalid solver type"):
+            ls.solve(7, 1e-8, 10, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+        with pytest.raises(RuntimeError, match="partition is fixed"):
+            ls.set_partition(S.SPACE_U, 0, pr.n_u, [])
+    finally:
+        ls.close()
+
+
+def test_solver_status_codes():
+    from navier_stokes_solver_amd import solver as S
+    pr = problem("unsteady16")
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr)
+        ls.setup_preconditioner(S.ASIMPLE, S.UNSTEADY)
+        # 1: outer solver out of iterations (the reference would die on an uncaught NoConvergence)
+        _, _, its, res, rc = ls.solve(S.FGMRES, 1e-12, 4, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+        assert (rc, its) == (1, 4) and res > 1e-12
+        with pytest.raises(S.NoConvergence):
+            du, dp = pr.x0_u.copy(), pr.x0_p.copy()
+            ls.L.nsk_setup_preconditioner(ls.h, S.ASIMPLE, S.UNSTEADY, 0.5)
+            xu, xp, it, r, st = ls.solve(S.FGMRES, 1e-12, 3, pr.rhs_u, pr.rhs_p, du, dp)
+            raise S.NoConvergence(st, it, r) if st else AssertionError
+        # 2: BiCGStab restarts exhausted below deal.II's absolute breakdown threshold
+        _, _, its, res, rc = ls.solve(S.BICGSTAB, 1e-10, 100000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+        assert rc == 2 and 1e-10 < res < 1e-3
+        # NaN in the right-hand side: SolverControl reports failure, nothing hangs
+        bad = pr.rhs_u.copy()
+        bad[10] = np.nan
+        _, _, its, res, rc = ls.solve(S.FGMRES, 1e-8, 50, bad, pr.rhs_p, pr.x0_u, pr.x0_p)
+        assert rc == 1 and np.isnan(res)
+    finally:
+        ls.close()
+
+
+def test_update_values_refreshes_the_preconditioner():
+    """Newton iteration 2: same pattern, new values (nsk_update_values + setup again)."""
+    from navier_stokes_solver_amd import problem as P
+    from navier_stokes_solver_amd import solver as S
+    from oracle import oracle as O
+    from tests.util import CASES, rel_err
+    pr1 = problem("ns16")
+    kw = dict(CASES["ns16"])
+    kw["nu"] = 1.0 / 50.0
+    pr2 = P.generate(**kw)
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr1)
+        ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+        ls.solve(S.FGMRES, 1e-6, 20000, pr1.rhs_u, pr1.rhs_p, pr1.x0_u, pr1.x0_p)
+        for blk, csr in ((S.BLK_F, pr2.F), (S.BLK_BT, pr2.Bt), (S.BLK_B, pr2.B), (S.BLK_MP, pr2.Mp)):
+            ls.update_values(blk, csr.val)
+        du, dp = pr2.x0_u.copy(), pr2.x0_p.copy()
+        its = ls.solve_system(S.FGMRES, S.ASIMPLE, 1e-12, pr2.rhs_u, pr2.rhs_p, du, dp)
+        b = np.concatenate([pr2.rhs_u, pr2.rhs_p])
+        xo, info = O.OracleProblem.from_local(pr2).solve(b, np.concatenate([pr2.x0_u, pr2.x0_p]), solver=1, prec=2,
+                                                         variant=0, tol=1e-12)
+        assert rel_err(np.concatenate([du, dp]), xo) <= 1e-7
+        assert abs(its - info["iters"]) <= max(3, 0.2 * info["iters"])
+    finally:
+        ls.close()
