@@ -117,6 +117,7 @@ def run(cfg, unsteady: bool) -> int:
     print("===============================================")
     print(f"Target Re = {cfg['Re']:g}")
     ls = S.LinearSolver()
+    ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)   # GPU-friendly ILU/SGS ordering
     variant = S.UNSTEADY if unsteady else S.STATIONARY
     U = 0.3 if unsteady else 0.1
     inv_dt = 1.0 / cfg["dt"] if unsteady else 0.0

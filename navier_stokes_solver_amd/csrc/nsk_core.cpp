@@ -67,7 +67,7 @@ void Comm::init(int rank_, int nranks_, const void *unique_id) {
   nranks = nranks_;
   comm = nullptr;
   local = nullptr;
-  if (nranks <= 1) return;
+  if (nranks <= 1 && !unique_id) return;  // a one-rank run with an id still goes through RCCL (self-test of the transport)
   if (!unique_id) throw Error(-21, "nranks > 1 needs an RCCL unique id");
   if (std::memcmp(unique_id, kLocalMagic, 8) == 0) {
     int id = 0, n = 0;
@@ -103,7 +103,7 @@ void Comm::destroy() {
 }
 
 void Comm::allreduce_sum(double *d, int count, hipStream_t s) {
-  if (nranks <= 1) return;
+  if (nranks <= 1 && !comm) return;
   if (local) {
     if (count > LocalGroup::kCap) throw Error(-23, "local allreduce: too many values");
     NSK_HIP(hipMemcpyAsync(h_tmp, d, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
@@ -208,7 +208,7 @@ void Ctx::dot(int n, const double *x, const double *y, int so) {
 }
 void Ctx::norm2(int n, const double *x, int so) {
   vec_dot(stream, ws, n, x, x, slot(so), 1);
-  if (comm.nranks > 1) {
+  if (comm.active()) {
     comm.allreduce_sum(slot(so), 1, stream);
     scalar_sqrt(stream, slot(so), slot(so) + 1);
   }
@@ -223,7 +223,7 @@ void Ctx::axpy_dot(int n, SRef a, const double *x, double *y, const double *w, i
 }
 void Ctx::axpy_norm2(int n, SRef a, const double *x, double *y, int so) {
   vec_axpy_dot(stream, ws, n, a, x, y, y, slot(so), 1);
-  if (comm.nranks > 1) {
+  if (comm.active()) {
     comm.allreduce_sum(slot(so), 1, stream);
     scalar_sqrt(stream, slot(so), slot(so) + 1);
   }
@@ -232,7 +232,7 @@ void Ctx::axpy_norm2(int n, SRef a, const double *x, double *y, int so) {
 }
 void Ctx::cg_update(int n, SRef a, const double *d, const double *h, double *x, double *g, int so) {
   vec_cg_update(stream, ws, n, a, d, h, x, g, slot(so));
-  if (comm.nranks > 1) {
+  if (comm.active()) {
     comm.allreduce_sum(slot(so), 1, stream);
     scalar_sqrt(stream, slot(so), slot(so) + 1);
   }
@@ -252,7 +252,7 @@ void Ctx::multi_axpy(int n, double *w, double *const *v, int m, int coef_slot, i
   VecPack P{};
   for (int k = 0; k < m; ++k) P.v[k] = v[k];
   vec_multi_axpy(stream, ws, n, w, P, m, slot(coef_slot), norm_slot >= 0 ? slot(norm_slot) : nullptr);
-  if (norm_slot >= 0 && comm.nranks > 1) {
+  if (norm_slot >= 0 && comm.active()) {
     comm.allreduce_sum(slot(norm_slot), 1, stream);
     scalar_sqrt(stream, slot(norm_slot), slot(norm_slot) + 1);
   }

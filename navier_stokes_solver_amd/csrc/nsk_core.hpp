@@ -135,6 +135,7 @@ struct Comm {
   const double *pub_buf = nullptr;
   const std::vector<int> *pub_peers = nullptr, *pub_send_ptr = nullptr;
   double *h_tmp = nullptr;
+  bool active() const { return nranks > 1 || comm != nullptr; }
   void init(int rank, int nranks, const void *unique_id);
   void destroy();
   void allreduce_sum(double *d, int count, hipStream_t s);

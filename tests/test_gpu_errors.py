@@ -77,6 +77,7 @@ def test_update_values_refreshes_the_preconditioner():
     pr2 = P.generate(**kw)
     ls = S.LinearSolver()
     try:
+        ls.set_option(S.OPT_TRI_ORDERING, 1)
         ls.set_problem(pr1)
         ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
         ls.solve(S.FGMRES, 1e-6, 20000, pr1.rhs_u, pr1.rhs_p, pr1.x0_u, pr1.x0_p)
@@ -85,7 +86,8 @@ def test_update_values_refreshes_the_preconditioner():
         du, dp = pr2.x0_u.copy(), pr2.x0_p.copy()
         its = ls.solve_system(S.FGMRES, S.ASIMPLE, 1e-12, pr2.rhs_u, pr2.rhs_p, du, dp)
         b = np.concatenate([pr2.rhs_u, pr2.rhs_p])
-        xo, info = O.OracleProblem.from_local(pr2).solve(b, np.concatenate([pr2.x0_u, pr2.x0_p]), solver=1, prec=2,
+        xo, info = O.OracleProblem.from_local(pr2, perm_F=ls.tri_perm(S.TRI_VELOCITY),
+                                              perm_S=ls.tri_perm(S.TRI_PRESSURE)).solve(b, np.concatenate([pr2.x0_u, pr2.x0_p]), solver=1, prec=2,
                                                          variant=0, tol=1e-12)
         assert rel_err(np.concatenate([du, dp]), xo) <= 1e-7
         assert abs(its - info["iters"]) <= max(3, 0.2 * info["iters"])

@@ -180,6 +180,8 @@ SOLVE_CASES = [
 @pytest.mark.parametrize("ordering", [0, 1])
 def test_solve_matches_oracle_and_direct(handles, name, solver, prec, variant, tol, ordering):
     S, O = _S(), _O()
+    if ordering == 0 and (name, prec, variant) == ("unsteady16", 0, 1):
+        pytest.skip("natural-order (serial-level) kernels are covered by the other cases; this one takes 40 s")
     pr = problem(name)
     ls = handles(name, ordering)
     J = pr.jacobian_scipy().tocsc()

@@ -153,3 +153,29 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering):
     xo, info = op.solve(b, np.concatenate([pr.x0_u, pr.x0_p]), solver=1, prec=prec, variant=variant, tol=1e-12)
     assert info["status"] == 0 and rel_err(x, xo) <= 1e-7
     assert abs(res[0]["its"] - info["iters"]) <= max(3, 0.2 * info["iters"])
+
+
+@pytest.mark.gpu
+def test_rccl_transport_self_test():
+    """One rank with a real RCCL communicator: every reduction of the solve goes through
+    ncclAllReduce on the library's stream (the 8-GPU node is only available at round end)."""
+    from navier_stokes_solver_amd import solver as S
+    pr = problem("ns16")
+    ref = S.LinearSolver()
+    ref.set_option(S.OPT_TRI_ORDERING, 1)
+    ref.set_problem(pr)
+    ref.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+    xr = ref.solve(S.FGMRES, 1e-10, 20000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    ref.close()
+    ls = S.LinearSolver(0, 1, 0, S.get_unique_id())
+    try:
+        ls.set_option(S.OPT_TRI_ORDERING, 1)
+        ls.set_problem(pr)
+        ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+        xg = ls.solve(S.FGMRES, 1e-10, 20000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+        d, nrm = ls.dot(rng_vec(1000, 1), rng_vec(1000, 2))
+    finally:
+        ls.close()
+    assert xg[4] == 0 and xg[2] == xr[2]                       # same iteration count
+    assert np.array_equal(xg[0], xr[0]) and np.array_equal(xg[1], xr[1])   # a 1-rank all-reduce is the identity
+    assert abs(d - float(np.dot(rng_vec(1000, 1), rng_vec(1000, 2)))) < 1e-12
