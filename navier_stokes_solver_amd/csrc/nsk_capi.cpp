@@ -75,9 +75,10 @@ struct nsk_handle_s {
   bool pools_ready = false;
   int tri_ordering = ORDER_NATURAL, subdomains = 1, fuse_block_row = 1, use_stream = 1;
   bool inner_fused_gs = true, outer_fused_gs = false;
-  DBuf<int> jrow_blk;  // row runs of the fused (F | Bt) block row
-  int jrow_nblk = 0;
-  bool jrow_ok = false;
+  int use_bsr = 1;
+  DBuf<int> jrow_blk, jblk_blk;  // row runs of the fused (F | Bt) block row: CSR and blocked variants
+  int jrow_nblk = 0, jblk_nblk = 0;
+  bool jrow_ok = false, jblk_ok = false;
 
   int prec_type = -1, variant = 0;
   double alpha = 0.5;
@@ -114,7 +115,9 @@ struct nsk_handle_s {
     const int op = (int)(&A - blk);
     EventSampler::Slot *smp = sampler.want(op);
     if (smp) (void)hipEventRecord(smp->e0[smp->used], s());
-    if (A.stream_ok && use_stream)
+    if (A.blk_ok && use_stream && use_bsr && mode == 0)
+      nsk::spmv_blk_stream(s(), A.blk_view(), A.blk_R, A.blk_C, A.blk_rowblk.p, A.blk_nblk, x.own, x.ghost, y);
+    else if (A.stream_ok && use_stream)
       nsk::spmv_stream(s(), A.view(), A.rowblk.p, A.nblk, A.even_rows, x.own, x.ghost, y, mode, z);
     else
       nsk::spmv(s(), A.view(), A.lpr, x.own, x.ghost, y, mode, z);
@@ -128,6 +131,17 @@ struct nsk_handle_s {
     halo(0, xu);
     halo(1, xp);
     Csr &F = blk[NSK_BLK_F], &Bt = blk[NSK_BLK_BT], &B = blk[NSK_BLK_B];
+    const bool blocked = use_stream && use_bsr && F.blk_ok && Bt.blk_ok && F.blk_R == 2 && Bt.blk_R == 2 &&
+                         F.blk_rows == Bt.blk_rows;
+    if (fuse_block_row && blocked && !jblk_ok && jblk_nblk == 0) {
+      std::vector<int> rb;
+      if (build_rowblocks(F.h_blk_rowptr.data(), Bt.h_blk_rowptr.data(), F.blk_rows, kBlkMax, nullptr, rb)) {
+        jblk_nblk = (int)rb.size() - 1;
+        jblk_blk.upload(rb, s());
+        ctx.sync();
+        jblk_ok = true;
+      } else jblk_nblk = -1;
+    }
     if (fuse_block_row && use_stream && !jrow_ok && jrow_nblk == 0 && F.even_rows) {
       std::vector<int> rb;
       if (build_rowblocks(F.h_rowptr.data(), Bt.h_rowptr.data(), F.n_rows, kStreamNnz, nullptr, rb)) {
@@ -137,14 +151,20 @@ struct nsk_handle_s {
         jrow_ok = true;
       } else jrow_nblk = -1;
     }
-    if (fuse_block_row && use_stream && jrow_ok) {
+    const double fused_bytes = (double)F.spmv_bytes() + (double)Bt.spmv_bytes() - 8.0 * F.n_rows - 4.0 * (F.n_rows + 1);
+    if (fuse_block_row && blocked && jblk_ok) {
+      nsk::spmv_blk_fused22_21(s(), F.blk_view(), xu.own, xu.ghost, Bt.blk_view(), xp.own, xp.ghost, jblk_blk.p,
+                               jblk_nblk, yb);
+      ctx.st.spmv_calls += 2;
+      ctx.st.spmv_bytes += fused_bytes;
+    } else if (fuse_block_row && use_stream && jrow_ok) {
       nsk::spmv2_stream(s(), F.view(), xu.own, xu.ghost, Bt.view(), xp.own, xp.ghost, jrow_blk.p, jrow_nblk, yb);
       ctx.st.spmv_calls += 2;
-      ctx.st.spmv_bytes += (double)F.spmv_bytes() + (double)Bt.spmv_bytes() - 8.0 * F.n_rows - 4.0 * (F.n_rows + 1);
+      ctx.st.spmv_bytes += fused_bytes;
     } else if (fuse_block_row) {
       nsk::spmv2(s(), F.view(), xu.own, xu.ghost, Bt.view(), xp.own, xp.ghost, yb, F.lpr);
       ctx.st.spmv_calls += 2;
-      ctx.st.spmv_bytes += (double)F.spmv_bytes() + (double)Bt.spmv_bytes() - 8.0 * F.n_rows - 4.0 * (F.n_rows + 1);
+      ctx.st.spmv_bytes += fused_bytes;
     } else {
       spmv_nohalo(F, xu, yb, 0);
       spmv_nohalo(Bt, xp, yb, 1);
@@ -518,8 +538,11 @@ int nsk_set_block_csr(nsk_handle h, int b, int n_rows, int n_cols, const int32_t
   A.lpr = pick_lpr(nnz, n_rows);
   A.present = true;
   A.build_stream_plan(h->s());
+  if (b == NSK_BLK_F) A.build_blocked(2, 2, h->s());
+  if (b == NSK_BLK_BT) A.build_blocked(2, 1, h->s());
+  if (b == NSK_BLK_B) A.build_blocked(1, 2, h->s());
   h->ctx.sync();
-  if (b == NSK_BLK_F || b == NSK_BLK_BT) { h->jrow_ok = false; h->jrow_nblk = 0; }
+  if (b == NSK_BLK_F || b == NSK_BLK_BT) { h->jrow_ok = h->jblk_ok = false; h->jrow_nblk = h->jblk_nblk = 0; }
   // a new pattern invalidates cached symbolic data
   if (b == NSK_BLK_F) h->tF_ok = false;
   if (b == NSK_BLK_MP) h->tMp_ok = false;
@@ -534,6 +557,7 @@ int nsk_update_values(nsk_handle h, int b, const double *val) {
   (void)hipSetDevice(h->ctx.device);
   Csr &A = h->blk[b];
   NSK_HIP(hipMemcpyAsync(A.val.p, val, sizeof(double) * (size_t)A.nnz, hipMemcpyHostToDevice, h->s()));
+  A.refresh_blocked(h->s());
   h->ctx.sync();
   return 0;
   NSK_CATCH(h)
@@ -546,6 +570,7 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
     case NSK_OPT_SUBDOMAINS: h->subdomains = std::max(1, (int)v); break;
     case NSK_OPT_FUSE_BLOCK_ROW: h->fuse_block_row = v != 0.0; break;
     case NSK_OPT_STREAM_KERNELS: h->use_stream = v != 0.0; h->tF.use_stream = h->tMp.use_stream = h->tS.use_stream = h->use_stream; break;
+    case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
     case NSK_OPT_TRI_X_LAYOUT:
       h->tF.x_layout = h->tMp.x_layout = h->tS.x_layout = v != 0.0;
       h->tF_ok = h->tMp_ok = h->tS_ok = false;

@@ -298,6 +298,59 @@ void Csr::build_stream_plan(hipStream_t s) {
   rowblk.upload(rb, s);
 }
 
+void Csr::build_blocked(int R, int C, hipStream_t s) {
+  blk_ok = false;
+  if (n_rows <= 0 || n_rows % R || n_own_cols % C || n_cols % C) return;
+  const int nr = n_rows / R;
+  std::vector<int> rp(nr + 1, 0);
+  // structure check: the R rows of a block row share their columns, which come in aligned groups of C
+  bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+  for (int r = 0; r < nr; ++r) {
+    const int a0 = h_rowptr[R * r], len = h_rowptr[R * r + 1] - a0;
+    bool good = len % C == 0;
+    for (int q = 1; good && q < R; ++q) good = h_rowptr[R * r + q + 1] - h_rowptr[R * r + q] == len;
+    for (int k = 0; good && k < len; k += C) {
+      const int c = h_col[a0 + k];
+      good = c % C == 0;
+      for (int q = 0; good && q < R; ++q)
+        for (int t = 0; good && t < C; ++t) good = h_col[h_rowptr[R * r + q] + k + t] == c + t;
+    }
+    rp[r + 1] = len / C;
+    ok = ok && good;
+  }
+  if (!ok) return;
+  for (int r = 0; r < nr; ++r) rp[r + 1] += rp[r];
+  blk_count = rp[nr];
+  std::vector<int> bcol((size_t)blk_count), bsrc((size_t)blk_count * R * C), rb;
+#pragma omp parallel for schedule(static)
+  for (int r = 0; r < nr; ++r)
+    for (int k = 0; k < rp[r + 1] - rp[r]; ++k) {
+      const size_t b = (size_t)rp[r] + k;
+      bcol[b] = h_col[h_rowptr[R * r] + C * k] / C;
+      for (int q = 0; q < R; ++q)
+        for (int t = 0; t < C; ++t) bsrc[(b * R + q) * C + t] = h_rowptr[R * r + q] + C * k + t;
+    }
+  if (!build_rowblocks(rp.data(), nullptr, nr, kBlkMax, nullptr, rb)) return;
+  blk_R = R;
+  blk_C = C;
+  blk_rows = nr;
+  blk_nblk = (int)rb.size() - 1;
+  h_blk_rowptr = rp;
+  blk_rowptr.upload(rp, s);
+  blk_col.upload(bcol, s);
+  blk_src.upload(bsrc, s);
+  blk_rowblk.upload(rb, s);
+  blk_val.alloc((size_t)blk_count * R * C);
+  NSK_HIP(hipStreamSynchronize(s));
+  blk_ok = true;
+  refresh_blocked(s);
+}
+
+void Csr::refresh_blocked(hipStream_t s) {
+  if (blk_ok) vec_gather(s, (int)(blk_count * blk_R * blk_C), blk_src.p, val.p, blk_val.p);
+}
+
 double *VecPool::get(bool zero) {
   double *p;
   if (!free_list.empty()) {

@@ -100,6 +100,16 @@ struct Csr {  // device CSR block with host copy of the pattern
   int nblk = 0;
   bool stream_ok = false, even_rows = false;
   void build_stream_plan(hipStream_t s);
+  // R x C blocked copy (F: 2x2, (0,1): 2x1, (1,0): 1x2), built when the pattern has that structure
+  bool blk_ok = false;
+  int blk_R = 1, blk_C = 1, blk_rows = 0, blk_nblk = 0;
+  int64_t blk_count = 0;
+  std::vector<int> h_blk_rowptr;
+  DBuf<int> blk_rowptr, blk_col, blk_src, blk_rowblk;
+  DBuf<double> blk_val;
+  void build_blocked(int R, int C, hipStream_t s);  // pattern analysis + upload (host); values via refresh_blocked
+  void refresh_blocked(hipStream_t s);              // blk_val[k] = val[blk_src[k]] on the device
+  BlkView blk_view() const { return BlkView{blk_rows, n_own_cols / blk_C, blk_rowptr.p, blk_col.p, blk_val.p}; }
   CsrView view() const { return CsrView{n_rows, n_own_cols, rowptr.p, col.p, val.p}; }
   size_t spmv_bytes() const {  // 12 nnz + 4 (rows+1) + 8 rows + 8 cols
     return (size_t)12 * nnz + 4 * ((size_t)n_rows + 1) + 8 * (size_t)n_rows + 8 * (size_t)n_cols;

@@ -52,6 +52,26 @@ void spmv_stream(hipStream_t s, const CsrView &A, const int *rowblk, int nblk, i
 void spmv2_stream(hipStream_t s, const CsrView &A, const double *xa_own, const double *xa_ghost, const CsrView &B,
                   const double *xb_own, const double *xb_ghost, const int *rowblk, int nblk, double *y);
 
+// Small dense blocks exploit the node structure of the Taylor-Hood blocks: both velocity components of a
+// node share one sparsity pattern, so F is made of 2x2 blocks, (0,1) of 2x1 and (1,0) of 1x2 blocks.  One
+// int32 block-column id then serves R*C values: 9 B/nnz for F and 10 B/nnz for the off-diagonal blocks
+// instead of CSR's 12 B/nnz, and the x-gather is one (vector) load per block.
+struct BlkView {
+  int n_brows;          // block rows
+  int n_own_bcols;      // owned block columns (ghost block columns follow)
+  const int *rowptr;    // per block row, in blocks
+  const int *col;       // block-column id
+  const double *val;    // R*C per block, row-major
+};
+constexpr int kBlkMax = 1024;  // blocks per workgroup (both matrices together in the fused kernel)
+// y = A x on an R x C blocked matrix (R, C in {1,2}); rowblk = runs of block rows
+void spmv_blk_stream(hipStream_t s, const BlkView &A, int R, int C, const int *rowblk, int nblk, const double *x_own,
+                     const double *x_ghost, double *y);
+// y = A xa + B xb with A 2x2-blocked and B 2x1-blocked over the same block rows (velocity block row of J)
+void spmv_blk_fused22_21(hipStream_t s, const BlkView &A, const double *xa_own, const double *xa_ghost,
+                         const BlkView &B, const double *xb_own, const double *xb_ghost, const int *rowblk, int nblk,
+                         double *y);
+
 // ---- BLAS-1 with device scalars ----
 void vec_set(hipStream_t s, int n, double *y, double v);
 void vec_copy(hipStream_t s, int n, const double *x, double *y);

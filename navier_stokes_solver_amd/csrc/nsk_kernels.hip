@@ -192,6 +192,93 @@ __global__ __launch_bounds__(BLK) void spmv2_stream_kernel(CsrView A, const doub
 // (colour) order, but the solution vector x and the column ids stay in the CALLER's (lattice)
 // numbering: the gathers x[col] of one row then fall into a few runs of neighbouring entries, like
 // the x-gathers of the SpMV, instead of one cache line per entry.
+// ------------------------------------------------------------------ blocked SpMV (R x C dense blocks)
+template <int R, int C>
+__device__ __forceinline__ void blk_products(const BlkView &A, int k0, int k1, const double *__restrict__ xo,
+                                             const double *__restrict__ xg, double *p0, double *p1) {
+  for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK) {
+    const int m = __builtin_nontemporal_load(A.col + k);
+    double x0, x1 = 0.0;
+    if (C == 2) {
+      if (m < A.n_own_bcols) {
+        const double2 xv = *reinterpret_cast<const double2 *>(xo + 2 * (size_t)m);
+        x0 = xv.x; x1 = xv.y;
+      } else {
+        const size_t g = 2 * (size_t)(m - A.n_own_bcols);  // the ghost tail may be only 8-byte aligned
+        x0 = xg[g]; x1 = xg[g + 1];
+      }
+    } else {
+      x0 = m < A.n_own_bcols ? xo[m] : xg[m - A.n_own_bcols];
+    }
+    const double *v = A.val + (size_t)(R * C) * k;
+    if (R == 2 && C == 2) {
+      const double2 a0 = *reinterpret_cast<const double2 *>(v), a1 = *reinterpret_cast<const double2 *>(v + 2);
+      p0[k - k0] = a0.x * x0 + a0.y * x1;
+      p1[k - k0] = a1.x * x0 + a1.y * x1;
+    } else if (R == 2 && C == 1) {
+      const double2 a = *reinterpret_cast<const double2 *>(v);
+      p0[k - k0] = a.x * x0;
+      p1[k - k0] = a.y * x0;
+    } else if (R == 1 && C == 2) {
+      const double2 a = *reinterpret_cast<const double2 *>(v);
+      p0[k - k0] = a.x * x0 + a.y * x1;
+    } else {
+      p0[k - k0] = v[0] * x0;
+    }
+  }
+}
+
+template <int R, int C>
+__global__ __launch_bounds__(BLK) void spmv_blk_kernel(BlkView A, const int *__restrict__ rowblk,
+                                                       const double *__restrict__ xo, const double *__restrict__ xg,
+                                                       double *__restrict__ y) {
+  __shared__ double p0[kBlkMax];
+  __shared__ double p1[R == 2 ? kBlkMax : 1];
+  const int r0 = rowblk[blockIdx.x], r1 = rowblk[blockIdx.x + 1];
+  const int k0 = A.rowptr[r0], k1 = A.rowptr[r1];
+  const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
+  const bool have = r < r1;
+  int jb = 0, je = 0;
+  if (have) { jb = A.rowptr[r] - k0; je = A.rowptr[r + 1] - k0; }
+  blk_products<R, C>(A, k0, k1, xo, xg, p0, p1);
+  __syncthreads();
+  double s0 = 0.0, s1 = 0.0;
+  for (int j = jb + lane; j < je; j += RG) { s0 += p0[j]; if (R == 2) s1 += p1[j]; }
+  s0 = subwave_sum<RG>(s0);
+  if (R == 2) s1 = subwave_sum<RG>(s1);
+  if (have && lane == 0) {
+    if (R == 2) *reinterpret_cast<double2 *>(y + 2 * (size_t)r) = make_double2(s0, s1);
+    else y[r] = s0;
+  }
+}
+
+__global__ __launch_bounds__(BLK) void spmv_blk_fused_kernel(BlkView A, const double *__restrict__ xao,
+                                                             const double *__restrict__ xag, BlkView B,
+                                                             const double *__restrict__ xbo,
+                                                             const double *__restrict__ xbg,
+                                                             const int *__restrict__ rowblk, double *__restrict__ y) {
+  __shared__ double p0[kBlkMax];
+  __shared__ double p1[kBlkMax];
+  const int r0 = rowblk[blockIdx.x], r1 = rowblk[blockIdx.x + 1];
+  const int a0 = A.rowptr[r0], a1 = A.rowptr[r1], b0 = B.rowptr[r0], b1 = B.rowptr[r1];
+  const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
+  const bool have = r < r1;
+  int ab = 0, ae = 0, bb = 0, be = 0;
+  if (have) {
+    ab = A.rowptr[r] - a0; ae = A.rowptr[r + 1] - a0;
+    bb = B.rowptr[r] - b0 + (a1 - a0); be = B.rowptr[r + 1] - b0 + (a1 - a0);
+  }
+  blk_products<2, 2>(A, a0, a1, xao, xag, p0, p1);
+  blk_products<2, 1>(B, b0, b1, xbo, xbg, p0 + (a1 - a0), p1 + (a1 - a0));
+  __syncthreads();
+  double s0 = 0.0, s1 = 0.0;
+  for (int j = ab + lane; j < ae; j += RG) { s0 += p0[j]; s1 += p1[j]; }
+  for (int j = bb + lane; j < be; j += RG) { s0 += p0[j]; s1 += p1[j]; }
+  s0 = subwave_sum<RG>(s0);
+  s1 = subwave_sum<RG>(s1);
+  if (have && lane == 0) *reinterpret_cast<double2 *>(y + 2 * (size_t)r) = make_double2(s0, s1);
+}
+
 // PERMX = 0: w is the caller-order vector x (i = perm[r]), column ids are caller-order ids.
 // PERMX = 1: w is an internal colour-ordered vector (i = r), column ids are colour-order ids; the lower
 //            solve gathers rhs through perm and the upper solve scatters the result to `out`.  A level
@@ -563,6 +650,23 @@ void spmv2_stream(hipStream_t s, const CsrView &A, const double *xao, const doub
                   const double *xbo, const double *xbg, const int *rowblk, int nblk, double *y) {
   if (nblk <= 0) return;
   hipLaunchKernelGGL((spmv2_stream_kernel<2>), dim3(nblk), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, rowblk, y);
+}
+
+void spmv_blk_stream(hipStream_t s, const BlkView &A, int R, int C, const int *rowblk, int nblk, const double *xo,
+                     const double *xg, double *y) {
+  if (nblk <= 0) return;
+#define NSK_BK(RR, CC) hipLaunchKernelGGL((spmv_blk_kernel<RR, CC>), dim3(nblk), dim3(BLK), 0, s, A, rowblk, xo, xg, y)
+  if (R == 2 && C == 2) NSK_BK(2, 2);
+  else if (R == 2 && C == 1) NSK_BK(2, 1);
+  else if (R == 1 && C == 2) NSK_BK(1, 2);
+  else NSK_BK(1, 1);
+#undef NSK_BK
+}
+
+void spmv_blk_fused22_21(hipStream_t s, const BlkView &A, const double *xao, const double *xag, const BlkView &B,
+                         const double *xbo, const double *xbg, const int *rowblk, int nblk, double *y) {
+  if (nblk > 0)
+    hipLaunchKernelGGL(spmv_blk_fused_kernel, dim3(nblk), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, rowblk, y);
 }
 
 void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx,

@@ -314,3 +314,20 @@ def test_tri_x_layouts_agree():
         finally:
             ls.close()
     assert rel_err(out[0][0], out[1][0]) <= 1e-12 and rel_err(out[0][1], out[1][1]) <= 1e-12
+
+
+@pytest.mark.parametrize("bsr", [0, 1])
+def test_velocity_block_bsr_toggle(bsr):
+    """SpMV with block (0,0): CSR-stream kernel and the 2x2 node-block kernel, also after new values."""
+    S, O = _S(), _O()
+    pr = problem("ns60")
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr)
+        ls.set_option(S.OPT_BSR_VELOCITY, bsr)
+        x = rng_vec(pr.n_u, 80)
+        assert rel_err(ls.spmv(S.BLK_F, x), O.spmv(O.CsrHolder.from_block(pr.F), x)) <= 1e-13
+        ls.update_values(S.BLK_F, 2.5 * pr.F.val)
+        assert rel_err(ls.spmv(S.BLK_F, x), 2.5 * O.spmv(O.CsrHolder.from_block(pr.F), x)) <= 1e-13
+    finally:
+        ls.close()
