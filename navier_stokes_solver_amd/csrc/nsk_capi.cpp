@@ -260,7 +260,7 @@ void H::setup(int type, int variant_, double alpha_) {
   const int kindF = (type == 0 && variant == 0) ? 1 : 0;
   const int kindP = (type == 0 && variant == 0) ? 1 : 0;
   if (!tF_ok || tF_key != key) {
-    tF.analyze(&ctx, F, kindF, tri_ordering, sub_offsets(0));
+    tF.analyze(&ctx, F, kindF, tri_ordering, sub_offsets(0), use_bsr && F.blk_ok && F.blk_R == 2 && F.blk_C == 2);
     tF_ok = true;
     tF_key = key;
   }

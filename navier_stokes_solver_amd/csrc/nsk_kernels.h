@@ -143,6 +143,20 @@ struct TriHalf {
 void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx,
                       const double *dinv, const int *perm, const double *rhs, double *w, double *out);
 
+// 2x2 node-block variant of the streamed level: node rows (two adjacent DoF rows) in node-colour order,
+// 2x2 blocks towards other nodes, and per node row intra = {l10, u01, 1/d0, 1/d1} for its own diagonal block.
+//   lower ILU: y0 = b0 - s0 ; y1 = b1 - s1 - l10 y0            lower SGS: y0 = (b0 - s0)/d0 ; y1 = (b1 - s1 - l10 y0)/d1
+//   upper ILU: x1 = (y1 - s1)/d1 ; x0 = (y0 - s0 - u01 x1)/d0  upper SGS: x1 = y1 - s1/d1 ; x0 = y0 - (s0 + u01 x1)/d0
+struct TriBlk {
+  const int *rowptr;   // per node row, in blocks
+  const int *col;      // caller-order node id of the block column
+  const double *val;   // 4 per block
+  const int4 *desc;    // per workgroup: {first node row, end node row, first block, end block}
+};
+void tri_blk_level(hipStream_t s, const TriBlk &M, int b0, int b1, int lower, int kind, const double *intra,
+                   const int *permn, const double *rhs, double *x);
+void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra);
+
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,
                        const int *col, double *val, int max_row_nnz);

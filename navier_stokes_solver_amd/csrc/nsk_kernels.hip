@@ -325,6 +325,56 @@ __global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int 
   }
 }
 
+template <int LOWER, int KIND>
+__global__ __launch_bounds__(BLK) void tri_blk_kernel(TriBlk M, int b0, int nb, const double *__restrict__ intra,
+                                                      const int *__restrict__ permn, const double *__restrict__ rhs,
+                                                      double *__restrict__ x) {
+  __shared__ double p0[kBlkMax];
+  __shared__ double p1[kBlkMax];
+  const int per = (int)gridDim.x >> 3;  // XCD-aware mapping, see tri_stream_kernel
+  const int mapped = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (mapped >= nb) return;
+  const int4 d = M.desc[b0 + mapped];
+  const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
+  const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
+  const bool have = r < r1;
+  int jb = 0, je = 0;
+  size_t i = 0;
+  double2 own = make_double2(0.0, 0.0), cf = make_double2(0.0, 0.0), di = make_double2(1.0, 1.0);
+  if (have) {
+    jb = M.rowptr[r] - k0;
+    je = M.rowptr[r + 1] - k0;
+    i = 2 * (size_t)permn[r];
+    own = *reinterpret_cast<const double2 *>((LOWER ? rhs : x) + i);
+    cf = *reinterpret_cast<const double2 *>(intra + 4 * (size_t)r);       // l10, u01
+    di = *reinterpret_cast<const double2 *>(intra + 4 * (size_t)r + 2);   // 1/d0, 1/d1
+  }
+  for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK) {
+    const int m = __builtin_nontemporal_load(M.col + k);
+    const double2 xv = *reinterpret_cast<const double2 *>(x + 2 * (size_t)m);
+    const double2 a0 = *reinterpret_cast<const double2 *>(M.val + 4 * (size_t)k);
+    const double2 a1 = *reinterpret_cast<const double2 *>(M.val + 4 * (size_t)k + 2);
+    p0[k - k0] = a0.x * xv.x + a0.y * xv.y;
+    p1[k - k0] = a1.x * xv.x + a1.y * xv.y;
+  }
+  __syncthreads();
+  double s0 = 0.0, s1 = 0.0;
+  for (int j = jb + lane; j < je; j += RG) { s0 += p0[j]; s1 += p1[j]; }
+  s0 = subwave_sum<RG>(s0);
+  s1 = subwave_sum<RG>(s1);
+  if (have && lane == 0) {
+    double v0, v1;
+    if (LOWER) {
+      if (KIND == 0) { v0 = own.x - s0; v1 = own.y - s1 - cf.x * v0; }
+      else { v0 = (own.x - s0) * di.x; v1 = (own.y - s1 - cf.x * v0) * di.y; }
+    } else {
+      if (KIND == 0) { v1 = (own.y - s1) * di.y; v0 = (own.x - s0 - cf.y * v1) * di.x; }
+      else { v1 = own.y - s1 * di.y; v0 = own.x - (s0 + cf.y * v1) * di.x; }
+    }
+    *reinterpret_cast<double2 *>(x + i) = make_double2(v0, v1);
+  }
+}
+
 // ------------------------------------------------------------------ element-wise
 template <class F>
 __global__ __launch_bounds__(BLK) void ew_kernel(int n, F f) {
@@ -652,6 +702,17 @@ void spmv2_stream(hipStream_t s, const CsrView &A, const double *xao, const doub
   hipLaunchKernelGGL((spmv2_stream_kernel<2>), dim3(nblk), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, rowblk, y);
 }
 
+void tri_blk_level(hipStream_t s, const TriBlk &M, int b0, int b1, int lower, int kind, const double *intra,
+                   const int *permn, const double *rhs, double *x) {
+  const int nb = b1 - b0;
+  if (nb <= 0) return;
+  const int grid = ((nb + 7) / 8) * 8;
+#define NSK_TB(L, K) hipLaunchKernelGGL((tri_blk_kernel<L, K>), dim3(grid), dim3(BLK), 0, s, M, b0, nb, intra, permn, rhs, x)
+  if (lower) { if (kind == 0) NSK_TB(1, 0); else NSK_TB(1, 1); }
+  else { if (kind == 0) NSK_TB(0, 0); else NSK_TB(0, 1); }
+#undef NSK_TB
+}
+
 void spmv_blk_stream(hipStream_t s, const BlkView &A, int R, int C, const int *rowblk, int nblk, const double *xo,
                      const double *xg, double *y) {
   if (nblk <= 0) return;
@@ -721,6 +782,13 @@ void vec_recip(hipStream_t s, int n, const double *x, double *y) {
 void scalar_sqrt(hipStream_t s, const double *in, double *out) {
   const int n = 1;
   NSK_EW(n, [=] __device__(int) { out[0] = sqrt(fabs(in[0])); });
+}
+void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra) {
+  const int n = n_nodes;
+  NSK_EW(n, [=] __device__(int i) {
+    intra[4 * (size_t)i + 2] = 1.0 / intra[4 * (size_t)i + 2];
+    intra[4 * (size_t)i + 3] = 1.0 / intra[4 * (size_t)i + 3];
+  });
 }
 void vec_gather(hipStream_t s, int n, const int *idx, const double *x, double *y) {
   NSK_EW(n, [=] __device__(int i) { y[i] = x[idx[i]]; });

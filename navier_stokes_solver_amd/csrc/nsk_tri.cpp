@@ -36,9 +36,39 @@ void level_lists(const std::vector<int> &level, int n_levels, std::vector<int> &
   std::vector<int> cur(lvl_ptr.begin(), lvl_ptr.end() - 1);
   for (int i = 0; i < n; ++i) rows[cur[level[i]]++] = i;  // ascending row id inside a level
 }
+// greedy distance-1 colouring on the graph of G + G^T, vertices visited in natural order
+int greedy_color(int nv, const std::vector<int> &grp, const std::vector<int> &gcol, std::vector<int> &color) {
+  const int64_t ne = grp[nv];
+  std::vector<int> trp(nv + 1, 0);
+  for (int64_t k = 0; k < ne; ++k) ++trp[gcol[k] + 1];
+  for (int i = 0; i < nv; ++i) trp[i + 1] += trp[i];
+  std::vector<int> tcol((size_t)ne), cur(trp.begin(), trp.end() - 1);
+  for (int i = 0; i < nv; ++i)
+    for (int k = grp[i]; k < grp[i + 1]; ++k) tcol[cur[gcol[k]]++] = i;
+  color.assign(nv, -1);
+  std::vector<int> mark;
+  int ncol = 0;
+  for (int i = 0; i < nv; ++i) {
+    auto visit = [&](int j) {
+      const int cj = color[j];
+      if (cj >= 0) {
+        if (cj >= (int)mark.size()) mark.resize(cj + 1, -1);
+        mark[cj] = i;
+      }
+    };
+    for (int k = grp[i]; k < grp[i + 1]; ++k) if (gcol[k] != i) visit(gcol[k]);
+    for (int k = trp[i]; k < trp[i + 1]; ++k) if (tcol[k] != i) visit(tcol[k]);
+    int cc = 0;
+    while (cc < (int)mark.size() && mark[cc] == i) ++cc;
+    color[i] = cc;
+    ncol = std::max(ncol, cc + 1);
+  }
+  return ncol;
+}
 }  // namespace
 
-void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off) {
+void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off,
+                       bool want_block2) {
   ctx = c;
   n = A.n_rows;
   kind = kind_;
@@ -77,31 +107,42 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   perm.clear();
   std::vector<int> pcolor;
   n_colors = 0;
-  if (ordering == ORDER_MULTICOLOR) {
-    // greedy distance-1 colouring on the graph of R + R^T, rows visited in natural order
-    std::vector<int> trp(n + 1, 0);
-    for (int64_t k = 0; k < nnz; ++k) ++trp[rcol[k] + 1];
-    for (int i = 0; i < n; ++i) trp[i + 1] += trp[i];
-    std::vector<int> tcol((size_t)nnz), cur(trp.begin(), trp.end() - 1);
-    for (int i = 0; i < n; ++i)
-      for (int k = rrp[i]; k < rrp[i + 1]; ++k) tcol[cur[rcol[k]]++] = i;
-    std::vector<int> color(n, -1), mark;
-    for (int i = 0; i < n; ++i) {
-      auto visit = [&](int j) {
-        const int cj = color[j];
-        if (cj >= 0) {
-          if (cj >= (int)mark.size()) mark.resize(cj + 1, -1);
-          mark[cj] = i;
-        }
-      };
-      for (int k = rrp[i]; k < rrp[i + 1]; ++k) if (rcol[k] != i) visit(rcol[k]);
-      for (int k = trp[i]; k < trp[i + 1]; ++k) if (tcol[k] != i) visit(tcol[k]);
-      int cc = 0;
-      while (cc < (int)mark.size() && mark[cc] == i) ++cc;
-      color[i] = cc;
-      if (cc + 1 > n_colors) n_colors = cc + 1;
+  // 2x2 node structure of the restricted pattern (both velocity components of a node share their columns,
+  // columns come in aligned pairs): colour NODES instead of DoFs, keep the two rows of a node adjacent
+  bool block2 = want_block2 && ordering == ORDER_MULTICOLOR && n > 0 && n % 2 == 0;
+  if (block2) {
+    bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+    for (int r = 0; r < n / 2; ++r) {
+      const int a0 = rrp[2 * r], a1 = rrp[2 * r + 1], len = a1 - a0;
+      bool good = (rrp[2 * r + 2] - a1 == len) && (len % 2 == 0);
+      for (int k = 0; good && k < len; k += 2) {
+        const int cc = rcol[a0 + k];
+        good = (cc % 2 == 0) && rcol[a0 + k + 1] == cc + 1 && rcol[a1 + k] == cc && rcol[a1 + k + 1] == cc + 1;
+      }
+      ok = ok && good;
     }
-    // perm: colours ascending, natural order inside a colour (counting sort, stable)
+    block2 = ok;
+  }
+  if (ordering == ORDER_MULTICOLOR) {
+    std::vector<int> color;
+    if (block2) {
+      const int nn = n / 2;
+      std::vector<int> nrp(nn + 1, 0);
+      for (int r = 0; r < nn; ++r) nrp[r + 1] = nrp[r] + (rrp[2 * r + 1] - rrp[2 * r]) / 2;
+      std::vector<int> ncol((size_t)nrp[nn]);
+#pragma omp parallel for schedule(static)
+      for (int r = 0; r < nn; ++r)
+        for (int k = 0; k < nrp[r + 1] - nrp[r]; ++k) ncol[(size_t)nrp[r] + k] = rcol[rrp[2 * r] + 2 * k] / 2;
+      std::vector<int> ncolor;
+      n_colors = greedy_color(nn, nrp, ncol, ncolor);
+      color.resize(n);
+      for (int i = 0; i < n; ++i) color[i] = ncolor[i / 2];
+    } else {
+      std::vector<int> rrp32(rrp.begin(), rrp.end());
+      n_colors = greedy_color(n, rrp32, rcol, color);
+    }
+    // perm: colours ascending, natural order inside a colour (counting sort, stable; a node's two rows stay adjacent)
     std::vector<int> cptr(n_colors + 1, 0);
     for (int i = 0; i < n; ++i) ++cptr[color[i] + 1];
     for (int q = 0; q < n_colors; ++q) cptr[q + 1] += cptr[q];
@@ -158,7 +199,14 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   // level schedule of the lower and upper dependency DAGs
   std::vector<int> levL(n, 0), levU(n, 0);
   n_levels_L = n_levels_U = 0;
-  if (!perm.empty()) {
+  if (!perm.empty() && block2) {
+    // node colours: the second row of a node depends on the first (lower) / the first on the second (upper)
+    for (int i = 0; i < n; ++i) {
+      levL[i] = 2 * pcolor[i] + (i & 1);
+      levU[i] = 2 * (n_colors - 1 - pcolor[i]) + (1 - (i & 1));
+    }
+    n_levels_L = n_levels_U = 2 * n_colors;
+  } else if (!perm.empty()) {
     // colour classes are independent sets: level = colour is a valid schedule for both DAGs
     // and keeps every level one contiguous run of rows
     for (int i = 0; i < n; ++i) { levL[i] = pcolor[i]; levU[i] = n_colors - 1 - pcolor[i]; }
@@ -189,7 +237,98 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
 
   hipStream_t s = ctx->stream;
   stream_ready = false;
-  if (!perm.empty()) {
+  block2_ready = false;
+  if (!perm.empty() && block2) {
+    // node rows in colour order; 2x2 blocks towards earlier (L) / later (U) colours, column ids = caller-order node ids
+    const int nn = n / 2;
+    std::vector<int> lrp(nn + 1, 0), urp(nn + 1, 0);
+    for (int r = 0; r < nn; ++r) {
+      int nl = 0, nu = 0;
+      for (int k = prp[2 * r]; k < prp[2 * r + 1]; k += 2) {
+        const int m = pcol[k] / 2;
+        if (m < r) ++nl; else if (m > r) ++nu;
+      }
+      lrp[r + 1] = lrp[r] + nl;
+      urp[r + 1] = urp[r] + nu;
+    }
+    nnzL = (int64_t)lrp[nn] * 4;
+    nnzU = (int64_t)urp[nn] * 4;
+    std::vector<int> lcol((size_t)lrp[nn]), lsrc((size_t)lrp[nn] * 4), ucol((size_t)urp[nn]), usrc((size_t)urp[nn] * 4);
+    std::vector<int> hpermn(nn), isrc((size_t)nn * 4);  // per node row: positions of l10, u01, d0, d1
+#pragma omp parallel
+    {
+      std::vector<std::pair<int, int>> bl, bu;  // (caller-order node id, k offset inside the row)
+#pragma omp for schedule(static)
+      for (int r = 0; r < nn; ++r) {
+        const int i0 = 2 * r, i1 = 2 * r + 1, a0 = prp[i0], a1 = prp[i1];
+        hpermn[r] = perm[i0] / 2;
+        bl.clear();
+        bu.clear();
+        for (int k = 0; k < prp[i0 + 1] - a0; k += 2) {
+          const int m = pcol[a0 + k] / 2;
+          if (m < r) bl.emplace_back(perm[pcol[a0 + k]] / 2, k);
+          else if (m > r) bu.emplace_back(perm[pcol[a0 + k]] / 2, k);
+          else {  // the node's own 2x2 diagonal block
+            isrc[4 * (size_t)r + 0] = a1 + k;      // l10 = (i1, i0)
+            isrc[4 * (size_t)r + 1] = a0 + k + 1;  // u01 = (i0, i1)
+            isrc[4 * (size_t)r + 2] = a0 + k;      // d0
+            isrc[4 * (size_t)r + 3] = a1 + k + 1;  // d1
+          }
+        }
+        std::sort(bl.begin(), bl.end());
+        std::sort(bu.begin(), bu.end());
+        size_t w = (size_t)lrp[r];
+        for (auto &e : bl) {
+          lcol[w] = e.first;
+          lsrc[4 * w + 0] = a0 + e.second; lsrc[4 * w + 1] = a0 + e.second + 1;
+          lsrc[4 * w + 2] = a1 + e.second; lsrc[4 * w + 3] = a1 + e.second + 1;
+          ++w;
+        }
+        w = (size_t)urp[r];
+        for (auto &e : bu) {
+          ucol[w] = e.first;
+          usrc[4 * w + 0] = a0 + e.second; usrc[4 * w + 1] = a0 + e.second + 1;
+          usrc[4 * w + 2] = a1 + e.second; usrc[4 * w + 3] = a1 + e.second + 1;
+          ++w;
+        }
+      }
+    }
+    // node-colour boundaries in node rows
+    std::vector<int> ncuts, cstart(n_colors + 1, nn);
+    for (int r = nn - 1; r >= 0; --r) cstart[pcolor[2 * r]] = r;
+    for (int c = 1; c < n_colors; ++c) ncuts.push_back(cstart[c]);
+    ncuts.push_back(nn);
+    std::vector<int> lb, ub;
+    if (build_rowblocks(lrp.data(), nullptr, nn, kBlkMax, &ncuts, lb) &&
+        build_rowblocks(urp.data(), nullptr, nn, kBlkMax, &ncuts, ub)) {
+      auto first_block_of = [&](const std::vector<int> &blk, std::vector<int> &out) {
+        out.assign(n_colors + 1, 0);
+        size_t b = 0;
+        for (int c = 0; c <= n_colors; ++c) {
+          const int row = c < n_colors ? cstart[c] : nn;
+          while (b + 1 < blk.size() && blk[b] < row) ++b;
+          out[c] = (int)b;
+        }
+      };
+      first_block_of(lb, LB);
+      first_block_of(ub, UB);
+      auto make_desc = [](const std::vector<int> &blk, const std::vector<int> &rp_) {
+        std::vector<int4> d(blk.size() - 1);
+        for (size_t b = 0; b + 1 < blk.size(); ++b) d[b] = make_int4(blk[b], blk[b + 1], rp_[blk[b]], rp_[blk[b + 1]]);
+        return d;
+      };
+      Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Ldesc.upload(make_desc(lb, lrp), s);
+      Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Udesc.upload(make_desc(ub, urp), s);
+      permn.upload(hpermn, s);
+      intra_src.upload(isrc, s);
+      Lval.alloc((size_t)nnzL);
+      Uval.alloc((size_t)nnzU);
+      intra.alloc((size_t)nn * 4);
+      ctx->sync();
+      block2_ready = true;
+    }
+  }
+  if (!perm.empty() && !block2) {
     // strict-lower / strict-upper CSR halves with every colour a contiguous run of rows
     std::vector<int> lrp(n + 1, 0), urp(n + 1, 0);
     for (int i = 0; i < n; ++i) {
@@ -269,6 +408,12 @@ void TriSolve::numeric(const double *a_val_dev) {
       else ilu0_factor_level(s, st.nrows, lvlL_rows.p + st.row_off, rowptr.p, diag.p, col.p, val.p, max_row_nnz);
     }
   }
+  if (block2_ready) {
+    vec_gather(s, (int)nnzL, Lsrc.p, val.p, Lval.p);
+    vec_gather(s, (int)nnzU, Usrc.p, val.p, Uval.p);
+    vec_gather(s, 2 * n, intra_src.p, val.p, intra.p);   // per node: l10, u01, d0, d1
+    invert_node_diagonals(s, n / 2, intra.p);            // d0, d1 -> 1/d0, 1/d1
+  }
   if (stream_ready) {
     vec_gather(s, (int)nnzL, Lsrc.p, val.p, Lval.p);
     vec_gather(s, (int)nnzU, Usrc.p, val.p, Uval.p);
@@ -279,6 +424,14 @@ void TriSolve::numeric(const double *a_val_dev) {
 
 void TriSolve::apply(const double *b, double *x) {
   hipStream_t s = ctx->stream;
+  if (block2_ready && use_stream) {
+    const TriBlk L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
+    for (int c = 0; c < n_colors; ++c) tri_blk_level(s, L, LB[c], LB[c + 1], 1, kind, intra.p, permn.p, b, x);
+    for (int c = n_colors - 1; c >= 0; --c) tri_blk_level(s, U, UB[c], UB[c + 1], 0, kind, intra.p, permn.p, nullptr, x);
+    ++ctx->st.tri_applies;
+    ctx->st.tri_bytes += (double)apply_bytes();
+    return;
+  }
   if (stream_ready && use_stream) {
     const TriHalf L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
     if (x_layout == 0) {

@@ -47,10 +47,16 @@ struct TriSolve {
   DBuf<double> Lval, Uval, dinv;
   std::vector<int> LB, UB;  // per colour: first workgroup of that colour in Lblk / Ublk (n_colors + 1)
   int64_t nnzL = 0, nnzU = 0;
+  // 2x2 node-block variant (velocity block): node rows in node-colour order, blocks in L*/U* above,
+  // per node row {l10, u01, 1/d0, 1/d1} in `intra`
+  bool block2_ready = false;
+  DBuf<int> permn, intra_src;
+  DBuf<double> intra;
 
   // A: host pattern of the local block (columns >= A.n_rows, i.e. ghosts, are dropped);
   // sub_off: optional n_sub+1 offsets of emulated MPI ranks inside this GPU (block Jacobi)
-  void analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off);
+  void analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off,
+               bool want_block2 = false);
   void numeric(const double *a_val_dev);           // refresh values (+ factorise for ILU)
   void apply(const double *b, double *x);          // x = M^{-1} b, caller's ordering
   TriView view() const { return TriView{n, rowptr.p, diag.p, col.p, val.p, perm.empty() ? nullptr : d_perm.p}; }

@@ -50,7 +50,7 @@ def test_fgmres_asimple_residual_is_the_true_residual(big):
     pr, ls, S = big
     ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
     st = ls.stats()
-    assert 30 <= st["n_colors_u"] <= 40 and st["nnz_s"] > 1.2e8
+    assert 14 <= st["n_colors_u"] <= 40 and st["nnz_s"] > 1.2e8   # 17 node colours (2x2 blocks) or 36 DoF colours
     b = np.concatenate([pr.rhs_u, pr.rhs_p])
     r0 = np.linalg.norm(b)                              # x0 = 0 on free rows; Dirichlet values are 0 here
     xu, xp, its, res, rc = ls.solve(S.FGMRES, 0.0, 3, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
