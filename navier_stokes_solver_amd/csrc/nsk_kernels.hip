@@ -102,23 +102,54 @@ __global__ __launch_bounds__(BLK) void spmv2_kernel(CsrView A, const double *__r
 // with RG lanes.  HBM sees one coalesced pass over the matrix.
 constexpr int RG = 4;  // lanes cooperating on one row in the reduce phase
 
+// NOTE on the shape of these loops: hipcc does not unroll a `for (k = k0 + tid; k < k1; k += BLK)` loop whose
+// body is load -> dependent gather -> LDS store; it then waits for every load before issuing the next one,
+// i.e. up to 8 x 2 serialised memory round trips per thread.  A run never exceeds kStreamNnz = 8 * BLK
+// entries, so the loops below are written with a fixed trip count in three stages — all index/value loads,
+// then all gathers, then the LDS stores — which keeps 16 + 8 loads in flight per thread.
 template <int VEC>
 __device__ __forceinline__ void stream_products(const int *__restrict__ col, const double *__restrict__ val, int k0,
                                                 int k1, int n_own, const double *__restrict__ xo,
                                                 const double *__restrict__ xg, double *prod) {
   if (VEC == 2) {
-    for (int k = k0 + 2 * (int)threadIdx.x; k < k1; k += 2 * BLK) {
-      const int2 c = *reinterpret_cast<const int2 *>(col + k);
-      const double2 v = *reinterpret_cast<const double2 *>(val + k);
-      const double x0 = c.x < n_own ? xo[c.x] : xg[c.x - n_own];
-      const double x1 = c.y < n_own ? xo[c.y] : xg[c.y - n_own];
-      prod[k - k0] = v.x * x0;
-      prod[k - k0 + 1] = v.y * x1;
+    constexpr int U = kStreamNnz / (2 * BLK);
+    int2 c[U];
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 2 * ((int)threadIdx.x + u * BLK);
+      const bool ok = k < k1;
+      c[u] = ok ? *reinterpret_cast<const int2 *>(col + k) : make_int2(0, 0);
+      v[u] = ok ? *reinterpret_cast<const double2 *>(val + k) : make_double2(0.0, 0.0);
+    }
+    double x0[U], x1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      x0[u] = *(c[u].x < n_own ? xo + c[u].x : xg + (c[u].x - n_own));
+      x1[u] = *(c[u].y < n_own ? xo + c[u].y : xg + (c[u].y - n_own));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 2 * ((int)threadIdx.x + u * BLK);
+      if (k < k1) { prod[k - k0] = v[u].x * x0[u]; prod[k - k0 + 1] = v[u].y * x1[u]; }
     }
   } else {
-    for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK) {
-      const int c = col[k];
-      prod[k - k0] = val[k] * (c < n_own ? xo[c] : xg[c - n_own]);
+    constexpr int U = kStreamNnz / BLK;
+    int c[U];
+    double v[U], xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      const bool ok = k < k1;
+      c[u] = ok ? col[k] : 0;
+      v[u] = ok ? val[k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[u] = *(c[u] < n_own ? xo + c[u] : xg + (c[u] - n_own));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      if (k < k1) prod[k - k0] = v[u] * xv[u];
     }
   }
 }
@@ -196,34 +227,43 @@ __global__ __launch_bounds__(BLK) void spmv2_stream_kernel(CsrView A, const doub
 template <int R, int C>
 __device__ __forceinline__ void blk_products(const BlkView &A, int k0, int k1, const double *__restrict__ xo,
                                              const double *__restrict__ xg, double *p0, double *p1) {
-  for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK) {
-    const int m = __builtin_nontemporal_load(A.col + k);
-    double x0, x1 = 0.0;
+  constexpr int U = kBlkMax / BLK;  // staged like stream_products: loads, gathers, LDS stores
+  int m[U];
+  double2 a0[U], a1[U];
+  double x0[U], x1[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k = k0 + (int)threadIdx.x + u * BLK;
+    const bool ok = k < k1;
+    m[u] = ok ? __builtin_nontemporal_load(A.col + k) : 0;
+    const double *v = A.val + (size_t)(R * C) * (ok ? k : k0);
+    if (R * C == 4) { a0[u] = *reinterpret_cast<const double2 *>(v); a1[u] = *reinterpret_cast<const double2 *>(v + 2); }
+    else if (R * C == 2) { a0[u] = *reinterpret_cast<const double2 *>(v); a1[u] = make_double2(0.0, 0.0); }
+    else { a0[u] = make_double2(v[0], 0.0); a1[u] = make_double2(0.0, 0.0); }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    x1[u] = 0.0;
     if (C == 2) {
-      if (m < A.n_own_bcols) {
-        const double2 xv = *reinterpret_cast<const double2 *>(xo + 2 * (size_t)m);
-        x0 = xv.x; x1 = xv.y;
+      if (m[u] < A.n_own_bcols) {
+        const double2 xv = *reinterpret_cast<const double2 *>(xo + 2 * (size_t)m[u]);
+        x0[u] = xv.x; x1[u] = xv.y;
       } else {
-        const size_t g = 2 * (size_t)(m - A.n_own_bcols);  // the ghost tail may be only 8-byte aligned
-        x0 = xg[g]; x1 = xg[g + 1];
+        const size_t g = 2 * (size_t)(m[u] - A.n_own_bcols);  // the ghost tail may be only 8-byte aligned
+        x0[u] = xg[g]; x1[u] = xg[g + 1];
       }
     } else {
-      x0 = m < A.n_own_bcols ? xo[m] : xg[m - A.n_own_bcols];
+      x0[u] = *(m[u] < A.n_own_bcols ? xo + m[u] : xg + (m[u] - A.n_own_bcols));
     }
-    const double *v = A.val + (size_t)(R * C) * k;
-    if (R == 2 && C == 2) {
-      const double2 a0 = *reinterpret_cast<const double2 *>(v), a1 = *reinterpret_cast<const double2 *>(v + 2);
-      p0[k - k0] = a0.x * x0 + a0.y * x1;
-      p1[k - k0] = a1.x * x0 + a1.y * x1;
-    } else if (R == 2 && C == 1) {
-      const double2 a = *reinterpret_cast<const double2 *>(v);
-      p0[k - k0] = a.x * x0;
-      p1[k - k0] = a.y * x0;
-    } else if (R == 1 && C == 2) {
-      const double2 a = *reinterpret_cast<const double2 *>(v);
-      p0[k - k0] = a.x * x0 + a.y * x1;
-    } else {
-      p0[k - k0] = v[0] * x0;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int k = k0 + (int)threadIdx.x + u * BLK;
+    if (k < k1) {
+      if (R == 2 && C == 2) { p0[k - k0] = a0[u].x * x0[u] + a0[u].y * x1[u]; p1[k - k0] = a1[u].x * x0[u] + a1[u].y * x1[u]; }
+      else if (R == 2 && C == 1) { p0[k - k0] = a0[u].x * x0[u]; p1[k - k0] = a0[u].y * x0[u]; }
+      else if (R == 1 && C == 2) p0[k - k0] = a0[u].x * x0[u] + a0[u].y * x1[u];
+      else p0[k - k0] = a0[u].x * x0[u];
     }
   }
 }
@@ -312,8 +352,25 @@ __global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int 
   }
   // the factor is streamed once per apply: non-temporal loads keep it from evicting the lines the
   // gathers want to find in L2 again
-  for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK)
-    prod[k - k0] = __builtin_nontemporal_load(M.val + k) * w[__builtin_nontemporal_load(M.col + k)];
+  {
+    constexpr int U = kStreamNnz / BLK;  // staged: see stream_products
+    int c[U];
+    double v[U], g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      const bool ok = k < k1;
+      c[u] = ok ? __builtin_nontemporal_load(M.col + k) : 0;
+      v[u] = ok ? __builtin_nontemporal_load(M.val + k) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) g[u] = w[c[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      if (k < k1) prod[k - k0] = v[u] * g[u];
+    }
+  }
   __syncthreads();
   const double sum = row_sum_lds(prod, jb, je, lane);
   if (have && lane == 0) {
@@ -349,13 +406,29 @@ __global__ __launch_bounds__(BLK) void tri_blk_kernel(TriBlk M, int b0, int nb, 
     cf = *reinterpret_cast<const double2 *>(intra + 4 * (size_t)r);       // l10, u01
     di = *reinterpret_cast<const double2 *>(intra + 4 * (size_t)r + 2);   // 1/d0, 1/d1
   }
-  for (int k = k0 + (int)threadIdx.x; k < k1; k += BLK) {
-    const int m = __builtin_nontemporal_load(M.col + k);
-    const double2 xv = *reinterpret_cast<const double2 *>(x + 2 * (size_t)m);
-    const double2 a0 = *reinterpret_cast<const double2 *>(M.val + 4 * (size_t)k);
-    const double2 a1 = *reinterpret_cast<const double2 *>(M.val + 4 * (size_t)k + 2);
-    p0[k - k0] = a0.x * xv.x + a0.y * xv.y;
-    p1[k - k0] = a1.x * xv.x + a1.y * xv.y;
+  {
+    constexpr int U = kBlkMax / BLK;  // staged: see stream_products
+    int m[U];
+    double2 a0[U], a1[U], xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      const bool ok = k < k1;
+      m[u] = ok ? __builtin_nontemporal_load(M.col + k) : 0;
+      const double *v = M.val + 4 * (size_t)(ok ? k : k0);
+      a0[u] = *reinterpret_cast<const double2 *>(v);
+      a1[u] = *reinterpret_cast<const double2 *>(v + 2);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const double2 *>(x + 2 * (size_t)m[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      if (k < k1) {
+        p0[k - k0] = a0[u].x * xv[u].x + a0[u].y * xv[u].y;
+        p1[k - k0] = a1[u].x * xv[u].x + a1[u].y * xv[u].y;
+      }
+    }
   }
   __syncthreads();
   double s0 = 0.0, s1 = 0.0;
