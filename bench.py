@@ -182,10 +182,10 @@ def main():
 
     if rank == 0:
         value = n_global * args.steps / dt
-        names = {0: "spmv_stream_kernel<2,0>: SpMV with F (inner FGMRES)",
+        names = {0: "spmv_blk_kernel<2,2>: SpMV with F (inner FGMRES), 2x2 node blocks",
                  3: "spmv_stream_kernel<1,0>: SpMV with Mp (inner CG)", 5: "spmv_stream_kernel<1,0>: SpMV with S (inner CG)",
-                 20: "tri_stream_kernel: ILU(0)/SGS apply on F (all level launches of one apply)",
-                 21: "tri_stream_kernel: ILU(0)/SGS apply on the pressure block (all level launches of one apply)"}
+                 20: "tri_blk_kernel: ILU(0)/SGS apply on F (17+17 node-colour level launches of one apply)",
+                 21: "tri_stream_kernel: ILU(0)/SGS apply on the pressure block (31+31 level launches of one apply)"}
         klass = {}
         for op, (ms, cnt, by, ncalls) in prof.items():
             klass[op] = dict(kernel=names[op], avg_ms=ms, launches_sampled=cnt, calls=ncalls, bytes_per_launch=by,
@@ -194,16 +194,15 @@ def main():
         dom = max(klass, key=lambda o: klass[o]["time_share"])
         k_ms, k_n, k_bytes, achieved = (klass[dom]["avg_ms"], klass[dom]["launches_sampled"],
                                         klass[dom]["bytes_per_launch"], klass[dom]["achieved"])
+        # HBM traffic of the dominant class from the committed PMC passes (rocprofv3 --pmc cannot run inside
+        # this process); only quoted when it was measured on this very workload
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_1200x400.json")
         if (nx, ny, world) == (1200, 400, 1) and os.path.exists(pmc):
-            kk = json.load(open(pmc))["kernels"]
-            if dom == 0 and "spmv_stream_kernel<2,0> on F" in kk:
-                traffic = kk["spmv_stream_kernel<2,0> on F"]["traffic_bytes_corrected"]
-            if dom == 20 and "ILU(F) apply, lower levels (36 launches)" in kk:
-                traffic = (kk["ILU(F) apply, lower levels (36 launches)"]["traffic_bytes_corrected_per_apply"] +
-                           kk["ILU(F) apply, upper levels (36 launches)"]["traffic_bytes_corrected_per_apply"])
-            traffic_src = "profiles/r01_pmc_traffic_1200x400.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None
+            kk = json.load(open(pmc)).get("by_op", {})
+            if str(dom) in kk:
+                traffic = kk[str(dom)]["traffic_bytes_corrected"]
+                traffic_src = "profiles/r01_pmc_traffic_1200x400.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
         out = {
             "metric": f"DoF*iters/s ({['GMRES', 'FGMRES', 'Bicgstab'][args.solver]}+"
                       f"{['blockDiagonal', 'blockTriangular', 'aSIMPLE'][args.preconditioner]}, Re={args.reynolds:g})",

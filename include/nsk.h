@@ -65,6 +65,7 @@ enum {
                                  (two sweeps, 8 vectors per pass); 0: deal.II's modified Gram-Schmidt (add_and_dot) */
   NSK_OPT_OUTER_FUSED_GS = 5, /* same for the outer FGMRES; default 0 (modified Gram-Schmidt, as deal.II) */
   NSK_OPT_BSR_VELOCITY = 7,   /* 1 (default): SpMVs with the jacobian blocks use 2x2 / 2x1 / 1x2 node-block copies when the pattern allows */
+  NSK_OPT_TRI_RUN_NNZ = 8,    /* non-zeros per workgroup in the scalar streamed triangular levels: 512, 1024, 2048 (default) */
   NSK_OPT_TRI_X_LAYOUT = 6    /* multicolour triangular solves: 0 (default) work in the caller's DoF order,
                                  1 work on an internal colour-ordered vector */
 };

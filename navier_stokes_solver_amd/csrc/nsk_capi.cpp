@@ -570,6 +570,10 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
     case NSK_OPT_SUBDOMAINS: h->subdomains = std::max(1, (int)v); break;
     case NSK_OPT_FUSE_BLOCK_ROW: h->fuse_block_row = v != 0.0; break;
     case NSK_OPT_STREAM_KERNELS: h->use_stream = v != 0.0; h->tF.use_stream = h->tMp.use_stream = h->tS.use_stream = h->use_stream; break;
+    case NSK_OPT_TRI_RUN_NNZ:
+      h->tF.run_nnz = h->tMp.run_nnz = h->tS.run_nnz = v <= 512 ? 512 : (v <= 1024 ? 1024 : 2048);
+      h->tF_ok = h->tMp_ok = h->tS_ok = false;
+      break;
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
     case NSK_OPT_TRI_X_LAYOUT:
       h->tF.x_layout = h->tMp.x_layout = h->tS.x_layout = v != 0.0;

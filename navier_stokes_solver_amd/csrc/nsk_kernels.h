@@ -140,7 +140,8 @@ struct TriHalf {
 };
 // permx = 1: w is an internal colour-ordered vector and M.col holds colour-order ids; the lower solve gathers
 // rhs through perm, the upper solve also scatters its result to out[perm[r]].
-void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx,
+// run_nnz: the non-zero cap the row runs in M.desc were built with (512, 1024 or 2048)
+void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx, int run_nnz,
                       const double *dinv, const int *perm, const double *rhs, double *w, double *out);
 
 // 2x2 node-block variant of the streamed level: node rows (two adjacent DoF rows) in node-colour order,

@@ -324,12 +324,12 @@ __global__ __launch_bounds__(BLK) void spmv_blk_fused_kernel(BlkView A, const do
 //            solve gathers rhs through perm and the upper solve scatters the result to `out`.  A level
 //            then only touches the segments of the colours it depends on (fewer bytes per level), at
 //            the price of one cache line per gathered entry.
-template <int LOWER, int KIND, int PERMX>
+template <int LOWER, int KIND, int PERMX, int NNZ>
 __global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int nb, const double *__restrict__ dinv,
                                                          const int *__restrict__ perm,
                                                          const double *__restrict__ rhs, double *__restrict__ w,
                                                          double *__restrict__ out) {
-  __shared__ double prod[kStreamNnz];
+  __shared__ double prod[NNZ];
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the k-th
   // contiguous eighth of the level's row runs.  Neighbouring rows then share one L2, and the same
   // slice of x is touched by the same XCD level after level (speed only, never correctness).
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int 
   // the factor is streamed once per apply: non-temporal loads keep it from evicting the lines the
   // gathers want to find in L2 again
   {
-    constexpr int U = kStreamNnz / BLK;  // staged: see stream_products
+    constexpr int U = NNZ / BLK;  // staged: see stream_products
     int c[U];
     double v[U], g[U];
 #pragma unroll
@@ -803,19 +803,26 @@ void spmv_blk_fused22_21(hipStream_t s, const BlkView &A, const double *xao, con
     hipLaunchKernelGGL(spmv_blk_fused_kernel, dim3(nblk), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, rowblk, y);
 }
 
-void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx,
+void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx, int run_nnz,
                       const double *dinv, const int *perm, const double *rhs, double *w, double *out) {
   const int nb = b1 - b0;
   if (nb <= 0) return;
   const int grid = ((nb + 7) / 8) * 8;
-#define NSK_TS(L, K, P) hipLaunchKernelGGL((tri_stream_kernel<L, K, P>), dim3(grid), dim3(BLK), 0, s, M, b0, nb, dinv, perm, rhs, w, out)
+#define NSK_TS(L, K, P, N) hipLaunchKernelGGL((tri_stream_kernel<L, K, P, N>), dim3(grid), dim3(BLK), 0, s, M, b0, nb, dinv, perm, rhs, w, out)
+#define NSK_TSN(L, K, P)                                            \
+  do {                                                              \
+    if (run_nnz <= 512) NSK_TS(L, K, P, 512);                       \
+    else if (run_nnz <= 1024) NSK_TS(L, K, P, 1024);                \
+    else NSK_TS(L, K, P, 2048);                                     \
+  } while (0)
   if (permx) {
-    if (lower) { if (kind == 0) NSK_TS(1, 0, 1); else NSK_TS(1, 1, 1); }
-    else { if (kind == 0) NSK_TS(0, 0, 1); else NSK_TS(0, 1, 1); }
+    if (lower) { if (kind == 0) NSK_TSN(1, 0, 1); else NSK_TSN(1, 1, 1); }
+    else { if (kind == 0) NSK_TSN(0, 0, 1); else NSK_TSN(0, 1, 1); }
   } else {
-    if (lower) { if (kind == 0) NSK_TS(1, 0, 0); else NSK_TS(1, 1, 0); }
-    else { if (kind == 0) NSK_TS(0, 0, 0); else NSK_TS(0, 1, 0); }
+    if (lower) { if (kind == 0) NSK_TSN(1, 0, 0); else NSK_TSN(1, 1, 0); }
+    else { if (kind == 0) NSK_TSN(0, 0, 0); else NSK_TSN(0, 1, 0); }
   }
+#undef NSK_TSN
 #undef NSK_TS
 }
 

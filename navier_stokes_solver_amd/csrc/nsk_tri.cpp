@@ -358,8 +358,8 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     }
     std::vector<int> cuts(hLp.begin() + 1, hLp.end());  // colour boundaries (levL = colour, rows ascending)
     std::vector<int> lb, ub;
-    if (build_rowblocks(lrp.data(), nullptr, n, kStreamNnz, &cuts, lb) &&
-        build_rowblocks(urp.data(), nullptr, n, kStreamNnz, &cuts, ub)) {
+    if (build_rowblocks(lrp.data(), nullptr, n, run_nnz, &cuts, lb) &&
+        build_rowblocks(urp.data(), nullptr, n, run_nnz, &cuts, ub)) {
       auto first_block_of = [&](const std::vector<int> &blk, std::vector<int> &out) {
         out.assign(n_colors + 1, 0);
         size_t b = 0;
@@ -436,11 +436,11 @@ void TriSolve::apply(const double *b, double *x) {
     const TriHalf L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
     if (x_layout == 0) {
       // x doubles as the intermediate vector: rows not yet solved hold L^-1 b, solved rows hold the result
-      for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, 0, dinv.p, d_perm.p, b, x, nullptr);
-      for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, 0, dinv.p, d_perm.p, nullptr, x, nullptr);
+      for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, 0, run_nnz, dinv.p, d_perm.p, b, x, nullptr);
+      for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, 0, run_nnz, dinv.p, d_perm.p, nullptr, x, nullptr);
     } else {
-      for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, 1, dinv.p, d_perm.p, b, y.p, nullptr);
-      for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, 1, dinv.p, d_perm.p, nullptr, y.p, x);
+      for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, 1, run_nnz, dinv.p, d_perm.p, b, y.p, nullptr);
+      for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, 1, run_nnz, dinv.p, d_perm.p, nullptr, y.p, x);
     }
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
