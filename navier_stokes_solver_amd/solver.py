@@ -65,6 +65,13 @@ def lib() -> C.CDLL:
         path = library_path()
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing — the HIP extension is required (run __graft_entry__.build())")
+        try:
+            # PyTorch bundles its own libamdhip64.so.7 / librccl.so.1.  Whichever copy is loaded first serves the
+            # whole process (same SONAMEs); loading the system copies first and torch afterwards aborts at
+            # interpreter exit (double free in the second ROCm stack's static destructors), so torch goes first.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path, mode=C.RTLD_GLOBAL)
         vp, i32p, f64p = C.c_void_p, C.c_void_p, C.c_void_p
         L.nsk_get_unique_id.argtypes = [vp]
