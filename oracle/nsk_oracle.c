@@ -10,6 +10,20 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Threads for the timed CPU baseline only (orc_set_threads): rows of SpMV / vector ops are split
+ * statically, reductions are summed per thread and then in thread order, and the triangular
+ * preconditioners run one emulated MPI rank (shard) per thread — the reference's own parallel model
+ * (block-Jacobi ILU, Ifpack overlap 0).  With one thread (the default, used by every parity test and
+ * golden fixture) every loop below runs in its original serial order. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
+int orc_get_threads(void) { return g_threads; }
+#define ORC_CHUNK(n, t, T, lo, hi) \
+  const long lo = (long)(n) * (t) / (T), hi = (long)(n) * ((t) + 1) / (T)
 
 static double now_s(void) {
   struct timespec ts;
@@ -20,6 +34,7 @@ static double now_s(void) {
 /* ------------------------------------------------------------------ BLAS-1 / SpMV
  * TrilinosWrappers::MPI::Vector ops used by the path. */
 void orc_spmv(const orc_csr *A, const double *x, double *y, int add) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
   for (int i = 0; i < A->n_rows; ++i) {
     double s = 0.0;
     for (int k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) s += A->val[k] * x[A->col[k]];
@@ -27,15 +42,41 @@ void orc_spmv(const orc_csr *A, const double *x, double *y, int add) {
   }
 }
 double orc_dot(int n, const double *x, const double *y) {
+  if (g_threads <= 1) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += x[i] * y[i];
+    return s;
+  }
+  double part[256];
+  const int T = g_threads;
+#pragma omp parallel num_threads(T)
+  {
+#ifdef _OPENMP
+    const int t = omp_get_thread_num();
+#else
+    const int t = 0;
+#endif
+    ORC_CHUNK(n, t, T, lo, hi);
+    double s = 0.0;
+    for (long i = lo; i < hi; ++i) s += x[i] * y[i];
+    part[t] = s;
+  }
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += x[i] * y[i];
+  for (int t = 0; t < T; ++t) s += part[t];
   return s;
 }
 double orc_norm2(int n, const double *x) { return sqrt(orc_dot(n, x, x)); }
-static void v_axpy(int n, double a, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] += a * x[i]; }
-static void v_equ(int n, double a, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = a * x[i]; }
+static void v_axpy(int n, double a, const double *x, double *y) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+  for (int i = 0; i < n; ++i) y[i] += a * x[i];
+}
+static void v_equ(int n, double a, const double *x, double *y) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+  for (int i = 0; i < n; ++i) y[i] = a * x[i];
+}
 /* this = s*this + a*V  (Vector::sadd) */
 static void v_sadd(int n, double s, double a, const double *v, double *self) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
   for (int i = 0; i < n; ++i) self[i] = s * self[i] + a * v[i];
 }
 /* add_and_dot(a, V, W): this += a V; return this . W   (two passes for Trilinos vectors) */
@@ -72,6 +113,8 @@ struct orc_tri {
   double *val;              /* ILU: L (unit, strict lower) and U in place; SGS: matrix values */
   int *perm;                /* perm[new] = old, or NULL */
   double *wb, *wx;          /* permuted work vectors */
+  int n_shards;             /* shards are independent diagonal blocks (natural order only): threaded apply */
+  int *shard_off;
 };
 
 static int cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
@@ -138,28 +181,71 @@ orc_tri *orc_tri_setup(const orc_csr *A, int kind, int n_shards, const int *shar
   (void)idx; (void)cmp_int;
   free(key); free(idx); free(shard); free(iperm);
   if (kind == 0) {
-    /* ILU(0), IKJ form (Ifpack_ILU, level of fill 0, athresh 0, rthresh 1, relax 0) */
-    int *pos = (int *)malloc(sizeof(int) * (size_t)n);
-    for (int i = 0; i < n; ++i) pos[i] = -1;
-    for (int i = 0; i < n; ++i) {
-      for (int k = T->rowptr[i]; k < T->rowptr[i + 1]; ++k) pos[T->col[k]] = k;
-      for (int k = T->rowptr[i]; k < T->rowptr[i + 1]; ++k) {
-        const int c = T->col[k];
-        if (c >= i) break;
-        const double l = T->val[k] / T->val[T->diag[c]];
-        T->val[k] = l;
-        for (int m = T->diag[c] + 1; m < T->rowptr[c + 1]; ++m) {
-          const int p = pos[T->col[m]];
-          if (p >= 0) T->val[p] -= l * T->val[m];
+    /* ILU(0), IKJ form (Ifpack_ILU, level of fill 0, athresh 0, rthresh 1, relax 0).  Without a
+       permutation the shards are contiguous independent blocks: one thread each in the timed baseline. */
+    const int ns = (!perm && n_shards > 1 && shard_off && g_threads > 1) ? n_shards : 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads) if (ns > 1)
+    for (int sh = 0; sh < ns; ++sh) {
+      const int lo = ns > 1 ? shard_off[sh] : 0, hi = ns > 1 ? shard_off[sh + 1] : n;
+      int *pos = (int *)malloc(sizeof(int) * (size_t)n);
+      for (int i = lo; i < hi; ++i)
+        for (int k = T->rowptr[i]; k < T->rowptr[i + 1]; ++k) pos[T->col[k]] = -1;
+      for (int i = lo; i < hi; ++i) {
+        for (int k = T->rowptr[i]; k < T->rowptr[i + 1]; ++k) pos[T->col[k]] = k;
+        for (int k = T->rowptr[i]; k < T->rowptr[i + 1]; ++k) {
+          const int c = T->col[k];
+          if (c >= i) break;
+          const double l = T->val[k] / T->val[T->diag[c]];
+          T->val[k] = l;
+          for (int m = T->diag[c] + 1; m < T->rowptr[c + 1]; ++m) {
+            const int p = pos[T->col[m]];
+            if (p >= 0) T->val[p] -= l * T->val[m];
+          }
         }
+        for (int k = T->rowptr[i]; k < T->rowptr[i + 1]; ++k) pos[T->col[k]] = -1;
       }
-      for (int k = T->rowptr[i]; k < T->rowptr[i + 1]; ++k) pos[T->col[k]] = -1;
+      free(pos);
     }
-    free(pos);
   }
   T->wb = (double *)malloc(sizeof(double) * (size_t)n);
   T->wx = (double *)malloc(sizeof(double) * (size_t)n);
+  T->n_shards = 1;
+  T->shard_off = NULL;
+  if (!perm && n_shards > 1 && shard_off) {
+    T->n_shards = n_shards;
+    T->shard_off = (int *)malloc(sizeof(int) * ((size_t)n_shards + 1));
+    memcpy(T->shard_off, shard_off, sizeof(int) * ((size_t)n_shards + 1));
+  }
   return T;
+}
+
+static void tri_apply_range(const orc_tri *T, const double *bb, double *y, int lo, int hi) {
+  if (T->kind == 0) {
+    /* L y = b (unit lower), U x = y */
+    for (int i = lo; i < hi; ++i) {
+      double s = bb[i];
+      for (int k = T->rowptr[i]; k < T->diag[i]; ++k) s -= T->val[k] * y[T->col[k]];
+      y[i] = s;
+    }
+    for (int i = hi - 1; i >= lo; --i) {
+      double s = y[i];
+      for (int k = T->diag[i] + 1; k < T->rowptr[i + 1]; ++k) s -= T->val[k] * y[T->col[k]];
+      y[i] = s / T->val[T->diag[i]];
+    }
+  } else {
+    /* Ifpack point relaxation, symmetric Gauss-Seidel, one sweep, zero start, omega 1:
+       (D+L) y = b ; (D+U) x = D y */
+    for (int i = lo; i < hi; ++i) {
+      double s = bb[i];
+      for (int k = T->rowptr[i]; k < T->diag[i]; ++k) s -= T->val[k] * y[T->col[k]];
+      y[i] = s / T->val[T->diag[i]];
+    }
+    for (int i = hi - 1; i >= lo; --i) {
+      double s = 0.0;
+      for (int k = T->diag[i] + 1; k < T->rowptr[i + 1]; ++k) s += T->val[k] * y[T->col[k]];
+      y[i] = y[i] - s / T->val[T->diag[i]];
+    }
+  }
 }
 
 void orc_tri_apply(const orc_tri *T, const double *b, double *x) {
@@ -170,31 +256,12 @@ void orc_tri_apply(const orc_tri *T, const double *b, double *x) {
     for (int i = 0; i < n; ++i) T->wb[i] = b[T->perm[i]];
     bb = T->wb;
   }
-  if (T->kind == 0) {
-    /* L y = b (unit lower), U x = y */
-    for (int i = 0; i < n; ++i) {
-      double s = bb[i];
-      for (int k = T->rowptr[i]; k < T->diag[i]; ++k) s -= T->val[k] * y[T->col[k]];
-      y[i] = s;
-    }
-    for (int i = n - 1; i >= 0; --i) {
-      double s = y[i];
-      for (int k = T->diag[i] + 1; k < T->rowptr[i + 1]; ++k) s -= T->val[k] * y[T->col[k]];
-      y[i] = s / T->val[T->diag[i]];
-    }
+  if (T->n_shards > 1 && g_threads > 1) {
+    /* independent diagonal blocks (couplings across shards were dropped at setup) */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+    for (int sh = 0; sh < T->n_shards; ++sh) tri_apply_range(T, bb, y, T->shard_off[sh], T->shard_off[sh + 1]);
   } else {
-    /* Ifpack point relaxation, symmetric Gauss-Seidel, one sweep, zero start, omega 1:
-       (D+L) y = b ; (D+U) x = D y */
-    for (int i = 0; i < n; ++i) {
-      double s = bb[i];
-      for (int k = T->rowptr[i]; k < T->diag[i]; ++k) s -= T->val[k] * y[T->col[k]];
-      y[i] = s / T->val[T->diag[i]];
-    }
-    for (int i = n - 1; i >= 0; --i) {
-      double s = 0.0;
-      for (int k = T->diag[i] + 1; k < T->rowptr[i + 1]; ++k) s += T->val[k] * y[T->col[k]];
-      y[i] = y[i] - s / T->val[T->diag[i]];
-    }
+    tri_apply_range(T, bb, y, 0, n);
   }
   if (T->perm) for (int i = 0; i < n; ++i) x[T->perm[i]] = y[i];
   else memcpy(x, y, sizeof(double) * (size_t)n);
@@ -202,7 +269,7 @@ void orc_tri_apply(const orc_tri *T, const double *b, double *x) {
 
 void orc_tri_free(orc_tri *T) {
   if (!T) return;
-  free(T->rowptr); free(T->col); free(T->diag); free(T->val); free(T->perm); free(T->wb); free(T->wx);
+  free(T->rowptr); free(T->col); free(T->diag); free(T->val); free(T->perm); free(T->wb); free(T->wx); free(T->shard_off);
   free(T);
 }
 int orc_tri_nnz(const orc_tri *T) { return T->rowptr[T->n]; }

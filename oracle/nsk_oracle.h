@@ -33,6 +33,10 @@ typedef struct {
   const double *val;
 } orc_csr;
 
+/* Threads of the timed CPU baseline (default 1 = the serial code every parity test uses). */
+void orc_set_threads(int n);
+int orc_get_threads(void);
+
 /* y = A x  (add != 0: y += A x).  Trilinos SparseMatrix::vmult / vmult_add. */
 void orc_spmv(const orc_csr *A, const double *x, double *y, int add);
 double orc_dot(int n, const double *x, const double *y);

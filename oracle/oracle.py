@@ -49,6 +49,8 @@ def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:
         L = C.CDLL(build())
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_get_threads.restype = C.c_int
         L.orc_spmv.argtypes = [C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_int]
         L.orc_dot.restype = C.c_double
         L.orc_dot.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
@@ -63,6 +65,11 @@ def lib() -> C.CDLL:
         L.orc_prec_apply.argtypes = [C.POINTER(Problem), C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
+
+
+def set_threads(n: int) -> None:
+    """Threads of the timed CPU baseline; 1 (default) is the serial code all parity tests run."""
+    lib().orc_set_threads(int(n))
 
 
 def _i32(a):
