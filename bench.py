@@ -58,7 +58,8 @@ def cpu_baseline(args, nu):
     from navier_stokes_solver_amd import problem as P
     from oracle import oracle as O
     nx, ny = (int(v) for v in args.cpu_mesh.split(","))
-    cores = max(1, min(args.cpu_threads or (os.cpu_count() or 1), nx // 4))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(args.cpu_threads or min(avail, 16), nx // 4))   # a one-GPU box's CPU share is 16 cores
     pr = P.generate(nx, ny, nu=nu, mode=1, state=1)
     ranges = P.generate(nx, ny, nu=nu, mode=1, state=1, nranks=cores, rank=0) if cores > 1 else None
     kw = dict(u_shard_off=ranges.u_ranges, p_shard_off=ranges.p_ranges) if ranges is not None else {}
