@@ -57,7 +57,9 @@ enum { NSK_TRI_VELOCITY = 0, NSK_TRI_PRESSURE = 1 };
 
 /* options (nsk_set_option) */
 enum {
-  NSK_OPT_TRI_ORDERING = 0, /* 0 natural (default), 1 rank-local multicolour permutation */
+  NSK_OPT_TRI_ORDERING = 0, /* 1 (default): rank-local multicolour permutation for ILU(0)/SGS (few, wide levels);
+                               0: the caller's DoF order — exactly what one MPI rank of the reference factorises,
+                               but O(nx+ny) narrow levels */
   NSK_OPT_SUBDOMAINS = 1,   /* emulated MPI ranks per GPU for the block-Jacobi ILU/SGS (default 1) */
   NSK_OPT_FUSE_BLOCK_ROW = 2, /* 1 (default): F x_u + Bt x_p in one kernel */
   NSK_OPT_STREAM_KERNELS = 3, /* 1 (default): LDS-staged CSR-stream kernels; 0: CSR-vector kernels */

@@ -73,7 +73,7 @@ struct nsk_handle_s {
   Csr blk[6];
   VecPool pool_u, pool_p, pool_b;
   bool pools_ready = false;
-  int tri_ordering = ORDER_NATURAL, subdomains = 1, fuse_block_row = 1, use_stream = 1;
+  int tri_ordering = ORDER_MULTICOLOR, subdomains = 1, fuse_block_row = 1, use_stream = 1;
   bool inner_fused_gs = true, outer_fused_gs = false;
   int use_bsr = 1;
   DBuf<int> jrow_blk, jblk_blk;  // row runs of the fused (F | Bt) block row: CSR and blocked variants

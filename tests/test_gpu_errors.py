@@ -45,6 +45,7 @@ def test_solver_status_codes():
     try:
         ls.set_problem(pr)
         ls.setup_preconditioner(S.ASIMPLE, S.UNSTEADY)
+        assert ls.stats()["n_colors_u"] > 0                  # multicolour ordering is the default
         # 1: outer solver out of iterations (the reference would die on an uncaught NoConvergence)
         _, _, its, res, rc = ls.solve(S.FGMRES, 1e-12, 4, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
         assert (rc, its) == (1, 4) and res > 1e-12
