@@ -109,3 +109,36 @@ def test_strip_partition_stitches_to_global(nranks):
         assert len(pr.ghost_u) > 0
         A = to_global(pr, pr.Bt_ghost, "p", glob.n_p)
         assert abs(A - Btg[pr.ghost_u]).max() == 0.0
+
+
+def test_lattice_matches_the_reference_mesh_dump():
+    """tests/golden/reference_mesh_60x40_rank_piece.msh is the reference repo's own `mesh.msh` (data, MSH v1:
+    the rank-local piece `GridOut::write_msh` dumped in a 60x40 run, NSSolverStationary.cpp:108-111): 249 nodes,
+    214 quads.  Every node must sit on the generator's 61x41 vertex lattice and every quad must be one of its
+    kept lattice cells."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_mesh_60x40_rank_piece.msh")
+    lines = open(path).read().split("\n")
+    n_nodes = int(lines[1])
+    nodes = {}
+    for ln in lines[2:2 + n_nodes]:
+        k, x, y, _ = ln.split()
+        nodes[int(k)] = (float(x), float(y))
+    e0 = lines.index("$ELM")
+    n_el = int(lines[e0 + 1])
+    assert (n_nodes, n_el) == (249, 214)
+    nx, ny = 60, 40
+    hx, hy = 2.2 / nx, 0.41 / ny
+    info = P.mesh_info(nx, ny)
+    assert info["n_cells"] == nx * ny - info["n_removed"]
+    for x, y in nodes.values():
+        i, j = x / hx, y / hy
+        assert abs(i - round(i)) < 2e-4 and abs(j - round(j)) < 2e-4 and 0 <= round(i) <= nx and 0 <= round(j) <= ny
+    for ln in lines[e0 + 2:e0 + 2 + n_el]:
+        f = ln.split()
+        assert f[1] == "3" and f[4] == "4"                      # 4-node quadrangle
+        xs = [nodes[int(v)][0] for v in f[5:9]]
+        ys = [nodes[int(v)][1] for v in f[5:9]]
+        assert abs((max(xs) - min(xs)) - hx) < 1e-4 and abs((max(ys) - min(ys)) - hy) < 1e-4   # one lattice cell
+        cx, cy = sum(xs) / 4, sum(ys) / 4
+        assert np.hypot(cx - 0.2, cy - 0.205) >= 0.05           # a kept cell under the centre rule (:43-44)
