@@ -332,3 +332,26 @@ def test_velocity_block_bsr_toggle(bsr):
         assert rel_err(ls.spmv(S.BLK_F, x), 2.5 * O.spmv(O.CsrHolder.from_block(pr.F), x)) <= 1e-13
     finally:
         ls.close()
+
+
+@pytest.mark.parametrize("inner,outer", [(0, 0), (1, 0), (1, 1)])
+def test_gram_schmidt_variants_reach_the_same_solution(inner, outer):
+    """deal.II's modified Gram-Schmidt (add_and_dot) vs the fused classical sweeps: same Arnoldi relation,
+    same solution to solver tolerance, iteration counts within a few percent."""
+    S, O = _S(), _O()
+    pr = problem("ns16")
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr)
+        ls.set_option(S.OPT_INNER_FUSED_GS, inner)
+        ls.set_option(S.OPT_OUTER_FUSED_GS, outer)
+        ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+        xu, xp, its, res, rc = ls.solve(S.FGMRES, 1e-12, 20000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+        assert rc == 0
+        op = O.OracleProblem.from_local(pr, perm_F=ls.tri_perm(S.TRI_VELOCITY), perm_S=ls.tri_perm(S.TRI_PRESSURE))
+        b = np.concatenate([pr.rhs_u, pr.rhs_p])
+        xo, info = op.solve(b, np.concatenate([pr.x0_u, pr.x0_p]), solver=1, prec=2, variant=0, tol=1e-12)
+        assert rel_err(np.concatenate([xu, xp]), xo) <= 1e-7
+        assert abs(its - info["iters"]) <= max(3, 0.2 * info["iters"])
+    finally:
+        ls.close()
