@@ -186,10 +186,21 @@ def main():
         ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
         ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
         torch.cuda.synchronize()
+        import threading
+        done = threading.Event()
+
+        def heartbeat():   # the C call blocks (GIL released): keep the log alive for long solves
+            t_start = time.time()
+            while not done.wait(60.0):
+                print(f"[bench] converging ... {time.time() - t_start:.0f} s", file=sys.stderr, flush=True)
+
+        hb = threading.Thread(target=heartbeat, daemon=True)
+        hb.start()
         t0 = time.perf_counter()
         cits, cres, crc = ls.solve_resident(args.solver, args.converge, 20000 if args.variant == 0 else 100000)
         torch.cuda.synchronize()
         cdt = time.perf_counter() - t0
+        done.set()
         conv = {"tol": args.converge, "iters": cits, "final_res": cres, "status": crc, "seconds": cdt,
                 "dof_iters_per_s": n_global * cits / cdt}
 
