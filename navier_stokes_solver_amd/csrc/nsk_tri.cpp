@@ -424,7 +424,10 @@ void TriSolve::numeric(const double *a_val_dev) {
 
 void TriSolve::apply(const double *b, double *x) {
   hipStream_t s = ctx->stream;
-  if (block2_ready && use_stream) {
+  // Tiny factors (a few MB: they sit in one XCD's L2) are latency-bound on the ~5 us per level launch:
+  // one 1024-thread workgroup walking all levels with __syncthreads in between is faster there.
+  const bool tiny = (double)nnz * 12.0 < 4.0e6 && !schedL.empty();
+  if (block2_ready && use_stream && !tiny) {
     const TriBlk L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
     for (int c = 0; c < n_colors; ++c) tri_blk_level(s, L, LB[c], LB[c + 1], 1, kind, intra.p, permn.p, b, x);
     for (int c = n_colors - 1; c >= 0; --c) tri_blk_level(s, U, UB[c], UB[c + 1], 0, kind, intra.p, permn.p, nullptr, x);
@@ -432,7 +435,7 @@ void TriSolve::apply(const double *b, double *x) {
     ctx->st.tri_bytes += (double)apply_bytes();
     return;
   }
-  if (stream_ready && use_stream) {
+  if (stream_ready && use_stream && !tiny) {
     const TriHalf L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
     if (x_layout == 0) {
       // x doubles as the intermediate vector: rows not yet solved hold L^-1 b, solved rows hold the result
