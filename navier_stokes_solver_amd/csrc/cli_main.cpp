@@ -1,0 +1,208 @@
+// cli_main.cpp — StationaryNSSolver / NSSolver command-line drivers over the two C ABIs
+// (include/nsk_problem.h: synthetic hand-off, include/nsk.h: GPU solve path).
+//
+// Flag surface, defaults, help text and the configuration echo follow the reference's drivers
+// (lab_new/src/testStationary.cpp:7-123, lab_new/src/test.cpp:8-146; README.md:56-67): same getopt
+// string ("M:m:r:s:t:p:h", plus "T:" for the unsteady driver — so -M swallows the next token exactly
+// as there), same integer codes for -s / -p.  What runs is the hot path only: one solve_system() per
+// continuation level the reference would visit (NSSolverStationary.cpp:662-665 / NSSolver.cpp:684);
+// the first level gets the reference's own first system (Stokes with the inlet data), later levels the
+// Newton system about the synthetic state.  Newton / line search / assembly for arbitrary states and
+// VTU output are callers / consumers of the path and are not part of it.
+//
+// Built twice from this file: -DNSK_UNSTEADY=0 -> StationaryNSSolver, -DNSK_UNSTEADY=1 -> NSSolver.
+#include <getopt.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <vector>
+
+#include "../../include/nsk.h"
+#include "../../include/nsk_problem.h"
+
+#ifndef NSK_UNSTEADY
+#define NSK_UNSTEADY 0
+#endif
+
+static void print_help() {
+  std::cout << "Usage: ./NSSolver [options]\n\nOptions:\n";
+  if (NSK_UNSTEADY)
+    std::cout << "  -T, --timespan-step T,dt  Set time span and time step (two floating point values separated by a comma)\n";
+  std::cout << "  -M, --read-mesh-from-file  Read mesh from file instead or generate it inside the program\n"
+            << "  -m, --mesh-size X,Y       Set mesh size (two integers separated by a comma)\n"
+            << "  -r, --reynolds N         Set Reynolds number (floating point value)\n"
+            << "  -s, --solver N            Select solver (valid values: 0: GMRES, 1: FGMRES, 2: Bicgstab)\n"
+            << "  -t, --tolerance D         Set tolerance (floating point value)\n"
+            << "  -p, --preconditioner N    Select preconditioner (valid values: 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE)\n"
+            << "  -h, --help                Display this help message\n";
+}
+
+static void check(nsk_handle h, int rc, const char *what) {
+  if (rc < 0) throw std::runtime_error(std::string(what) + ": " + nsk_last_error(h));
+}
+
+int main(int argc, char *argv[]) {
+  bool read_mesh_from_file = false;
+  double Re = 100.0, tolerance = 1e-6, time_span = 1.0, time_step = 0.01;
+  int mesh_size_x = 100, mesh_size_y = 100, solver_type = 1, preconditioner = 0;
+
+  static struct option long_options[] = {{"timespan-step", required_argument, 0, 'T'},
+                                         {"read-mesh-from-file", no_argument, 0, 'M'},
+                                         {"mesh-size", required_argument, 0, 'm'},
+                                         {"reynolds", required_argument, 0, 'r'},
+                                         {"solver", required_argument, 0, 's'},
+                                         {"tolerance", required_argument, 0, 't'},
+                                         {"preconditioner", required_argument, 0, 'p'},
+                                         {"help", no_argument, 0, 'h'},
+                                         {0, 0, 0, 0}};
+  const char *shortopts = NSK_UNSTEADY ? "T:M:m:r:s:t:p:h" : "M:m:r:s:t:p:h";
+  int opt;
+  while ((opt = getopt_long(argc, argv, shortopts, NSK_UNSTEADY ? long_options : long_options + 1, nullptr)) != -1) {
+    switch (opt) {
+      case 'T': {
+        char *comma = strchr(optarg, ',');
+        if (!comma) { std::cerr << "Error: timespan-step requires two values separated by comma\n"; return 1; }
+        *comma = '\0';
+        time_span = std::atof(optarg);
+        time_step = std::atof(comma + 1);
+        break;
+      }
+      case 'M': read_mesh_from_file = true; break;
+      case 'm': {
+        char *comma = strchr(optarg, ',');
+        if (!comma) { std::cerr << "Error: mesh-size requires two values separated by comma\n"; return 1; }
+        *comma = '\0';
+        mesh_size_x = std::atoi(optarg);
+        mesh_size_y = std::atoi(comma + 1);
+        break;
+      }
+      case 'r': Re = std::atof(optarg); break;
+      case 's': solver_type = std::atoi(optarg); break;
+      case 't': tolerance = std::atof(optarg); break;
+      case 'p': preconditioner = std::atoi(optarg); break;
+      case 'h': print_help(); return 0;
+      default: print_help(); return 1;
+    }
+  }
+  if (tolerance <= 0 || (NSK_UNSTEADY && (time_step <= 0 || time_span <= 0))) {
+    std::cerr << (NSK_UNSTEADY ? "Error: time_step, time_span, and tolerance must be positive\n"
+                               : "Error: tolerance must be positive\n");
+    return 1;
+  }
+
+  std::cout << "--------- CONFIGURATION PARAMETERS --------- \n";
+  if (NSK_UNSTEADY) std::cout << "Time span: " << time_span << "\nTime step: " << time_step << "\n";
+  std::cout << "Mesh size: " << mesh_size_x << "x" << mesh_size_y << "\nReynolds number: " << Re << "\nSolver type: ";
+  if (solver_type == 0) std::cout << "GMRES\n";
+  else if (solver_type == 1) std::cout << "FGMRES\n";
+  else if (solver_type == 2) std::cout << "Bicgstab\n";
+  std::cout << "Tolerance: " << tolerance << "\nPreconditioner: ";
+  if (preconditioner == 0) std::cout << "blockDiagonal\n";
+  else if (preconditioner == 1) std::cout << "blockTriangular\n";
+  else if (preconditioner == 2) std::cout << "aSIMPLE\n";
+  std::cout << "-----------------------------------------------\n";
+
+  if (read_mesh_from_file) {
+    std::cerr << "-M (gmsh P2/P1 mesh from file) is outside the accelerated path; generated meshes only\n";
+    return 1;
+  }
+  nsk_handle h = nullptr;
+  nsp_mesh *mesh = nullptr;
+  try {
+    if (preconditioner < 0 || preconditioner > 2)
+      throw std::invalid_argument("Invalid preconditioner type. Use 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE.");
+    mesh = nsp_mesh_create(mesh_size_x, mesh_size_y, 1, 0);
+    if (!mesh) throw std::invalid_argument("mesh size rejected");
+    nsp_info info;
+    nsp_mesh_info(mesh, &info);
+    std::cout << "  Number of elements = " << info.n_cells << "\n"
+              << "Initializing the finite element space\n  Velocity degree:           = 3\n"
+              << "  Pressure degree:           = 2\n  DoFs per cell              = 41\n"
+              << "  Quadrature points per cell = 16\n  Quadrature points per face = 4\n"
+              << "-----------------------------------------------\nInitializing the DoF handler\n  Number of DoFs: \n"
+              << "    velocity = " << info.n_u_global << "\n    pressure = " << info.n_p_global << "\n    total    = "
+              << info.n_u_global + info.n_p_global << "\n-----------------------------------------------\n"
+              << "===============================================\nTarget Re = " << Re << std::endl;
+
+    h = nsk_create(0, 1, 0, nullptr);
+    if (!h) throw std::runtime_error("nsk_create failed: no usable GPU (there is no CPU fallback)");
+    const int variant = NSK_UNSTEADY ? NSK_VARIANT_UNSTEADY : NSK_VARIANT_STATIONARY;
+    const int max_iter = NSK_UNSTEADY ? 100000 : 20000;
+    long total_its = 0;
+    int n_solves = 0;
+    double t_solve = 0.0;
+    bool first = true;
+    for (double current_Re = NSK_UNSTEADY ? 1.0 : 10.0; current_Re <= Re; current_Re += NSK_UNSTEADY ? 10.0 : 20.0) {
+      const double nu = 1.0 / current_Re;
+      std::cout << "===============================================\nSolving for nu = " << nu << std::endl;
+      nsp_params prm;
+      std::memset(&prm, 0, sizeof(prm));
+      prm.mode = first ? 0 : 1;
+      prm.state = first ? 0 : 1;
+      prm.inlet_bc = first ? 1 : 0;
+      prm.nu = nu;
+      prm.inv_dt = NSK_UNSTEADY ? 1.0 / time_step : 0.0;
+      prm.U = NSK_UNSTEADY ? 0.3 : 0.1;
+      prm.p_out = 1.0;
+      if (nsp_assemble(mesh, &prm) != 0) throw std::runtime_error("nsp_assemble failed");
+      std::cout << (first ? "Solving Stokes adding BCs" : "Solving NS") << std::endl;
+      const int n_u = (int)nsp_block_rows(mesh, NSP_BLK_F), n_p = (int)nsp_block_rows(mesh, NSP_BLK_B);
+      if (first) {
+        check(h, nsk_set_partition(h, NSK_SPACE_U, 0, n_u, 0, nullptr), "nsk_set_partition");
+        check(h, nsk_set_partition(h, NSK_SPACE_P, 0, n_p, 0, nullptr), "nsk_set_partition");
+        const int blks[4] = {NSP_BLK_F, NSP_BLK_BT, NSP_BLK_B, NSP_BLK_MP};
+        for (int b : blks)
+          check(h, nsk_set_block_csr(h, b, (int)nsp_block_rows(mesh, b), (int)nsp_block_cols(mesh, b),
+                                     nsp_block_rowptr(mesh, b), nsp_block_col(mesh, b), nsp_block_val(mesh, b)),
+                "nsk_set_block_csr");
+      } else {
+        const int blks[4] = {NSP_BLK_F, NSP_BLK_BT, NSP_BLK_B, NSP_BLK_MP};
+        for (int b : blks) check(h, nsk_update_values(h, b, nsp_block_val(mesh, b)), "nsk_update_values");
+      }
+      double r2 = 0.0;
+      for (int i = 0; i < n_u; ++i) r2 += nsp_rhs_u(mesh)[i] * nsp_rhs_u(mesh)[i];
+      for (int i = 0; i < n_p; ++i) r2 += nsp_rhs_p(mesh)[i] * nsp_rhs_p(mesh)[i];
+      std::printf("Newton iteration 0/%d - ||r|| = %.6e", NSK_UNSTEADY ? 10 : 15, std::sqrt(r2));
+      std::fflush(stdout);
+      if (NSK_UNSTEADY) std::cout << "\nSolver tolerance: " << tolerance << std::endl;
+      std::vector<double> du(nsp_x0_u(mesh), nsp_x0_u(mesh) + n_u), dp(nsp_x0_p(mesh), nsp_x0_p(mesh) + n_p);
+      const auto t0 = std::chrono::steady_clock::now();
+      // int solve_system(): fresh preconditioner, outer solve, last_step()
+      check(h, nsk_setup_preconditioner(h, preconditioner, variant, 0.5), "nsk_setup_preconditioner");
+      int iters = 0;
+      double res = 0.0;
+      const int rc = nsk_solve(h, solver_type, tolerance, max_iter, nsp_rhs_u(mesh), nsp_rhs_p(mesh), du.data(),
+                               dp.data(), &iters, &res);
+      check(h, rc, "nsk_solve");
+      t_solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (rc > 0) {  // the reference dies on deal.II's uncaught SolverControl::NoConvergence here
+        std::cerr << "\nIterative method reported convergence failure in step " << iters << ". The residual in the last step was "
+                  << res << ".\n";
+        nsk_destroy(h);
+        nsp_mesh_destroy(mesh);
+        return 3;
+      }
+      std::cout << "   " << iters << (NSK_UNSTEADY ? " iterations" : " solver iterations") << std::endl;
+      total_its += iters;
+      ++n_solves;
+      first = false;
+    }
+    const double n = (double)(info.n_u_global + info.n_p_global);
+    std::printf("===============================================\n[nsk] %d solve_system() calls, %ld outer iterations, "
+                "%.3f s in solve_system (setup + solve) -> %.4g DoF*iters/s\n",
+                n_solves, total_its, t_solve, n * total_its / (t_solve > 0 ? t_solve : 1e-12));
+  } catch (const std::exception &e) {
+    std::cerr << e.what() << std::endl;
+    if (h) nsk_destroy(h);
+    if (mesh) nsp_mesh_destroy(mesh);
+    return 2;
+  }
+  nsk_destroy(h);
+  nsp_mesh_destroy(mesh);
+  return 0;
+}

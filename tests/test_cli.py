@@ -59,3 +59,46 @@ def test_stationary_driver_runs_reference_cpu_config():
     text = out.getvalue()
     assert rc == 0
     assert "total    = 26832" in text and "Solving Stokes adding BCs" in text and "solver iterations" in text
+
+
+def _bin(name):
+    import os
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "navier_stokes_solver_amd", "bin", name)
+
+
+def test_cpp_drivers_help_and_argument_errors():
+    """The C++ drivers (csrc/cli_main.cpp over the two C ABIs) parse like the reference's."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build_problem_lib()
+    import os
+    if not os.path.exists(_bin("StationaryNSSolver")):
+        g.build_cli()
+    out = subprocess.run([_bin("StationaryNSSolver"), "-h"], capture_output=True, text=True)
+    assert out.returncode == 0 and "--preconditioner N" in out.stdout and "--timespan-step" not in out.stdout
+    out = subprocess.run([_bin("NSSolver"), "-h"], capture_output=True, text=True)
+    assert out.returncode == 0 and "--timespan-step" in out.stdout
+    out = subprocess.run([_bin("StationaryNSSolver"), "-m", "60"], capture_output=True, text=True)
+    assert out.returncode == 1 and "mesh-size requires two values" in out.stderr
+    out = subprocess.run([_bin("NSSolver"), "-T", "5"], capture_output=True, text=True)
+    assert out.returncode == 1 and "timespan-step requires two values" in out.stderr
+    out = subprocess.run([_bin("StationaryNSSolver"), "-t", "-1"], capture_output=True, text=True)
+    assert out.returncode == 1 and "tolerance must be positive" in out.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_stationary_driver_runs_reference_cpu_config():
+    import subprocess
+    out = subprocess.run([_bin("StationaryNSSolver"), "-m", "60,20", "-r", "20", "-s", "1", "-p", "0", "-t", "1e-8"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Mesh size: 60x20" in out.stdout and "total    = 26832" in out.stdout and "solver iterations" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_unsteady_driver_runs():
+    import subprocess
+    out = subprocess.run([_bin("NSSolver"), "-T", "0.02,0.01", "-m", "16,10", "-r", "11", "-s", "1", "-p", "2", "-t", "1e-8"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "Time step: 0.01" in out.stdout and out.stdout.count(" iterations") >= 2
