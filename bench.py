@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--ordering", type=int, default=1, help="0 natural, 1 multicolour (triangular solves)")
     ap.add_argument("--subdomains", type=int, default=1)
+    ap.add_argument("--sync-free", type=int, default=1, help="0 per-level launches, 1 single-launch S/Mp solves, 2 also F")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mesh", type=str, default="300,100")
     ap.add_argument("--cpu-steps", type=int, default=4)
@@ -141,6 +142,7 @@ def main():
     ls = S.LinearSolver(rank, world, local_rank, uid)
     ls.set_option(S.OPT_TRI_ORDERING, args.ordering)
     ls.set_option(S.OPT_SUBDOMAINS, args.subdomains)
+    ls.set_option(S.OPT_TRI_SYNC_FREE, args.sync_free if world == 1 else 0)   # rank-local fallback would desync ranks
     t0 = time.time()
     ls.set_problem(pr, plan)
     t_upload = time.time() - t0
@@ -157,7 +159,17 @@ def main():
 
     # warm-up
     ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
-    ls.solve_resident(args.solver, 0.0, max(1, args.warmup))
+    try:
+        ls.solve_resident(args.solver, 0.0, max(1, args.warmup))
+    except RuntimeError as e:
+        if "-70" not in str(e):
+            raise
+        # single-launch triangular solves gave up on a hand-off on this box: use one launch per level
+        print(f"[bench] rank {rank}: {e}; falling back to per-level launches", file=sys.stderr, flush=True)
+        ls.set_option(S.OPT_TRI_SYNC_FREE, 0)
+        ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
+        ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+        ls.solve_resident(args.solver, 0.0, max(1, args.warmup))
     # timed: exactly K outer iterations from the same initial state, fresh preconditioner object
     ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
     ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
@@ -209,7 +221,9 @@ def main():
         names = {0: "spmv_blk_kernel<2,2>: SpMV with F (inner FGMRES), 2x2 node blocks",
                  3: "spmv_stream_kernel<1,0>: SpMV with Mp (inner CG)", 5: "spmv_stream_kernel<1,0>: SpMV with S (inner CG)",
                  20: "tri_blk_kernel: ILU(0)/SGS apply on F (17+17 node-colour level launches of one apply)",
-                 21: "tri_stream_kernel: ILU(0)/SGS apply on the pressure block (31+31 level launches of one apply)"}
+                 21: ("tri_stream_sf_kernel: ILU(0)/SGS apply on the pressure block (one launch per half, in-kernel hand-off)"
+                      if (world == 1 and args.sync_free >= 1) else
+                      "tri_stream_kernel: ILU(0)/SGS apply on the pressure block (31+31 level launches of one apply)")}
         klass = {}
         for op, (ms, cnt, by, ncalls) in prof.items():
             klass[op] = dict(kernel=names[op], avg_ms=ms, launches_sampled=cnt, calls=ncalls, bytes_per_launch=by,

@@ -68,6 +68,11 @@ enum {
   NSK_OPT_OUTER_FUSED_GS = 5, /* same for the outer FGMRES; default 0 (modified Gram-Schmidt, as deal.II) */
   NSK_OPT_BSR_VELOCITY = 7,   /* 1 (default): SpMVs with the jacobian blocks use 2x2 / 2x1 / 1x2 node-block copies when the pattern allows */
   NSK_OPT_TRI_RUN_NNZ = 8,    /* non-zeros per workgroup in the scalar streamed triangular levels: 512, 1024, 2048 (default) */
+  NSK_OPT_TRI_SYNC_FREE = 9,  /* multicolour triangular solves with ONE launch per half: rows wait in-kernel for the entries
+                                 they depend on (bounded spins on a sentinel-filled vector, see nsk_kernels.h).
+                                 0: off (one launch per level); 1 (default): scalar factors (S, Mp); 2: also the 2x2-blocked
+                                 velocity factor.  If a wait ever runs out, nsk_solve falls back to 0 and redoes the solve;
+                                 nsk_solve_resident returns -70 */
   NSK_OPT_TRI_X_LAYOUT = 6    /* multicolour triangular solves: 0 (default) work in the caller's DoF order,
                                  1 work on an internal colour-ordered vector */
 };

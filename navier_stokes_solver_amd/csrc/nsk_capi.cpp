@@ -76,6 +76,7 @@ struct nsk_handle_s {
   int tri_ordering = ORDER_MULTICOLOR, subdomains = 1, fuse_block_row = 1, use_stream = 1;
   bool inner_fused_gs = true, outer_fused_gs = false;
   int use_bsr = 1;
+  int sync_free_mode = 1;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
   DBuf<int> jrow_blk, jblk_blk;  // row runs of the fused (F | Bt) block row: CSR and blocked variants
   int jrow_nblk = 0, jblk_nblk = 0;
   bool jrow_ok = false, jblk_ok = false;
@@ -190,6 +191,18 @@ struct nsk_handle_s {
     off[subdomains] = n;
     return off;
   }
+  void check_sync_free() {  // call after a stream sync
+    for (TriSolve *T : {&tF, &tMp, &tS})
+      if (T->sf_err.p) {
+        int e = 0;
+        NSK_HIP(hipMemcpy(&e, T->sf_err.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (e) {
+          NSK_HIP(hipMemset(T->sf_err.p, 0, sizeof(int)));
+          throw Error(-70, "sync-free triangular solve: a producer/consumer wait ran out of spins (results invalid); "
+                           "set NSK_OPT_TRI_SYNC_FREE to 0");
+        }
+      }
+  }
   void schur_symbolic();
   void setup(int type, int variant_, double alpha_);
   void prec_vmult(DVec &dst, const DVec &src);
@@ -250,6 +263,8 @@ void H::schur_symbolic() {
 void H::setup(int type, int variant_, double alpha_) {
   if (type < 0 || type > 2) throw Error(-44, "Invalid preconditioner type. Use 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE.");
   ensure_pools();
+  tMp.sync_free = tS.sync_free = sync_free_mode >= 1;
+  tF.sync_free = sync_free_mode >= 2;
   const double t0 = wall_ms();
   prec_type = type;
   variant = variant_;
@@ -414,6 +429,7 @@ int H::solve_resident(int solver, double tol, int max_iter, int *iters, double *
   }
   ctx.slot_top = slot_mark;
   ctx.sync();
+  check_sync_free();
   solve_ms = wall_ms() - t0;
   outer_iters += control.last_step();
   if (iters) *iters = control.last_step();
@@ -454,6 +470,9 @@ nsk_handle nsk_create(int rank, int nranks, int device_id, const void *uid) {
   try {
     h->ctx.init(device_id);
     h->ctx.comm.init(rank, nranks, uid);
+    // a rank-local fallback from the single-launch triangular solves would desynchronise the ranks'
+    // collectives, so several ranks default to one launch per level
+    if (nranks > 1) h->sync_free_mode = 0;
   } catch (const std::exception &e) {
     fprintf(stderr, "nsk_create: %s\n", e.what());
     delete h;
@@ -574,6 +593,11 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
       h->tF.run_nnz = h->tMp.run_nnz = h->tS.run_nnz = v <= 512 ? 512 : (v <= 1024 ? 1024 : 2048);
       h->tF_ok = h->tMp_ok = h->tS_ok = false;
       break;
+    case NSK_OPT_TRI_SYNC_FREE:
+      h->sync_free_mode = (int)v;
+      h->tMp.sync_free = h->tS.sync_free = v >= 1.0;
+      h->tF.sync_free = v >= 2.0;
+      break;
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
     case NSK_OPT_TRI_X_LAYOUT:
       h->tF.x_layout = h->tMp.x_layout = h->tS.x_layout = v != 0.0;
@@ -630,7 +654,17 @@ int nsk_solve(nsk_handle h, int solver, double tol, int max_iter, const double *
               double *xp, int *iters, double *final_res) {
   int rc = nsk_upload_system(h, ru, rp, xu, xp);
   if (rc < 0) return rc;
-  const int rs = nsk_solve_resident(h, solver, tol, max_iter, iters, final_res);
+  int rs = nsk_solve_resident(h, solver, tol, max_iter, iters, final_res);
+  if (rs == -70 && h->ctx.comm.nranks == 1) {
+    // the single-launch triangular solves gave up on a hand-off: fall back to one launch per level and redo the
+    // solve from the caller's initial guess (a fresh preconditioner object: stale inner state must not leak)
+    nsk_set_option(h, NSK_OPT_TRI_SYNC_FREE, 0.0);
+    rc = nsk_setup_preconditioner(h, h->prec_type, h->variant, h->alpha);
+    if (rc < 0) return rc;
+    rc = nsk_upload_system(h, ru, rp, xu, xp);
+    if (rc < 0) return rc;
+    rs = nsk_solve_resident(h, solver, tol, max_iter, iters, final_res);
+  }
   if (rs < 0) return rs;
   rc = nsk_download_solution(h, xu, xp);
   return rc < 0 ? rc : rs;
@@ -705,6 +739,7 @@ int nsk_tri_apply(nsk_handle h, int which, const double *b, double *x) {
   h->ctx.sync();
   p.put(bv);
   p.put(xv);
+  h->check_sync_free();
   return 0;
   NSK_CATCH(h)
 }
@@ -741,6 +776,7 @@ int nsk_precond_vmult(nsk_handle h, const double *su, const double *sp_, double 
   h->ctx.sync();
   h->pool_b.put(sb);
   h->pool_b.put(db);
+  h->check_sync_free();
   return rc;
   NSK_CATCH(h)
 }
@@ -892,6 +928,7 @@ int nsk_time_op(nsk_handle h, int op, int reps, double *avg_ms, double *bytes) {
   if (bytes) *bytes = by;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  h->check_sync_free();
   h->ctx.slot_top = sl;
   h->pool_b.put(xb);
   h->pool_b.put(yb);

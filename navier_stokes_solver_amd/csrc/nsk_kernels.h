@@ -158,6 +158,21 @@ void tri_blk_level(hipStream_t s, const TriBlk &M, int b0, int b1, int lower, in
                    const int *permn, const double *rhs, double *x);
 void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra);
 
+// ---- "sync-free" triangular solves: ONE launch per half instead of one per level ----
+// Every workgroup still owns a row run of one colour, but all colours go into one grid whose workgroups
+// are in dependency order (lower: ascending rows, upper: descending).  The solution vector is pre-filled
+// with a sentinel NaN; a gathered entry that still holds the sentinel has not been produced yet, so the
+// consumer re-polls it with an agent-scope (sc1, L1-bypassing) load until the producer's single 8-byte
+// agent-scope store lands (MI355X_MICROARCH.md: a naturally aligned 8-byte granule written by one store
+// needs no separate flag or fence).  Producers are always in lower-indexed workgroups, which the dispatcher
+// starts first; every spin is bounded and raises *err instead of hanging.
+void vec_fill_sentinel(hipStream_t s, int n, double *y);
+void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int n_blocks, int lower, int kind, int run_nnz,
+                         const double *dinv, const int *perm, const double *rhs, const double *own, double *w,
+                         int *err);
+void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int n_blocks, int lower, int kind, const double *intra,
+                      const int *permn, const double *rhs, const double *own, double *w, int *err);
+
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,
                        const int *col, double *val, int max_row_nnz);

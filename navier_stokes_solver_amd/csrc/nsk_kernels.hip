@@ -448,6 +448,158 @@ __global__ __launch_bounds__(BLK) void tri_blk_kernel(TriBlk M, int b0, int nb, 
   }
 }
 
+// ------------------------------------------------------------------ sync-free triangular solves
+constexpr unsigned long long kSentinel = 0x7FF8DEADBEEF0001ull;  // a NaN payload no arithmetic produces
+constexpr int kMaxSpins = 1 << 19;  // ~0.5 s of polling, then give up and flag the error
+
+__device__ __forceinline__ unsigned long long sf_load(const double *p) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sf_store(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// First look: an ordinary (L1/L2-cached) load.  Every entry is written exactly once after the sentinel fill,
+// so a non-sentinel value is final wherever it was cached; only a sentinel (possibly a stale line) sends the
+// lane to the agent-scope polling loop below.
+__device__ __forceinline__ unsigned long long sf_peek(const double *p) {
+  return (unsigned long long)__double_as_longlong(*reinterpret_cast<const volatile double *>(p));
+}
+// re-poll until the producer's store is visible; bounded
+__device__ __forceinline__ double sf_wait(const double *p, unsigned long long first, int *err) {
+  unsigned long long v = first;
+  int spins = 0;
+  while (v == kSentinel) {
+    if (++spins > kMaxSpins) { *err = 1; break; }
+    __builtin_amdgcn_s_sleep(1);
+    v = sf_load(p);
+  }
+  return __longlong_as_double((long long)v);
+}
+
+template <int LOWER, int KIND, int NNZ>
+__global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, const double *__restrict__ dinv,
+                                                            const int *__restrict__ perm,
+                                                            const double *__restrict__ rhs,
+                                                            const double *__restrict__ ownv, double *w, int *err) {
+  __shared__ double prod[NNZ];
+  // dependency order: lower = ascending runs, upper = descending runs (no XCD remap: producers must be
+  // in workgroups the dispatcher has already started)
+  const int blk = LOWER ? (int)blockIdx.x : nb - 1 - (int)blockIdx.x;
+  const int4 d = M.desc[blk];
+  const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
+  const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
+  const bool have = r < r1;
+  int jb = 0, je = 0, i = 0;
+  double own = 0.0, dv = 1.0;
+  if (have) {
+    jb = M.rowptr[r] - k0;
+    je = M.rowptr[r + 1] - k0;
+    i = perm[r];
+    own = LOWER ? rhs[i] : ownv[i];
+    if (KIND == 1 || !LOWER) dv = dinv[r];
+  }
+  {
+    constexpr int U = NNZ / BLK;
+    int c[U];
+    double v[U];
+    unsigned long long g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      const bool ok = k < k1;
+      c[u] = ok ? __builtin_nontemporal_load(M.col + k) : -1;
+      v[u] = ok ? __builtin_nontemporal_load(M.val + k) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) g[u] = c[u] >= 0 ? sf_peek(w + c[u]) : 0ull;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      if (k < k1) prod[k - k0] = v[u] * sf_wait(w + c[u], g[u], err);
+    }
+  }
+  __syncthreads();
+  const double sum = row_sum_lds(prod, jb, je, lane);
+  if (have && lane == 0) {
+    double x;
+    if (LOWER) x = KIND == 0 ? (own - sum) : (own - sum) * dv;
+    else x = KIND == 0 ? (own - sum) * dv : own - sum * dv;
+    sf_store(w + i, x);
+  }
+}
+
+template <int LOWER, int KIND>
+__global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, const double *__restrict__ intra,
+                                                         const int *__restrict__ permn,
+                                                         const double *__restrict__ rhs,
+                                                         const double *__restrict__ ownv, double *x, int *err) {
+  __shared__ double p0[kBlkMax];
+  __shared__ double p1[kBlkMax];
+  const int blk = LOWER ? (int)blockIdx.x : nb - 1 - (int)blockIdx.x;
+  const int4 d = M.desc[blk];
+  const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
+  const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
+  const bool have = r < r1;
+  int jb = 0, je = 0;
+  size_t i = 0;
+  double2 own = make_double2(0.0, 0.0), cf = make_double2(0.0, 0.0), di = make_double2(1.0, 1.0);
+  if (have) {
+    jb = M.rowptr[r] - k0;
+    je = M.rowptr[r + 1] - k0;
+    i = 2 * (size_t)permn[r];
+    own = *reinterpret_cast<const double2 *>((LOWER ? rhs : ownv) + i);
+    cf = *reinterpret_cast<const double2 *>(intra + 4 * (size_t)r);
+    di = *reinterpret_cast<const double2 *>(intra + 4 * (size_t)r + 2);
+  }
+  {
+    constexpr int U = kBlkMax / BLK;
+    int m[U];
+    double2 a0[U], a1[U];
+    unsigned long long g0[U], g1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      const bool ok = k < k1;
+      m[u] = ok ? __builtin_nontemporal_load(M.col + k) : -1;
+      const double *v = M.val + 4 * (size_t)(ok ? k : k0);
+      a0[u] = *reinterpret_cast<const double2 *>(v);
+      a1[u] = *reinterpret_cast<const double2 *>(v + 2);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      g0[u] = m[u] >= 0 ? sf_peek(x + 2 * (size_t)m[u]) : 0ull;
+      g1[u] = m[u] >= 0 ? sf_peek(x + 2 * (size_t)m[u] + 1) : 0ull;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      if (k < k1) {
+        const double xa = sf_wait(x + 2 * (size_t)m[u], g0[u], err), xb = sf_wait(x + 2 * (size_t)m[u] + 1, g1[u], err);
+        p0[k - k0] = a0[u].x * xa + a0[u].y * xb;
+        p1[k - k0] = a1[u].x * xa + a1[u].y * xb;
+      }
+    }
+  }
+  __syncthreads();
+  double s0 = 0.0, s1 = 0.0;
+  for (int j = jb + lane; j < je; j += RG) { s0 += p0[j]; s1 += p1[j]; }
+  s0 = subwave_sum<RG>(s0);
+  s1 = subwave_sum<RG>(s1);
+  if (have && lane == 0) {
+    double v0, v1;
+    if (LOWER) {
+      if (KIND == 0) { v0 = own.x - s0; v1 = own.y - s1 - cf.x * v0; }
+      else { v0 = (own.x - s0) * di.x; v1 = (own.y - s1 - cf.x * v0) * di.y; }
+    } else {
+      if (KIND == 0) { v1 = (own.y - s1) * di.y; v0 = (own.x - s0 - cf.y * v1) * di.x; }
+      else { v1 = own.y - s1 * di.y; v0 = own.x - (s0 + cf.y * v1) * di.x; }
+    }
+    sf_store(x + i, v0);
+    sf_store(x + i + 1, v1);
+  }
+}
+
 // ------------------------------------------------------------------ element-wise
 template <class F>
 __global__ __launch_bounds__(BLK) void ew_kernel(int n, F f) {
@@ -862,6 +1014,33 @@ void vec_recip(hipStream_t s, int n, const double *x, double *y) {
 void scalar_sqrt(hipStream_t s, const double *in, double *out) {
   const int n = 1;
   NSK_EW(n, [=] __device__(int) { out[0] = sqrt(fabs(in[0])); });
+}
+void vec_fill_sentinel(hipStream_t s, int n, double *y) {
+  unsigned long long *p = reinterpret_cast<unsigned long long *>(y);
+  NSK_EW(n, [=] __device__(int i) { p[i] = kSentinel; });
+}
+void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int kind, int run_nnz, const double *dinv,
+                         const int *perm, const double *rhs, const double *own, double *w, int *err) {
+  if (nb <= 0) return;
+#define NSK_SF(L, K, N) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N>), dim3(nb), dim3(BLK), 0, s, M, nb, dinv, perm, rhs, own, w, err)
+#define NSK_SFN(L, K)                                      \
+  do {                                                     \
+    if (run_nnz <= 512) NSK_SF(L, K, 512);                 \
+    else if (run_nnz <= 1024) NSK_SF(L, K, 1024);          \
+    else NSK_SF(L, K, 2048);                               \
+  } while (0)
+  if (lower) { if (kind == 0) NSK_SFN(1, 0); else NSK_SFN(1, 1); }
+  else { if (kind == 0) NSK_SFN(0, 0); else NSK_SFN(0, 1); }
+#undef NSK_SFN
+#undef NSK_SF
+}
+void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int nb, int lower, int kind, const double *intra,
+                      const int *permn, const double *rhs, const double *own, double *w, int *err) {
+  if (nb <= 0) return;
+#define NSK_SB(L, K) hipLaunchKernelGGL((tri_blk_sf_kernel<L, K>), dim3(nb), dim3(BLK), 0, s, M, nb, intra, permn, rhs, own, w, err)
+  if (lower) { if (kind == 0) NSK_SB(1, 0); else NSK_SB(1, 1); }
+  else { if (kind == 0) NSK_SB(0, 0); else NSK_SB(0, 1); }
+#undef NSK_SB
 }
 void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra) {
   const int n = n_nodes;

@@ -427,6 +427,28 @@ void TriSolve::apply(const double *b, double *x) {
   // Tiny factors (a few MB: they sit in one XCD's L2) are latency-bound on the ~5 us per level launch:
   // one 1024-thread workgroup walking all levels with __syncthreads in between is faster there.
   const bool tiny = (double)nnz * 12.0 < 4.0e6 && !schedL.empty();
+  if (sync_free && use_stream && !tiny && (block2_ready || (stream_ready && x_layout == 0))) {
+    if (!sf_err.p) {
+      sf_err.alloc(1);
+      NSK_HIP(hipMemsetAsync(sf_err.p, 0, sizeof(int), s));
+    }
+    // lower half into y (pre-filled with the sentinel), upper half into x; each half is ONE launch
+    vec_fill_sentinel(s, n, y.p);
+    if (block2_ready) {
+      const TriBlk L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
+      tri_blk_syncfree(s, L, LB[n_colors], 1, kind, intra.p, permn.p, b, nullptr, y.p, sf_err.p);
+      vec_fill_sentinel(s, n, x);
+      tri_blk_syncfree(s, U, UB[n_colors], 0, kind, intra.p, permn.p, nullptr, y.p, x, sf_err.p);
+    } else {
+      const TriHalf L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
+      tri_stream_syncfree(s, L, LB[n_colors], 1, kind, run_nnz, dinv.p, d_perm.p, b, nullptr, y.p, sf_err.p);
+      vec_fill_sentinel(s, n, x);
+      tri_stream_syncfree(s, U, UB[n_colors], 0, kind, run_nnz, dinv.p, d_perm.p, nullptr, y.p, x, sf_err.p);
+    }
+    ++ctx->st.tri_applies;
+    ctx->st.tri_bytes += (double)apply_bytes();
+    return;
+  }
   if (block2_ready && use_stream && !tiny) {
     const TriBlk L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
     for (int c = 0; c < n_colors; ++c) tri_blk_level(s, L, LB[c], LB[c + 1], 1, kind, intra.p, permn.p, b, x);

@@ -25,6 +25,7 @@ STATIONARY, UNSTEADY = 0, 1
 TRI_VELOCITY, TRI_PRESSURE = 0, 1
 OPT_TRI_ORDERING, OPT_SUBDOMAINS, OPT_FUSE_BLOCK_ROW, OPT_STREAM_KERNELS = 0, 1, 2, 3
 OPT_INNER_FUSED_GS, OPT_OUTER_FUSED_GS, OPT_TRI_X_LAYOUT, OPT_BSR_VELOCITY, OPT_TRI_RUN_NNZ = 4, 5, 6, 7, 8
+OPT_TRI_SYNC_FREE = 9
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
 
 EXPORTS = [

@@ -355,3 +355,28 @@ def test_gram_schmidt_variants_reach_the_same_solution(inner, outer):
         assert abs(its - info["iters"]) <= max(3, 0.2 * info["iters"])
     finally:
         ls.close()
+
+
+@pytest.mark.parametrize("name", ["ns60", "stokes60"])
+def test_sync_free_triangular_solves(name):
+    """One launch per triangular half with in-kernel hand-off (sentinel polling) == level-by-level launches."""
+    S, O = _S(), _O()
+    pr = problem(name)
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr)
+        ls.set_option(S.OPT_TRI_SYNC_FREE, 1)
+        for prec, variant in ((S.ASIMPLE, S.STATIONARY), (S.BLOCK_DIAGONAL, S.STATIONARY)):
+            ls.setup_preconditioner(prec, variant)
+            kind = 1 if prec == S.BLOCK_DIAGONAL else 0
+            b = rng_vec(pr.n_u, 90)
+            ref = O.Tri(O.CsrHolder.from_block(pr.F), kind=kind, perm=ls.tri_perm(S.TRI_VELOCITY)).apply(b)
+            for _ in range(3):
+                assert rel_err(ls.tri_apply(S.TRI_VELOCITY, b), ref) <= 1e-11
+        ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+        xu, xp, its, res, rc = ls.solve(S.FGMRES, 1e-8, 20000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+        assert rc == 0
+        J = pr.jacobian_scipy()
+        assert np.linalg.norm(np.concatenate([pr.rhs_u, pr.rhs_p]) - J @ np.concatenate([xu, xp])) <= 1.05e-8
+    finally:
+        ls.close()
