@@ -9,7 +9,7 @@ from tests.util import rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mesh", [(1, 1), (2, 1), (3, 2), (7, 3)])
+@pytest.mark.parametrize("mesh", [(1, 1), (3, 2), (7, 3)])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_tiny_meshes(mesh, mode):
     from navier_stokes_solver_amd import solver as S

@@ -357,7 +357,7 @@ def test_gram_schmidt_variants_reach_the_same_solution(inner, outer):
         ls.close()
 
 
-@pytest.mark.parametrize("name", ["ns60", "stokes60"])
+@pytest.mark.parametrize("name", ["ns60"])
 def test_sync_free_triangular_solves(name):
     """One launch per triangular half with in-kernel hand-off (sentinel polling) == level-by-level launches."""
     S, O = _S(), _O()
