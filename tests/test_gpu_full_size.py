@@ -61,6 +61,22 @@ def test_fgmres_asimple_residual_is_the_true_residual(big):
     assert res < r0
 
 
+def test_single_launch_and_per_level_pressure_solves_agree(big):
+    """ILU(S) apply at full size: sync-free single launch per half == one launch per level."""
+    pr, ls, S = big
+    rng = np.random.default_rng(11)
+    b = rng.uniform(-1, 1, pr.n_p)
+    out = []
+    for mode in (1, 0, 2):
+        ls.set_option(S.OPT_TRI_SYNC_FREE, mode)
+        ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+        out.append((ls.tri_apply(S.TRI_PRESSURE, b), ls.tri_apply(S.TRI_VELOCITY, np.resize(b, pr.n_u))))
+    ls.set_option(S.OPT_TRI_SYNC_FREE, 1)
+    for k in (1, 2):
+        assert np.abs(out[k][0] - out[0][0]).max() <= 1e-12 * np.abs(out[0][0]).max()
+        assert np.abs(out[k][1] - out[0][1]).max() <= 1e-12 * np.abs(out[0][1]).max()
+
+
 def test_ilu_apply_inverts_its_own_factors(big):
     """x = U^-1 L^-1 b  =>  the multicolour ILU(0) apply is linear and idempotent under refactorisation."""
     pr, ls, S = big

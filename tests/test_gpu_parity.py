@@ -365,7 +365,7 @@ def test_sync_free_triangular_solves(name):
     ls = S.LinearSolver()
     try:
         ls.set_problem(pr)
-        ls.set_option(S.OPT_TRI_SYNC_FREE, 1)
+        ls.set_option(S.OPT_TRI_SYNC_FREE, 2)   # 2: also the blocked velocity factor (the scalar ones are tiny here)
         for prec, variant in ((S.ASIMPLE, S.STATIONARY), (S.BLOCK_DIAGONAL, S.STATIONARY)):
             ls.setup_preconditioner(prec, variant)
             kind = 1 if prec == S.BLOCK_DIAGONAL else 0
