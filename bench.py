@@ -142,7 +142,7 @@ def main():
     ls = S.LinearSolver(rank, world, local_rank, uid)
     ls.set_option(S.OPT_TRI_ORDERING, args.ordering)
     ls.set_option(S.OPT_SUBDOMAINS, args.subdomains)
-    ls.set_option(S.OPT_TRI_SYNC_FREE, args.sync_free if world == 1 else 0)   # rank-local fallback would desync ranks
+    ls.set_option(S.OPT_TRI_SYNC_FREE, args.sync_free)
     t0 = time.time()
     ls.set_problem(pr, plan)
     t_upload = time.time() - t0
@@ -222,7 +222,7 @@ def main():
                  3: "spmv_stream_kernel<1,0>: SpMV with Mp (inner CG)", 5: "spmv_stream_kernel<1,0>: SpMV with S (inner CG)",
                  20: "tri_blk_kernel: ILU(0)/SGS apply on F (17+17 node-colour level launches of one apply)",
                  21: ("tri_stream_sf_kernel: ILU(0)/SGS apply on the pressure block (one launch per half, in-kernel hand-off)"
-                      if (world == 1 and args.sync_free >= 1) else
+                      if args.sync_free >= 1 else
                       "tri_stream_kernel: ILU(0)/SGS apply on the pressure block (31+31 level launches of one apply)")}
         klass = {}
         for op, (ms, cnt, by, ncalls) in prof.items():

@@ -191,17 +191,27 @@ struct nsk_handle_s {
     off[subdomains] = n;
     return off;
   }
-  void check_sync_free() {  // call after a stream sync
+  // Call after a stream sync.  Collective: with several ranks the flag is all-reduced so that every rank
+  // takes the same decision (a rank-local fallback would desynchronise the ranks' collectives).
+  void check_sync_free() {
+    int e = 0;
     for (TriSolve *T : {&tF, &tMp, &tS})
       if (T->sf_err.p) {
-        int e = 0;
-        NSK_HIP(hipMemcpy(&e, T->sf_err.p, sizeof(int), hipMemcpyDeviceToHost));
-        if (e) {
-          NSK_HIP(hipMemset(T->sf_err.p, 0, sizeof(int)));
-          throw Error(-70, "sync-free triangular solve: a producer/consumer wait ran out of spins (results invalid); "
-                           "set NSK_OPT_TRI_SYNC_FREE to 0");
-        }
+        int ei = 0;
+        NSK_HIP(hipMemcpy(&ei, T->sf_err.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (ei) NSK_HIP(hipMemset(T->sf_err.p, 0, sizeof(int)));
+        e |= ei;
       }
+    if (ctx.comm.active() && sync_free_mode > 0) {
+      const int sl = ctx.alloc_slots(1);
+      vec_set(s(), 1, ctx.slot(sl), e ? 1.0 : 0.0);
+      ctx.comm.allreduce_sum(ctx.slot(sl), 1, s());
+      e = ctx.read_slots(sl, 1)[0] > 0.0;
+      ctx.slot_top = sl;
+    }
+    if (e)
+      throw Error(-70, "sync-free triangular solve: a producer/consumer wait ran out of spins (results invalid); "
+                       "set NSK_OPT_TRI_SYNC_FREE to 0");
   }
   void schur_symbolic();
   void setup(int type, int variant_, double alpha_);
@@ -470,9 +480,7 @@ nsk_handle nsk_create(int rank, int nranks, int device_id, const void *uid) {
   try {
     h->ctx.init(device_id);
     h->ctx.comm.init(rank, nranks, uid);
-    // a rank-local fallback from the single-launch triangular solves would desynchronise the ranks'
-    // collectives, so several ranks default to one launch per level
-    if (nranks > 1) h->sync_free_mode = 0;
+
   } catch (const std::exception &e) {
     fprintf(stderr, "nsk_create: %s\n", e.what());
     delete h;
@@ -655,7 +663,7 @@ int nsk_solve(nsk_handle h, int solver, double tol, int max_iter, const double *
   int rc = nsk_upload_system(h, ru, rp, xu, xp);
   if (rc < 0) return rc;
   int rs = nsk_solve_resident(h, solver, tol, max_iter, iters, final_res);
-  if (rs == -70 && h->ctx.comm.nranks == 1) {
+  if (rs == -70) {  // the error is agreed on by all ranks (check_sync_free), so every rank retries
     // the single-launch triangular solves gave up on a hand-off: fall back to one launch per level and redo the
     // solve from the caller's initial guess (a fresh preconditioner object: stale inner state must not leak)
     nsk_set_option(h, NSK_OPT_TRI_SYNC_FREE, 0.0);
