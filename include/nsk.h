@@ -71,7 +71,7 @@ enum {
   NSK_OPT_TRI_SYNC_FREE = 9,  /* multicolour triangular solves with ONE launch per half: rows wait in-kernel for the entries
                                  they depend on (bounded spins on a sentinel-filled vector, see nsk_kernels.h).
                                  0: off (one launch per level); 1 (default): scalar factors (S, Mp); 2: also the 2x2-blocked
-                                 velocity factor.  If a wait ever runs out, nsk_solve falls back to 0 and redoes the solve;
+                                 velocity factor; 3: test hook (wrong order in the upper half).  If a wait ever runs out, nsk_solve falls back to 0 and redoes the solve;
                                  nsk_solve_resident returns -70 */
   NSK_OPT_TRI_X_LAYOUT = 6    /* multicolour triangular solves: 0 (default) work in the caller's DoF order,
                                  1 work on an internal colour-ordered vector */
@@ -83,6 +83,7 @@ typedef struct {
   double spmv_bytes, tri_bytes, blas1_bytes; /* algorithmic bytes moved (SURVEY 8d formulas) */
   int32_t n_colors_u, n_levels_u, n_colors_p, n_levels_p;
   int64_t nnz_s;
+  int64_t sync_free_fallbacks; /* times nsk_solve fell back to per-level launches */
 } nsk_stats;
 
 /* 128-byte RCCL unique id, produced on rank 0 and distributed by the caller (e.g. MPI_Bcast). */

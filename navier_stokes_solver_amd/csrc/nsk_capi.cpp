@@ -76,6 +76,7 @@ struct nsk_handle_s {
   int tri_ordering = ORDER_MULTICOLOR, subdomains = 1, fuse_block_row = 1, use_stream = 1;
   bool inner_fused_gs = true, outer_fused_gs = false;
   int use_bsr = 1;
+  int sync_free_fallbacks = 0;
   int sync_free_mode = 1;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
   DBuf<int> jrow_blk, jblk_blk;  // row runs of the fused (F | Bt) block row: CSR and blocked variants
   int jrow_nblk = 0, jblk_nblk = 0;
@@ -274,7 +275,8 @@ void H::setup(int type, int variant_, double alpha_) {
   if (type < 0 || type > 2) throw Error(-44, "Invalid preconditioner type. Use 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE.");
   ensure_pools();
   tMp.sync_free = tS.sync_free = sync_free_mode >= 1;
-  tF.sync_free = sync_free_mode >= 2;
+  tF.sync_free = sync_free_mode == 2;
+  tMp.sf_fault = tS.sf_fault = sync_free_mode == 3;
   const double t0 = wall_ms();
   prec_type = type;
   variant = variant_;
@@ -604,7 +606,8 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
     case NSK_OPT_TRI_SYNC_FREE:
       h->sync_free_mode = (int)v;
       h->tMp.sync_free = h->tS.sync_free = v >= 1.0;
-      h->tF.sync_free = v >= 2.0;
+      h->tF.sync_free = v == 2.0;
+      h->tMp.sf_fault = h->tS.sf_fault = v == 3.0;  // 3: fault injection for the tests (consumers before producers)
       break;
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
     case NSK_OPT_TRI_X_LAYOUT:
@@ -667,6 +670,7 @@ int nsk_solve(nsk_handle h, int solver, double tol, int max_iter, const double *
     // the single-launch triangular solves gave up on a hand-off: fall back to one launch per level and redo the
     // solve from the caller's initial guess (a fresh preconditioner object: stale inner state must not leak)
     nsk_set_option(h, NSK_OPT_TRI_SYNC_FREE, 0.0);
+    h->sync_free_fallbacks++;
     rc = nsk_setup_preconditioner(h, h->prec_type, h->variant, h->alpha);
     if (rc < 0) return rc;
     rc = nsk_upload_system(h, ru, rp, xu, xp);
@@ -828,6 +832,7 @@ int nsk_get_stats(nsk_handle h, nsk_stats *o) {
   o->n_colors_p = h->tP ? h->tP->n_colors : 0;
   o->n_levels_p = h->tP ? h->tP->n_levels_L : 0;
   o->nnz_s = h->blk[NSK_BLK_S].present ? h->blk[NSK_BLK_S].nnz : 0;
+  o->sync_free_fallbacks = h->sync_free_fallbacks;
   return 0;
   NSK_CATCH(h)
 }

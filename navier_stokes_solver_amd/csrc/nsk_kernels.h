@@ -168,8 +168,8 @@ void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra);
 // starts first; every spin is bounded and raises *err instead of hanging.
 void vec_fill_sentinel(hipStream_t s, int n, double *y);
 void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int n_blocks, int lower, int kind, int run_nnz,
-                         const double *dinv, const int *perm, const double *rhs, const double *own, double *w,
-                         int *err);
+                         int wrong_order /* test hook */, const double *dinv, const int *perm, const double *rhs,
+                         const double *own, double *w, int *err);
 void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int n_blocks, int lower, int kind, const double *intra,
                       const int *permn, const double *rhs, const double *own, double *w, int *err);
 

@@ -470,7 +470,12 @@ __device__ __forceinline__ double sf_wait(const double *p, unsigned long long fi
   unsigned long long v = first;
   int spins = 0;
   while (v == kSentinel) {
-    if (++spins > kMaxSpins) { *err = 1; break; }
+    // once any wait has given up, nobody waits any more: the solve then finishes quickly on garbage (NaNs
+    // end the Krylov loops) and the host reports the error, instead of timing out again and again
+    if (++spins > kMaxSpins || ((spins & 1023) == 1 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
     __builtin_amdgcn_s_sleep(1);
     v = sf_load(p);
   }
@@ -478,14 +483,17 @@ __device__ __forceinline__ double sf_wait(const double *p, unsigned long long fi
 }
 
 template <int LOWER, int KIND, int NNZ>
-__global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, const double *__restrict__ dinv,
+__global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, int wrong_order,
+                                                            const double *__restrict__ dinv,
                                                             const int *__restrict__ perm,
                                                             const double *__restrict__ rhs,
                                                             const double *__restrict__ ownv, double *w, int *err) {
   __shared__ double prod[NNZ];
   // dependency order: lower = ascending runs, upper = descending runs (no XCD remap: producers must be
   // in workgroups the dispatcher has already started)
-  const int blk = LOWER ? (int)blockIdx.x : nb - 1 - (int)blockIdx.x;
+  // wrong_order (test hook): run the upper half in ascending order, i.e. consumers before their producers,
+  // to exercise the bounded-spin / fallback path
+  const int blk = (LOWER || wrong_order) ? (int)blockIdx.x : nb - 1 - (int)blockIdx.x;
   const int4 d = M.desc[blk];
   const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
   const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
@@ -1019,10 +1027,11 @@ void vec_fill_sentinel(hipStream_t s, int n, double *y) {
   unsigned long long *p = reinterpret_cast<unsigned long long *>(y);
   NSK_EW(n, [=] __device__(int i) { p[i] = kSentinel; });
 }
-void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int kind, int run_nnz, const double *dinv,
-                         const int *perm, const double *rhs, const double *own, double *w, int *err) {
+void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int kind, int run_nnz, int wrong_order,
+                         const double *dinv, const int *perm, const double *rhs, const double *own, double *w,
+                         int *err) {
   if (nb <= 0) return;
-#define NSK_SF(L, K, N) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N>), dim3(nb), dim3(BLK), 0, s, M, nb, dinv, perm, rhs, own, w, err)
+#define NSK_SF(L, K, N) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, dinv, perm, rhs, own, w, err)
 #define NSK_SFN(L, K)                                      \
   do {                                                     \
     if (run_nnz <= 512) NSK_SF(L, K, 512);                 \

@@ -441,9 +441,9 @@ void TriSolve::apply(const double *b, double *x) {
       tri_blk_syncfree(s, U, UB[n_colors], 0, kind, intra.p, permn.p, nullptr, y.p, x, sf_err.p);
     } else {
       const TriHalf L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
-      tri_stream_syncfree(s, L, LB[n_colors], 1, kind, run_nnz, dinv.p, d_perm.p, b, nullptr, y.p, sf_err.p);
+      tri_stream_syncfree(s, L, LB[n_colors], 1, kind, run_nnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, sf_err.p);
       vec_fill_sentinel(s, n, x);
-      tri_stream_syncfree(s, U, UB[n_colors], 0, kind, run_nnz, dinv.p, d_perm.p, nullptr, y.p, x, sf_err.p);
+      tri_stream_syncfree(s, U, UB[n_colors], 0, kind, run_nnz, sf_fault ? 1 : 0, dinv.p, d_perm.p, nullptr, y.p, x, sf_err.p);
     }
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();

@@ -44,7 +44,7 @@ class Stats(C.Structure):
                 ("reductions", C.c_int64), ("host_syncs", C.c_int64),
                 ("spmv_bytes", C.c_double), ("tri_bytes", C.c_double), ("blas1_bytes", C.c_double),
                 ("n_colors_u", C.c_int32), ("n_levels_u", C.c_int32), ("n_colors_p", C.c_int32),
-                ("n_levels_p", C.c_int32), ("nnz_s", C.c_int64)]
+                ("n_levels_p", C.c_int32), ("nnz_s", C.c_int64), ("sync_free_fallbacks", C.c_int64)]
 
 
 class NoConvergence(RuntimeError):

@@ -77,6 +77,31 @@ def test_single_launch_and_per_level_pressure_solves_agree(big):
         assert np.abs(out[k][1] - out[0][1]).max() <= 1e-12 * np.abs(out[0][1]).max()
 
 
+def test_sync_free_timeout_falls_back(big):
+    """Fault injection: the upper half of the single-launch ILU(S) solve runs its workgroups in the wrong
+    order, so consumers wait for producers that are not scheduled yet.  The bounded spins must give up (no
+    hang), nsk_solve_resident must report -70, and nsk_solve must fall back to per-level launches by itself."""
+    import time
+    pr, ls, S = big
+    ls.set_option(S.OPT_TRI_SYNC_FREE, 1)
+    ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+    good = ls.solve(S.FGMRES, 0.0, 1, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    ls.set_option(S.OPT_TRI_SYNC_FREE, 3)
+    ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+    ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="-70"):
+        ls.solve_resident(S.FGMRES, 0.0, 1)
+    assert time.time() - t0 < 120.0
+    ls.set_option(S.OPT_TRI_SYNC_FREE, 3)
+    ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+    before = ls.stats()["sync_free_fallbacks"]
+    xu, xp, its, res, rc = ls.solve(S.FGMRES, 0.0, 1, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    assert ls.stats()["sync_free_fallbacks"] == before + 1 and (its, rc) == (good[2], good[4])
+    assert np.abs(xu - good[0]).max() <= 1e-9 * np.abs(good[0]).max() and abs(res - good[3]) <= 1e-9 * good[3]
+    ls.set_option(S.OPT_TRI_SYNC_FREE, 1)
+
+
 def test_ilu_apply_inverts_its_own_factors(big):
     """x = U^-1 L^-1 b  =>  the multicolour ILU(0) apply is linear and idempotent under refactorisation."""
     pr, ls, S = big
