@@ -463,7 +463,7 @@ __device__ __forceinline__ void sf_store(double *p, double v) {
 // so a non-sentinel value is final wherever it was cached; only a sentinel (possibly a stale line) sends the
 // lane to the agent-scope polling loop below.
 __device__ __forceinline__ unsigned long long sf_peek(const double *p) {
-  return (unsigned long long)__double_as_longlong(*reinterpret_cast<const volatile double *>(p));
+  return (unsigned long long)__double_as_longlong(*p);
 }
 // re-poll until the producer's store is visible; bounded
 __device__ __forceinline__ double sf_wait(const double *p, unsigned long long first, int *err) {
@@ -489,13 +489,14 @@ __global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, i
                                                             const double *__restrict__ rhs,
                                                             const double *__restrict__ ownv, double *w, int *err) {
   __shared__ double prod[NNZ];
-  // dependency order: lower = ascending runs, upper = descending runs (no XCD remap: producers must be
-  // in workgroups the dispatcher has already started)
-  // wrong_order (test hook): run the upper half in ascending order, i.e. consumers before their producers,
-  // to exercise the bounded-spin / fallback path
-  const int blk = (LOWER || wrong_order) ? (int)blockIdx.x : nb - 1 - (int)blockIdx.x;
-  const int4 d = M.desc[blk];
+  // M.desc is in DISPATCH order (TriSolve::sf_dispatch_order): colours in dependency order, so producers
+  // always sit in workgroups the dispatcher has started earlier; inside a colour (padded to a multiple of 8
+  // with empty runs) the runs are dealt so that XCD k works on the k-th eighth of every colour.
+  // wrong_order (test hook): walk the list backwards, i.e. consumers before their producers, to exercise
+  // the bounded-spin / fallback path
+  const int4 d = M.desc[wrong_order ? nb - 1 - (int)blockIdx.x : (int)blockIdx.x];
   const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
+  if (r0 == r1) return;  // padding run
   const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
   const bool have = r < r1;
   int jb = 0, je = 0, i = 0;
@@ -544,9 +545,9 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, const
                                                          const double *__restrict__ ownv, double *x, int *err) {
   __shared__ double p0[kBlkMax];
   __shared__ double p1[kBlkMax];
-  const int blk = LOWER ? (int)blockIdx.x : nb - 1 - (int)blockIdx.x;
-  const int4 d = M.desc[blk];
+  const int4 d = M.desc[blockIdx.x];  // dispatch order, see tri_stream_sf_kernel
   const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
+  if (r0 == r1) return;  // padding run
   const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
   const bool have = r < r1;
   int jb = 0, je = 0;
@@ -576,8 +577,10 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, const
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      g0[u] = m[u] >= 0 ? sf_peek(x + 2 * (size_t)m[u]) : 0ull;
-      g1[u] = m[u] >= 0 ? sf_peek(x + 2 * (size_t)m[u] + 1) : 0ull;
+      // one cached 16-byte look at both components of the node
+      const double2 t = m[u] >= 0 ? *reinterpret_cast<const double2 *>(x + 2 * (size_t)m[u]) : make_double2(0.0, 0.0);
+      g0[u] = (unsigned long long)__double_as_longlong(t.x);
+      g1[u] = (unsigned long long)__double_as_longlong(t.y);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {

@@ -67,6 +67,28 @@ int greedy_color(int nv, const std::vector<int> &grp, const std::vector<int> &gc
 }
 }  // namespace
 
+// Dispatch order for the single-launch (sync-free) kernels.  Workgroup b of a grid lands on XCD b % 8 and
+// workgroups start in index order.  Colours follow each other in dependency order (ascending for the lower
+// half, descending for the upper half), each padded with empty runs to a multiple of 8, and inside a colour
+// position 8 q + k holds the colour's run k * per + q: XCD k then owns the k-th eighth of every colour, i.e.
+// the same slice of the lattice colour after colour, so most gathers find lines its own L2 already holds
+// (and values produced on the same XCD are read back without polling).
+static std::vector<int4> sf_dispatch_order(const std::vector<int4> &desc, const std::vector<int> &first, bool lower) {
+  const int nc = (int)first.size() - 1;
+  std::vector<int4> out;
+  out.reserve(desc.size() + 8 * (size_t)nc);
+  for (int cc = 0; cc < nc; ++cc) {
+    const int c = lower ? cc : nc - 1 - cc;
+    const int b0 = first[c], nb = first[c + 1] - first[c];
+    const int per = (nb + 7) / 8;
+    for (int p = 0; p < 8 * per; ++p) {
+      const int logical = (p & 7) * per + (p >> 3);
+      out.push_back(logical < nb ? desc[(size_t)b0 + logical] : make_int4(0, 0, 0, 0));
+    }
+  }
+  return out;
+}
+
 void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off,
                        bool want_block2) {
   ctx = c;
@@ -317,8 +339,12 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
         for (size_t b = 0; b + 1 < blk.size(); ++b) d[b] = make_int4(blk[b], blk[b + 1], rp_[blk[b]], rp_[blk[b + 1]]);
         return d;
       };
-      Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Ldesc.upload(make_desc(lb, lrp), s);
-      Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Udesc.upload(make_desc(ub, urp), s);
+      const std::vector<int4> ld = make_desc(lb, lrp), ud = make_desc(ub, urp);
+      const std::vector<int4> lsf = sf_dispatch_order(ld, LB, true), usf = sf_dispatch_order(ud, UB, false);
+      n_Lsf = (int)lsf.size();
+      n_Usf = (int)usf.size();
+      Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Ldesc.upload(ld, s); Lsf.upload(lsf, s);
+      Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Udesc.upload(ud, s); Usf.upload(usf, s);
       permn.upload(hpermn, s);
       intra_src.upload(isrc, s);
       Lval.alloc((size_t)nnzL);
@@ -376,8 +402,12 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
         for (size_t b = 0; b + 1 < blk.size(); ++b) d[b] = make_int4(blk[b], blk[b + 1], rp_[blk[b]], rp_[blk[b + 1]]);
         return d;
       };
-      Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Ldesc.upload(make_desc(lb, lrp), s);
-      Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Udesc.upload(make_desc(ub, urp), s);
+      const std::vector<int4> ld = make_desc(lb, lrp), ud = make_desc(ub, urp);
+      const std::vector<int4> lsf = sf_dispatch_order(ld, LB, true), usf = sf_dispatch_order(ud, UB, false);
+      n_Lsf = (int)lsf.size();
+      n_Usf = (int)usf.size();
+      Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Ldesc.upload(ld, s); Lsf.upload(lsf, s);
+      Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Udesc.upload(ud, s); Usf.upload(usf, s);
       Lval.alloc((size_t)nnzL);
       Uval.alloc((size_t)nnzU);
       dinv.alloc((size_t)n);
@@ -435,15 +465,15 @@ void TriSolve::apply(const double *b, double *x) {
     // lower half into y (pre-filled with the sentinel), upper half into x; each half is ONE launch
     vec_fill_sentinel(s, n, y.p);
     if (block2_ready) {
-      const TriBlk L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
-      tri_blk_syncfree(s, L, LB[n_colors], 1, kind, intra.p, permn.p, b, nullptr, y.p, sf_err.p);
+      const TriBlk L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
+      tri_blk_syncfree(s, L, n_Lsf, 1, kind, intra.p, permn.p, b, nullptr, y.p, sf_err.p);
       vec_fill_sentinel(s, n, x);
-      tri_blk_syncfree(s, U, UB[n_colors], 0, kind, intra.p, permn.p, nullptr, y.p, x, sf_err.p);
+      tri_blk_syncfree(s, U, n_Usf, 0, kind, intra.p, permn.p, nullptr, y.p, x, sf_err.p);
     } else {
-      const TriHalf L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
-      tri_stream_syncfree(s, L, LB[n_colors], 1, kind, run_nnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, sf_err.p);
+      const TriHalf L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
+      tri_stream_syncfree(s, L, n_Lsf, 1, kind, run_nnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, sf_err.p);
       vec_fill_sentinel(s, n, x);
-      tri_stream_syncfree(s, U, UB[n_colors], 0, kind, run_nnz, sf_fault ? 1 : 0, dinv.p, d_perm.p, nullptr, y.p, x, sf_err.p);
+      tri_stream_syncfree(s, U, n_Usf, 0, kind, run_nnz, sf_fault ? 1 : 0, dinv.p, d_perm.p, nullptr, y.p, x, sf_err.p);
     }
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();

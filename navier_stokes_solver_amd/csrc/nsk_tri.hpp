@@ -48,6 +48,8 @@ struct TriSolve {
   int x_layout = 0;  // 0: solve in the caller's (lattice) order; 1: internal colour-ordered vector
   DBuf<int> Lrp, Lcol, Lsrc, Urp, Ucol, Usrc;
   DBuf<int4> Ldesc, Udesc;
+  DBuf<int4> Lsf, Usf;     // the same runs in the dispatch order of the single-launch kernels
+  int n_Lsf = 0, n_Usf = 0;
   DBuf<double> Lval, Uval, dinv;
   std::vector<int> LB, UB;  // per colour: first workgroup of that colour in Lblk / Ublk (n_colors + 1)
   int64_t nnzL = 0, nnzU = 0;

@@ -11,7 +11,7 @@ ls = S.LinearSolver()
 ls.set_option(S.OPT_TRI_ORDERING, 1)
 ls.set_problem(pr)
 ls.setup_preconditioner(2, 0, 0.5)
-for op in (31, 30, 0, 5, 20):
+for op in (31, 30, 0, 5, 20, 21):
     ms, by = ls.time_op(op, 3)
     print(op, ms, by)
 ls.close()
