@@ -99,7 +99,11 @@ def main():
         # torch.distributed.run pins OMP_NUM_THREADS=1; the host-side hand-off generation and the one-off
         # symbolic analysis are OpenMP loops, so give every rank its share of the cores (set before any
         # OpenMP runtime is loaded)
-        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // world))
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cores = os.cpu_count() or 1
+        os.environ["OMP_NUM_THREADS"] = str(max(1, min(32, cores // world)))
     import numpy as np
     import torch
     import torch.distributed as dist

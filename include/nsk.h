@@ -73,6 +73,9 @@ enum {
                                  0: off (one launch per level); 1 (default): scalar factors (S, Mp); 2: also the 2x2-blocked
                                  velocity factor; 3: test hook (wrong order in the upper half).  If a wait ever runs out, nsk_solve falls back to 0 and redoes the solve;
                                  nsk_solve_resident returns -70 */
+  NSK_OPT_VELOCITY_AMG = 10,  /* stationary blockTriangular: 1 (default) precondition F with the smoothed-aggregation AMG
+                                 V-cycle (the reference configures TrilinosWrappers::PreconditionAMG there,
+                                 NSSolverStationary.hpp:225,231); 0: ILU(0), as the unsteady variant does */
   NSK_OPT_TRI_X_LAYOUT = 6    /* multicolour triangular solves: 0 (default) work in the caller's DoF order,
                                  1 work on an internal colour-ordered vector */
 };
@@ -138,8 +141,13 @@ int nsk_spmv(nsk_handle h, int blk, const double *x_owned, double *y, int add);
 int nsk_jacobian_vmult(nsk_handle h, const double *x_u, const double *x_p, double *y_u, double *y_p);
 /* dot(x,y) and ||x||_2 over the owned entries of all ranks */
 int nsk_dot(nsk_handle h, int n, const double *x, const double *y, double *dot_out, double *norm_x_out);
-/* x = M^-1 b with the velocity / pressure triangular preconditioner of the current setup */
+/* x = M^-1 b with the velocity / pressure preconditioner of the current setup (triangular solves, or one AMG
+ * V-cycle for the velocity block of the stationary blockTriangular setup) */
 int nsk_tri_apply(nsk_handle h, int which, const double *b, double *x);
+/* Hierarchy of the velocity AMG of the current setup (replaces TrilinosWrappers::PreconditionAMG,
+ * NSSolverStationary.hpp:225): returns the number of levels of sub-domain `shard` (0 when the setup has no AMG)
+ * and, for a valid `level`, its size, non-zeros and the lambda_max(D^-1 A) estimate the smoother uses. */
+int nsk_amg_info(nsk_handle h, int shard, int level, int64_t *rows, int64_t *nnz, double *lambda_max);
 /* ordering used by that triangular preconditioner: perm[new] = old (identity when natural) */
 int nsk_tri_get_perm(nsk_handle h, int which, int32_t *perm);
 /* preconditioner.vmult(dst, src), applied `calls` times on the same object; dst is in/out */

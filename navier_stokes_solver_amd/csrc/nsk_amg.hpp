@@ -1,0 +1,67 @@
+// nsk_amg.hpp — smoothed-aggregation AMG V-cycle for the velocity block.
+//
+// Replaces TrilinosWrappers::PreconditionAMG (Trilinos ML) as configured by the reference's stationary
+// block-triangular preconditioner: `preconditioner_velocity.initialize(*velocity_stiffness)` with the
+// deal.II default AdditionalData (lab_new/src/NSSolverStationary.hpp:225,231).  ML's aggregates cannot be
+// reproduced bit for bit (its source is the only specification), so this is the same METHOD under the
+// same parameters — see DESIGN.md "AMG" for the deterministic details both this file and the oracle follow:
+//   uncoupled greedy aggregation (strength threshold 1e-4), one constant near-null-space vector,
+//   prolongator smoothing (I - 4/3 / lambda D^-1 A), R = P^T, Galerkin R A P, <= 10 levels,
+//   coarsest level (<= 128 unknowns) solved directly, V(1,1) cycle with a degree-2 Chebyshev polynomial in
+//   D^-1 A (eigenvalue ratio 20), lambda = 1.1 x (10 power iterations).
+// Rank-local like every preconditioner of the reference's stack under additive Schwarz with overlap 0:
+// ghost columns are dropped (block Jacobi across ranks / sub-domains).
+//
+// Set-up runs on the host (OpenMP) from a copy of the block's values; the cycle runs on the device with
+// the library's CSR-stream SpMV kernels.
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "nsk_core.hpp"
+
+namespace nsk {
+
+struct HostCsr {
+  int n_rows = 0, n_cols = 0;
+  std::vector<int> rp, col;
+  std::vector<double> val;
+};
+
+struct AmgLevel {
+  int n = 0;
+  Csr own_A;          // this level's operator when it is not the caller's block itself
+  Csr *A = nullptr;   // -> own_A, or the caller's F (level 0 of a single shard without ghost columns)
+  Csr P, R;
+  bool has_coarse = false;
+  double lam = 1.0;
+  DBuf<double> dinv, inv, x, b, r, w;
+};
+
+struct AmgHierarchy {
+  int offset = 0;  // first row of this shard in the caller's vector
+  std::vector<std::unique_ptr<AmgLevel>> lev;
+};
+
+struct Amg {
+  Ctx *ctx = nullptr;
+  std::vector<AmgHierarchy> shards;
+  double setup_host_ms = 0;
+  // F: device block with host pattern; shard_off: empty = one shard
+  void setup(Ctx *ctx, Csr &F, const std::vector<int> &shard_off);
+  void apply(const double *b, double *x);
+  void clear() { shards.clear(); }
+  int n_levels(int shard = 0) const { return shards.empty() ? 0 : (int)shards[shard].lev.size(); }
+  int level_rows(int shard, int l) const { return shards[shard].lev[l]->n; }
+  int64_t level_nnz(int shard, int l) const { return shards[shard].lev[l]->A->nnz; }
+  double level_lambda(int shard, int l) const { return shards[shard].lev[l]->lam; }
+  size_t apply_bytes() const;  // algorithmic bytes of one V-cycle (SURVEY 8d formulas)
+
+ private:
+  void build(AmgHierarchy &H, HostCsr &&A0, Csr *alias);
+  void cheby(AmgLevel &L, const double *b, double *x, bool zero_init);
+  void vcycle(AmgHierarchy &H, int l, const double *b, double *x);
+  void mv(Csr &A, const double *x, double *y, int mode = 0, const double *z = nullptr);
+};
+
+}  // namespace nsk

@@ -14,6 +14,7 @@
 
 #include "../../include/nsk.h"
 #include "nsk_solver.hpp"
+#include "nsk_amg.hpp"
 #include "nsk_tri.hpp"
 
 using namespace nsk;
@@ -85,6 +86,9 @@ struct nsk_handle_s {
   int prec_type = -1, variant = 0;
   double alpha = 0.5;
   TriSolve tF, tMp, tS;
+  Amg amgF;                 // velocity AMG of the stationary block-triangular preconditioner
+  int velocity_amg = 1;     // NSK_OPT_VELOCITY_AMG
+  bool amg_active = false;  // the current setup preconditions F with amgF instead of tF
   bool tF_ok = false, tMp_ok = false, tS_ok = false, s_symbolic = false;
   int tF_key = -1, tMp_key = -1, tS_key = -1;
   TriSolve *tP = nullptr;
@@ -286,13 +290,20 @@ void H::setup(int type, int variant_, double alpha_) {
   // kinds: blockDiagonal stationary = SSOR/SSOR, unsteady = ILU/ILU; blockTriangular = (AMG->ILU)/ILU; aSIMPLE = ILU/ILU
   const int kindF = (type == 0 && variant == 0) ? 1 : 0;
   const int kindP = (type == 0 && variant == 0) ? 1 : 0;
-  if (!tF_ok || tF_key != key) {
-    tF.analyze(&ctx, F, kindF, tri_ordering, sub_offsets(0), use_bsr && F.blk_ok && F.blk_R == 2 && F.blk_C == 2);
-    tF_ok = true;
-    tF_key = key;
+  // PreconditionBlockTriangular, stationary: preconditioner_velocity is an AMG (NSSolverStationary.hpp:225,231)
+  amg_active = type == 1 && variant == 0 && velocity_amg != 0;
+  if (amg_active) {
+    amgF.setup(&ctx, F, sub_offsets(0));
+  } else {
+    amgF.clear();
+    if (!tF_ok || tF_key != key) {
+      tF.analyze(&ctx, F, kindF, tri_ordering, sub_offsets(0), use_bsr && F.blk_ok && F.blk_R == 2 && F.blk_C == 2);
+      tF_ok = true;
+      tF_key = key;
+    }
+    tF.kind = kindF;
+    tF.numeric(F.val.p);
   }
-  tF.kind = kindF;
-  tF.numeric(F.val.p);
   if (type == 2) {
     if (!s_symbolic) schur_symbolic();
     if (!D) { D = pool_u.get(true); Dinv = pool_u.get(true); tmp_u = pool_u.get(true); }
@@ -339,7 +350,10 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
   const DVec su = ub(src.own), spv = pb(src.own);
   const int nu = n_u(), np = n_p();
   MatVec A_F = [&](const DVec &x, double *y) { halo(0, x); spmv_nohalo(F, x, y); };
-  PrecVmult P_F = [&](DVec &d, const DVec &r) { tri_apply_sampled(tF, 20, r.own, d.own); };
+  PrecVmult P_F = [&](DVec &d, const DVec &r) {
+    if (amg_active) amgF.apply(r.own, d.own);
+    else tri_apply_sampled(tF, 20, r.own, d.own);
+  };
   PrecVmult P_P = [&](DVec &d, const DVec &r) { tri_apply_sampled(*tP, 21, r.own, d.own); };
   const int sl = ctx.alloc_slots(4);
   struct Rel { Ctx &c; int sl; ~Rel() { c.slot_top = sl; } } rel{ctx, sl};
@@ -610,6 +624,7 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
       h->tMp.sf_fault = h->tS.sf_fault = v == 3.0;  // 3: fault injection for the tests (consumers before producers)
       break;
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
+    case NSK_OPT_VELOCITY_AMG: h->velocity_amg = v != 0.0; break;
     case NSK_OPT_TRI_X_LAYOUT:
       h->tF.x_layout = h->tMp.x_layout = h->tS.x_layout = v != 0.0;
       h->tF_ok = h->tMp_ok = h->tS_ok = false;
@@ -746,7 +761,8 @@ int nsk_tri_apply(nsk_handle h, int which, const double *b, double *x) {
   VecPool &p = which == NSK_TRI_VELOCITY ? h->pool_u : h->pool_p;
   double *bv = p.get(true), *xv = p.get(true);
   NSK_HIP(hipMemcpyAsync(bv, b, sizeof(double) * (size_t)p.n, hipMemcpyHostToDevice, h->s()));
-  T->apply(bv, xv);
+  if (which == NSK_TRI_VELOCITY && h->amg_active) h->amgF.apply(bv, xv);  // the velocity preconditioner is the AMG
+  else T->apply(bv, xv);
   NSK_HIP(hipMemcpyAsync(x, xv, sizeof(double) * (size_t)p.n, hipMemcpyDeviceToHost, h->s()));
   h->ctx.sync();
   p.put(bv);
@@ -756,10 +772,27 @@ int nsk_tri_apply(nsk_handle h, int which, const double *b, double *x) {
   NSK_CATCH(h)
 }
 
+int nsk_amg_info(nsk_handle h, int shard, int level, int64_t *rows, int64_t *nnz, double *lambda_max) {
+  NSK_TRY(h)
+  if (!h->amg_active || shard < 0 || shard >= (int)h->amgF.shards.size()) return 0;
+  const int nl = h->amgF.n_levels(shard);
+  if (level >= 0 && level < nl) {
+    if (rows) *rows = h->amgF.level_rows(shard, level);
+    if (nnz) *nnz = h->amgF.level_nnz(shard, level);
+    if (lambda_max) *lambda_max = h->amgF.level_lambda(shard, level);
+  }
+  return nl;
+  NSK_CATCH(h)
+}
+
 int nsk_tri_get_perm(nsk_handle h, int which, int32_t *perm) {
   NSK_TRY(h)
   if (h->prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
   TriSolve *T = which == NSK_TRI_VELOCITY ? &h->tF : h->tP;
+  if (which == NSK_TRI_VELOCITY && h->amg_active) {  // no triangular factor in this setup
+    for (int i = 0; i < h->n_u(); ++i) perm[i] = i;
+    return 0;
+  }
   for (int i = 0; i < T->n; ++i) perm[i] = T->perm.empty() ? i : T->perm[i];
   return 0;
   NSK_CATCH(h)

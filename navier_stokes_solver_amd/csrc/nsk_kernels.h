@@ -84,6 +84,10 @@ void vec_mul(hipStream_t s, int n, const double *d, double *y);                 
 void vec_submul(hipStream_t s, int n, const double *d, const double *x, double *y);     // y -= d .* x
 void vec_sub_then_mul(hipStream_t s, int n, const double *x, const double *d, double *y);  // y = (y - x) .* d
 void vec_recip(hipStream_t s, int n, const double *x, double *y);                       // y = 1 / x
+// Chebyshev smoother step: w = c1 w + c2 dinv .* r ; x = set_x ? w : x + w   (w is not read when c1 == 0)
+void vec_cheby_step(hipStream_t s, int n, double c1, double c2, const double *dinv, const double *r, double *w,
+                    double *x, int set_x);
+void dense_mv(hipStream_t s, int n, const double *M, const double *b, double *x);       // x = M b, M n x n row-major
 // reductions: results land in out[0] (and out[1] = sqrt(out[0]) when want_sqrt)
 void vec_dot(hipStream_t s, const ReduceWs &ws, int n, const double *x, const double *y, double *out, int want_sqrt);
 // y += a x ; out = y . w  (w may alias y)  — deal.II add_and_dot, one pass

@@ -1022,6 +1022,29 @@ void vec_sub_then_mul(hipStream_t s, int n, const double *x, const double *d, do
 void vec_recip(hipStream_t s, int n, const double *x, double *y) {
   NSK_EW(n, [=] __device__(int i) { y[i] = 1.0 / x[i]; });
 }
+void vec_cheby_step(hipStream_t s, int n, double c1, double c2, const double *dinv, const double *r, double *w,
+                    double *x, int set_x) {
+  NSK_EW(n, [=] __device__(int i) {
+    const double wi = (c1 != 0.0 ? c1 * w[i] : 0.0) + c2 * dinv[i] * r[i];
+    w[i] = wi;
+    x[i] = set_x ? wi : x[i] + wi;
+  });
+}
+
+// x = M b for a small dense row-major matrix (coarsest AMG level): one wavefront per row
+__global__ __launch_bounds__(BLK) void dense_mv_kernel(int n, const double *__restrict__ M, const double *__restrict__ b,
+                                                       double *__restrict__ x) {
+  const int row = (int)(blockIdx.x * (BLK / 64) + threadIdx.x / 64), lane = threadIdx.x % 64;
+  double sum = 0.0;
+  if (row < n)
+    for (int j = lane; j < n; j += 64) sum += M[(size_t)row * n + j] * b[j];
+  sum = subwave_sum<64>(sum);
+  if (row < n && lane == 0) x[row] = sum;
+}
+void dense_mv(hipStream_t s, int n, const double *M, const double *b, double *x) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(dense_mv_kernel, dim3((n + BLK / 64 - 1) / (BLK / 64)), dim3(BLK), 0, s, n, M, b, x);
+}
 void scalar_sqrt(hipStream_t s, const double *in, double *out) {
   const int n = 1;
   NSK_EW(n, [=] __device__(int) { out[0] = sqrt(fabs(in[0])); });

@@ -26,13 +26,14 @@ TRI_VELOCITY, TRI_PRESSURE = 0, 1
 OPT_TRI_ORDERING, OPT_SUBDOMAINS, OPT_FUSE_BLOCK_ROW, OPT_STREAM_KERNELS = 0, 1, 2, 3
 OPT_INNER_FUSED_GS, OPT_OUTER_FUSED_GS, OPT_TRI_X_LAYOUT, OPT_BSR_VELOCITY, OPT_TRI_RUN_NNZ = 4, 5, 6, 7, 8
 OPT_TRI_SYNC_FREE = 9
+OPT_VELOCITY_AMG = 10
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
 
 EXPORTS = [
     "nsk_get_unique_id", "nsk_local_group_id", "nsk_create", "nsk_destroy", "nsk_last_error", "nsk_set_partition", "nsk_set_halo_plan",
     "nsk_set_block_csr", "nsk_update_values", "nsk_set_option", "nsk_setup_preconditioner", "nsk_solve",
     "nsk_upload_system", "nsk_solve_resident", "nsk_download_solution", "nsk_spmv", "nsk_jacobian_vmult", "nsk_dot",
-    "nsk_tri_apply", "nsk_tri_get_perm", "nsk_precond_vmult", "nsk_block_nnz", "nsk_get_block", "nsk_get_stats",
+    "nsk_tri_apply", "nsk_amg_info", "nsk_tri_get_perm", "nsk_precond_vmult", "nsk_block_nnz", "nsk_get_block", "nsk_get_stats",
     "nsk_reset_stats", "nsk_time_op", "nsk_profile_begin", "nsk_profile_read", "nsk_profile_end",
 ]
 
@@ -96,6 +97,8 @@ def lib() -> C.CDLL:
         L.nsk_spmv.argtypes = [vp, C.c_int, f64p, f64p, C.c_int]
         L.nsk_jacobian_vmult.argtypes = [vp, f64p, f64p, f64p, f64p]
         L.nsk_dot.argtypes = [vp, C.c_int, f64p, f64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.nsk_amg_info.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_double)]
         L.nsk_tri_apply.argtypes = [vp, C.c_int, f64p, f64p]
         L.nsk_tri_get_perm.argtypes = [vp, C.c_int, i32p]
         L.nsk_precond_vmult.argtypes = [vp, f64p, f64p, f64p, f64p, C.c_int]
@@ -297,6 +300,18 @@ class LinearSolver:
         rp, col, val = np.empty(n_rows + 1, np.int32), np.empty(nnz, np.int32), np.empty(nnz)
         self._ck(self.L.nsk_get_block(self.h, blk, rp.ctypes.data, col.ctypes.data, val.ctypes.data))
         return rp, col, val
+
+    def amg_levels(self, shard=0):
+        """[(rows, nnz, lambda_max)] of the velocity AMG of the current setup ([] when there is none)."""
+        out = []
+        rows, nnz, lam = C.c_int64(), C.c_int64(), C.c_double()
+        nl = self.L.nsk_amg_info(self.h, shard, -1, None, None, None)
+        if nl < 0:
+            self._ck(nl)
+        for l in range(nl):
+            self.L.nsk_amg_info(self.h, shard, l, C.byref(rows), C.byref(nnz), C.byref(lam))
+            out.append((rows.value, nnz.value, lam.value))
+        return out
 
     def stats(self) -> dict:
         st = Stats()

@@ -600,6 +600,7 @@ typedef struct {
   const orc_problem *P;
   const orc_opts *o;
   orc_tri *tF, *tP; /* triangular preconditioners of F and of Mp or S */
+  orc_amg *aF;      /* AMG V-cycle for F (stationary blockTriangular) */
   /* aSIMPLE state */
   int *s_rowptr, *s_col;
   double *s_val;
@@ -610,9 +611,11 @@ typedef struct {
 
 static void op_csr(void *ctx, const double *x, double *y) { orc_spmv((const orc_csr *)ctx, x, y, 0); }
 static int prec_tri(void *ctx, double *dst, const double *src) { orc_tri_apply((const orc_tri *)ctx, src, dst); return 0; }
+static int prec_amg(void *ctx, double *dst, const double *src) { orc_amg_apply((const orc_amg *)ctx, src, dst); return 0; }
 
 static void prec_free(prec_t *pc) {
   orc_tri_free(pc->tF); orc_tri_free(pc->tP);
+  orc_amg_free(pc->aF);
   free(pc->s_rowptr); free(pc->s_col); free(pc->s_val);
   free(pc->D); free(pc->Dinv); free(pc->tmp_p); free(pc->delta_p); free(pc->tmp_u);
 }
@@ -628,9 +631,10 @@ static void prec_setup(prec_t *pc, const orc_problem *P, const orc_opts *o, orc_
     pc->tF = orc_tri_setup(&P->F, kind, P->n_shards, P->u_shard_off, P->perm_F);
     pc->tP = orc_tri_setup(&P->Mp, kind, P->n_shards, P->p_shard_off, P->perm_Mp);
   } else if (o->prec == 1) {
-    /* stationary uses ML AMG for F (NSSolverStationary.hpp:225): NOT restated — ILU(0) is
-       substituted, as the unsteady variant itself does (NSSolver.hpp:244). Pressure: ILU. */
-    pc->tF = orc_tri_setup(&P->F, 0, P->n_shards, P->u_shard_off, P->perm_F);
+    /* stationary: AMG for F (NSSolverStationary.hpp:225,231; the smoothed-aggregation V-cycle of
+       nsk_oracle_amg.c stands in for ML); unsteady: ILU(0) (NSSolver.hpp:244). Pressure: ILU. */
+    if (o->variant == 0 && o->velocity_amg) pc->aF = orc_amg_setup(&P->F, P->n_shards, P->u_shard_off);
+    else pc->tF = orc_tri_setup(&P->F, 0, P->n_shards, P->u_shard_off, P->perm_F);
     pc->tP = orc_tri_setup(&P->Mp, 0, P->n_shards, P->p_shard_off, P->perm_Mp);
     pc->tmp_p = (double *)calloc((size_t)np, sizeof(double));
   } else {
@@ -691,7 +695,8 @@ static int prec_vmult(void *ctx, double *dst, const double *src) {
       cu = (control_t){2000001, 1e-4 * orc_norm2(nu, su), 0, 0};
       cp = (control_t){2000000, 1e-5 * orc_norm2(np, sp), 0, 0};
     }
-    rc = solve_fgmres(op_csr, (void *)&P->F, prec_tri, pc->tF, nu, du, su, &cu, uit, NULL);
+    if (pc->aF) rc = solve_fgmres(op_csr, (void *)&P->F, prec_amg, pc->aF, nu, du, su, &cu, uit, NULL);
+    else rc = solve_fgmres(op_csr, (void *)&P->F, prec_tri, pc->tF, nu, du, su, &cu, uit, NULL);
     if (rc) return 3;
     orc_spmv(&P->B, du, pc->tmp_p, 0);         /* tmp = B u */
     v_sadd(np, -1.0, 1.0, sp, pc->tmp_p);      /* tmp = src_p - B u   (tmp.sadd(-1, src_p)) */

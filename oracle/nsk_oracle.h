@@ -59,6 +59,17 @@ void orc_tri_export(const orc_tri *T, int *rowptr, int *col, double *val);
  * Two calls: first with c_col == NULL to obtain nnz via c_rowptr, then fill. */
 void orc_spgemm_adb(const orc_csr *A, const double *d, const orc_csr *B, int *c_rowptr, int *c_col, double *c_val);
 
+/* Smoothed-aggregation AMG V-cycle standing in for TrilinosWrappers::PreconditionAMG (ML) on the velocity
+ * block (NSSolverStationary.hpp:225,231): see nsk_oracle_amg.c.  Rank-local (block Jacobi over shards). */
+typedef struct orc_amg orc_amg;
+orc_amg *orc_amg_setup(const orc_csr *A, int n_shards, const int *shard_off);
+void orc_amg_apply(const orc_amg *M, const double *b, double *x);
+void orc_amg_free(orc_amg *M);
+int orc_amg_levels(const orc_amg *M, int shard);
+int orc_amg_level_rows(const orc_amg *M, int shard, int level);
+long orc_amg_level_nnz(const orc_amg *M, int shard, int level);
+double orc_amg_level_lambda(const orc_amg *M, int shard, int level);
+
 typedef struct {
   int n_u, n_p;
   orc_csr F, Bt, B, Mp;     /* jacobian (0,0) (0,1) (1,0), pressure_mass (1,1); square local parts */
@@ -77,6 +88,8 @@ typedef struct {
   int max_iter;   /* 20000 stationary / 100000 unsteady */
   double tol;     /* absolute */
   double alpha;   /* aSIMPLE damping, 0.5 */
+  int velocity_amg; /* stationary blockTriangular: 1 = AMG V-cycle for F (what the reference configures),
+                       0 = ILU(0) (what the unsteady variant uses) */
 } orc_opts;
 
 typedef struct {

@@ -28,7 +28,7 @@ class Problem(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("solver", C.c_int), ("prec", C.c_int), ("variant", C.c_int), ("max_iter", C.c_int),
-                ("tol", C.c_double), ("alpha", C.c_double)]
+                ("tol", C.c_double), ("alpha", C.c_double), ("velocity_amg", C.c_int)]
 
 
 class Result(C.Structure):
@@ -39,8 +39,8 @@ class Result(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "_build", "libnsk_oracle.so")
-    src = os.path.join(_HERE, "nsk_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("nsk_oracle.c", "nsk_oracle_amg.c", "nsk_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
@@ -61,6 +61,16 @@ def lib() -> C.CDLL:
         L.orc_tri_nnz.argtypes = [C.c_void_p]
         L.orc_tri_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_spgemm_adb.argtypes = [C.POINTER(Csr), C.c_void_p, C.POINTER(Csr), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_amg_setup.restype = C.c_void_p
+        L.orc_amg_setup.argtypes = [C.POINTER(Csr), C.c_int, C.c_void_p]
+        L.orc_amg_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_amg_free.argtypes = [C.c_void_p]
+        L.orc_amg_levels.argtypes = [C.c_void_p, C.c_int]
+        L.orc_amg_level_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_amg_level_nnz.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_amg_level_nnz.restype = C.c_long
+        L.orc_amg_level_lambda.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_amg_level_lambda.restype = C.c_double
         L.orc_solve.argtypes = [C.POINTER(Problem), C.POINTER(Opts), C.c_void_p, C.c_void_p, C.POINTER(Result)]
         L.orc_prec_apply.argtypes = [C.POINTER(Problem), C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_int]
         _LIB = L
@@ -138,6 +148,34 @@ class Tri:
             self.h = None
 
 
+class Amg:
+    """Smoothed-aggregation V-cycle on the diagonal shards of A (stand-in for ML, see nsk_oracle_amg.c)."""
+
+    def __init__(self, A: CsrHolder, shard_off=None):
+        self.A = A
+        self.n = A.n_rows
+        so = _i32(shard_off) if shard_off is not None else None
+        self._keep = so
+        self.h = lib().orc_amg_setup(C.byref(A.c), 0 if so is None else len(so) - 1, None if so is None else so.ctypes.data)
+
+    def apply(self, b):
+        b = _f64(b)
+        x = np.zeros(self.n)
+        lib().orc_amg_apply(self.h, b.ctypes.data, x.ctypes.data)
+        return x
+
+    def levels(self, shard=0):
+        """[(rows, nnz, lambda)] per level of one shard's hierarchy."""
+        L = lib()
+        return [(L.orc_amg_level_rows(self.h, shard, l), L.orc_amg_level_nnz(self.h, shard, l),
+                 L.orc_amg_level_lambda(self.h, shard, l)) for l in range(L.orc_amg_levels(self.h, shard))]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_amg_free(self.h)
+            self.h = None
+
+
 def spgemm_adb(A: CsrHolder, d, B: CsrHolder):
     """C = A diag(d) B with the structural product pattern; returns (rowptr, col, val)."""
     d = _f64(d)
@@ -167,10 +205,10 @@ class OracleProblem:
         return cls(CsrHolder.from_block(pr.F), CsrHolder.from_block(pr.Bt), CsrHolder.from_block(pr.B),
                    CsrHolder.from_block(pr.Mp), **kw)
 
-    def solve(self, rhs, x0, solver=1, prec=0, variant=0, tol=1e-6, max_iter=None, alpha=0.5):
+    def solve(self, rhs, x0, solver=1, prec=0, variant=0, tol=1e-6, max_iter=None, alpha=0.5, velocity_amg=0):
         if max_iter is None:
             max_iter = 20000 if variant == 0 else 100000  # NSSolverStationary.cpp:580 / NSSolver.cpp:604
-        o = Opts(solver, prec, variant, max_iter, tol, alpha)
+        o = Opts(solver, prec, variant, max_iter, tol, alpha, velocity_amg)
         r = Result()
         x = _f64(x0).copy()
         rhs = _f64(rhs)
@@ -178,8 +216,8 @@ class OracleProblem:
         info = {k: getattr(r, k) for k, _ in Result._fields_}
         return x, info
 
-    def prec_apply(self, src, dst0=None, prec=2, variant=0, alpha=0.5, calls=1):
-        o = Opts(1, prec, variant, 0, 0.0, alpha)
+    def prec_apply(self, src, dst0=None, prec=2, variant=0, alpha=0.5, calls=1, velocity_amg=0):
+        o = Opts(1, prec, variant, 0, 0.0, alpha, velocity_amg)
         src = _f64(src)
         dst = np.zeros(self.n_u + self.n_p) if dst0 is None else _f64(dst0).copy()
         rc = lib().orc_prec_apply(C.byref(self.c), C.byref(o), src.ctypes.data, dst.ctypes.data, calls)

@@ -157,7 +157,8 @@ def test_precond_vmult(handles, prec, variant):
     for calls in (1, 2):
         ls.setup_preconditioner(prec, variant, 0.5)  # fresh object, as solve_system() builds one per call
         du, dp, rc = ls.precond_vmult(src[:pr.n_u], src[pr.n_u:], calls=calls)
-        ref, orc = op.prec_apply(src, prec=prec, variant=variant, alpha=0.5, calls=calls)
+        ref, orc = op.prec_apply(src, prec=prec, variant=variant, alpha=0.5, calls=calls,
+                                 velocity_amg=int((prec, variant) == (1, 0)))
         assert rc == 0 and orc == 0
         tol = 1e-10 if (prec == 2 and variant == 1) else 1e-7
         assert rel_err(np.concatenate([du, dp]), ref) <= tol, (prec, variant, calls)
@@ -196,7 +197,9 @@ def test_solve_matches_oracle_and_direct(handles, name, solver, prec, variant, t
     op = O.OracleProblem.from_local(pr, **kw)
     max_iter = 20000 if variant == 0 else 100000
     xu, xp, its, res, rc = ls.solve(solver, tol, max_iter, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
-    xo, info = op.solve(b, x0, solver=solver, prec=prec, variant=variant, tol=tol)
+    # stationary blockTriangular preconditions F with the AMG V-cycle (NSSolverStationary.hpp:225)
+    xo, info = op.solve(b, x0, solver=solver, prec=prec, variant=variant, tol=tol,
+                        velocity_amg=int((prec, variant) == (1, 0)))
     assert rc == 0 and info["status"] == 0
     x = np.concatenate([xu, xp])
     true_res = np.linalg.norm(b - J @ x)
@@ -212,6 +215,39 @@ def test_solve_matches_oracle_and_direct(handles, name, solver, prec, variant, t
     assert rel_err(x, xo) <= 1e-7, (rel_err(x, xo), its, info["iters"])
     assert rel_err(x, xs) <= 1e-7
     assert abs(its - info["iters"]) <= max(3, 0.2 * info["iters"]), (its, info["iters"])
+
+
+@pytest.mark.parametrize("name,subdomains", [("ns16", 1), ("ns60", 1), ("ns60", 3)])
+def test_amg_vcycle_matches_oracle(handles, name, subdomains):
+    """a17: the velocity AMG of the stationary blockTriangular setup (stand-in for ML, NSSolverStationary.hpp:225).
+    Same hierarchy (level sizes, non-zeros, lambda estimates) and the same V-cycle result as the oracle; with
+    sub-domains the hierarchy is built per diagonal block (additive Schwarz, overlap 0)."""
+    S, O = _S(), _O()
+    pr = problem(name)
+    ls = handles(name, 1, subdomains)
+    ls.set_option(S.OPT_VELOCITY_AMG, 1)
+    ls.setup_preconditioner(S.BLOCK_TRIANGULAR, S.STATIONARY)
+    off = None
+    if subdomains > 1:
+        off = np.array([(pr.n_u * k // subdomains) & ~1 for k in range(subdomains)] + [pr.n_u], np.int32)
+    M = O.Amg(O.CsrHolder.from_block(pr.F), off)
+    for shard in range(subdomains):
+        lv, ov = ls.amg_levels(shard), M.levels(shard)
+        assert len(lv) == len(ov) >= 2
+        for (r, z, lam), (orows, onnz, olam) in zip(lv, ov):
+            assert (r, z) == (orows, onnz) and abs(lam - olam) <= 1e-12 * olam
+    b = rng_vec(pr.n_u, 77)
+    x, xo = ls.tri_apply(S.TRI_VELOCITY, b), M.apply(b)
+    assert rel_err(x, xo) <= 1e-11
+    # it is a useful preconditioner: one cycle reduces the residual of F x = b
+    F = pr.F.to_scipy()
+    if subdomains == 1:
+        assert np.linalg.norm(b - F @ x) < 0.8 * np.linalg.norm(b)
+    # option 0 restores ILU(0), what the unsteady variant uses
+    ls.set_option(S.OPT_VELOCITY_AMG, 0)
+    ls.setup_preconditioner(S.BLOCK_TRIANGULAR, S.STATIONARY)
+    assert ls.amg_levels() == []
+    ls.set_option(S.OPT_VELOCITY_AMG, 1)
 
 
 def test_solve_system_raises_like_reference(handles):

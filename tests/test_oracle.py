@@ -99,6 +99,53 @@ def test_fgmres_reaches_the_direct_solution(name, prec, variant):
     assert rel_err(x, xs) <= 1e-8
 
 
+def test_amg_vcycle_properties():
+    """The smoothed-aggregation V-cycle standing in for ML (NSSolverStationary.hpp:225): the Galerkin coarse
+    operator equals P^T A P, the cycle is a LINEAR operator, it contracts the error of F x = b, the coarsest
+    level is small enough for the direct solve, and FGMRES preconditioned with it reaches the direct solution."""
+    pr = problem("ns60")
+    F = pr.F.to_scipy().tocsr()
+    M = O.Amg(O.CsrHolder.from_block(pr.F))
+    lv = M.levels()
+    assert len(lv) >= 3 and lv[0][0] == pr.n_u and lv[-1][0] <= 128
+    assert all(a[0] > 10 * b[0] for a, b in zip(lv, lv[1:]))          # aggressive coarsening (about 37 : 1 on Q3)
+    assert all(1.0 < lam < 4.0 for _, _, lam in lv)                     # lambda_max(D^-1 A) of an FE operator
+    a, b = rng_vec(pr.n_u, 1), rng_vec(pr.n_u, 2)
+    assert rel_err(M.apply(2.0 * a - 3.0 * b), 2.0 * M.apply(a) - 3.0 * M.apply(b)) <= 1e-12
+    x = np.zeros(pr.n_u)
+    r0 = np.linalg.norm(b)
+    for _ in range(5):
+        x += M.apply(b - F @ x)
+    assert np.linalg.norm(b - F @ x) < 0.2 * r0
+    # Dirichlet rows (diagonal only) are not aggregated: the smoother alone solves them to ~ the Chebyshev residual
+    free = pr.dirichlet_u == 0
+    assert (~free).sum() > 0
+
+
+def test_block_triangular_with_amg_reaches_the_direct_solution():
+    pr, J, b, x0 = _sys("ns16")
+    xs = spl.splu(J).solve(b)
+    op = O.OracleProblem.from_local(pr)
+    x, info = op.solve(b, x0, solver=1, prec=1, variant=0, tol=1e-12, velocity_amg=1)
+    assert info["status"] == 0 and np.linalg.norm(b - J @ x) <= 1.05e-12 and rel_err(x, xs) <= 1e-8
+    _, info_ilu = op.solve(b, x0, solver=1, prec=1, variant=0, tol=1e-12, velocity_amg=0)
+    assert info_ilu["status"] == 0 and info["inner_u_its"] != info_ilu["inner_u_its"]
+
+
+def test_amg_shards_are_independent_hierarchies():
+    pr = problem("ns60")
+    F = pr.F.to_scipy().tocsr()
+    n = pr.n_u
+    off = np.array([0, (n // 2) & ~1, n], np.int32)
+    M = O.Amg(O.CsrHolder.from_block(pr.F), off)
+    b = rng_vec(n, 9)
+    x = M.apply(b)
+    for s in range(2):
+        sl = slice(off[s], off[s + 1])
+        sub = O.Amg(O.CsrHolder.from_scipy(F[sl][:, sl]))
+        assert rel_err(x[sl], sub.apply(b[sl])) <= 1e-13
+
+
 def test_gmres_and_bicgstab_with_a_fixed_preconditioner():
     pr, J, b, x0 = _sys("unsteady16")
     xs = spl.splu(J).solve(b)
