@@ -4,7 +4,7 @@
 // block-triangular preconditioner: `preconditioner_velocity.initialize(*velocity_stiffness)` with the
 // deal.II default AdditionalData (lab_new/src/NSSolverStationary.hpp:225,231).  ML's aggregates cannot be
 // reproduced bit for bit (its source is the only specification), so this is the same METHOD under the
-// same parameters — see DESIGN.md "AMG" for the deterministic details both this file and the oracle follow:
+// same parameters — see DESIGN.md "AMG" for the deterministic details of this specification:
 //   uncoupled greedy aggregation (strength threshold 1e-4), one constant near-null-space vector,
 //   prolongator smoothing (I - 4/3 / lambda D^-1 A), R = P^T, Galerkin R A P, <= 10 levels,
 //   coarsest level (<= 128 unknowns) solved directly, V(1,1) cycle with a degree-2 Chebyshev polynomial in
