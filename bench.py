@@ -222,12 +222,16 @@ def main():
 
     if rank == 0:
         value = n_global * args.steps / dt
+        lu, lp = st["n_colors_u"] or st["n_levels_u"], st["n_colors_p"] or st["n_levels_p"]
         names = {0: "spmv_blk_kernel<2,2>: SpMV with F (inner FGMRES), 2x2 node blocks",
                  3: "spmv_stream_kernel<1,0>: SpMV with Mp (inner CG)", 5: "spmv_stream_kernel<1,0>: SpMV with S (inner CG)",
-                 20: "tri_blk_kernel: ILU(0)/SGS apply on F (17+17 node-colour level launches of one apply)",
+                 20: (f"tri_blk_kernel: ILU(0)/SGS apply on F ({lu}+{lu} node-colour level launches "
+                      "of one apply)" if args.sync_free != 2 else
+                      "tri_blk_sf_kernel: ILU(0)/SGS apply on F (one launch per half, in-kernel hand-off)"),
                  21: ("tri_stream_sf_kernel: ILU(0)/SGS apply on the pressure block (one launch per half, in-kernel hand-off)"
                       if args.sync_free >= 1 else
-                      "tri_stream_kernel: ILU(0)/SGS apply on the pressure block (31+31 level launches of one apply)")}
+                      f"tri_stream_kernel: ILU(0)/SGS apply on the pressure block ({lp}+{lp} level "
+                      "launches of one apply)")}
         klass = {}
         for op, (ms, cnt, by, ncalls) in prof.items():
             klass[op] = dict(kernel=names[op], avg_ms=ms, launches_sampled=cnt, calls=ncalls, bytes_per_launch=by,

@@ -383,8 +383,12 @@ size_t Amg::apply_bytes() const {
   size_t by = 0;
   for (const AmgHierarchy &H : shards)
     for (const auto &L : H.lev) {
-      if (L->has_coarse) by += 4 * L->A->spmv_bytes() + L->P.spmv_bytes() + L->R.spmv_bytes() + (size_t)L->n * 8 * 5 * 4;
-      else by += (size_t)L->n * L->n * 8;
+      // pre-smoother 1 SpMV (zero guess), residual 1, post-smoother 2; restriction, prolongation (+ 8 n for the add);
+      // four Chebyshev updates of 5 vector streams each
+      if (L->has_coarse) by += 4 * (L->A->spmv_bytes() + 8 * (size_t)L->n) + L->P.spmv_bytes() + 8 * (size_t)L->n +
+                               L->R.spmv_bytes() + (size_t)L->n * 8 * 5 * 4;
+      else if (L->inv.p) by += (size_t)L->n * L->n * 8;
+      else by += 3 * (L->A->spmv_bytes() + 8 * (size_t)L->n) + (size_t)L->n * 8 * 5 * 4;
     }
   return by;
 }

@@ -949,8 +949,13 @@ int nsk_time_op(nsk_handle h, int op, int reps, double *avg_ms, double *bytes) {
   } else if (op == 20 || op == 21) {
     if (h->prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
     TriSolve *T = op == 20 ? &h->tF : h->tP;
-    by = (double)T->apply_bytes();
-    f = [=]() { T->apply(xb, yb); };
+    if (op == 20 && h->amg_active) {  // the velocity preconditioner of this setup is the AMG V-cycle
+      by = (double)h->amgF.apply_bytes();
+      f = [=]() { h->amgF.apply(xb, yb); };
+    } else {
+      by = (double)T->apply_bytes();
+      f = [=]() { T->apply(xb, yb); };
+    }
   } else if (op == 30) {
     by = 16.0 * h->N();
     f = [=]() { h->ctx.dot(h->N(), xb, zb, sl); };
