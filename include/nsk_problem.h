@@ -47,7 +47,8 @@ typedef struct {
 
 typedef struct {
   int32_t mode;      /* 0 = Stokes system (NSSolverStationary.cpp:383-406), 1 = Newton/NS system (:408-452) */
-  int32_t state;     /* linearisation state: 0 = zero, 1 = inlet profile extended along x */
+  int32_t state;     /* linearisation state: 0 = zero, 1 = inlet profile extended along x,
+                        2 = the vectors given to nsp_set_state (`solution` of the Newton loop, :370-374) */
   int32_t inlet_bc;  /* 1 = inhomogeneous inlet Dirichlet data (global first iteration, :549-552) */
   int32_t reserved;
   double nu;         /* kinematic viscosity = 1/current_Re (:665) */
@@ -63,6 +64,10 @@ void nsp_mesh_info(const nsp_mesh *m, nsp_info *out);
 
 /* Owned global DoF ranges of every rank: out_u/out_p have nranks+1 entries. */
 void nsp_mesh_ranges(const nsp_mesh *m, int64_t *out_u, int64_t *out_p);
+
+/* Linearisation state for params.state == 2: velocity and pressure in GLOBAL DoF numbering
+ * (n_u_global and n_p_global entries; every rank passes the same vectors).  Copied. */
+int nsp_set_state(nsp_mesh *m, const double *u_global, const double *p_global);
 
 /* Assemble all blocks, rhs and initial guess for this rank.  0 on success,
  * <0 on error (e.g. local nnz overflows int32). */

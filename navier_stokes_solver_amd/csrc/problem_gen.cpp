@@ -149,8 +149,17 @@ struct nsp_mesh {
   std::vector<double> rhs_u, rhs_p, x0_u, x0_p;
   std::vector<int32_t> ghost_u, ghost_p;
   std::vector<uint8_t> dir_owned;
-  std::vector<double> conv;  // [cj][32][32]
+  std::vector<double> conv;  // [cell cache index][32][32]
+  std::vector<double> state_u, state_p;  // linearisation state in global DoF numbering (params.state == 2)
   nsp_params prm;
+
+  // Element data depends on the cell row only for the analytic states (0, 1) and on the cell for a state
+  // vector (2); the cache covers the rank's strip plus one cell column either side.
+  inline int cache_c0() const { return std::max(0, ccol[rank] - 1); }
+  inline int cache_cells() const { return prm.state == 2 ? (std::min(nx, ccol[rank + 1] + 1) - cache_c0()) * ny : ny; }
+  inline size_t cache_index(int ci, int cj) const {
+    return prm.state == 2 ? (size_t)(ci - cache_c0()) * ny + cj : (size_t)cj;
+  }
 
   inline bool cell_kept(int ci, int cj) const {
     return ci >= 0 && ci < nx && cj >= 0 && cj < ny && kept[(size_t)ci * ny + cj];
@@ -256,15 +265,31 @@ static void build_lattice(nsp_mesh &M) {
   }
 }
 
-// Convective element matrix of one cell row (state depends on y only).
-static void conv_element(const nsp_mesh &M, int cj, double *C /*32x32*/) {
+// nodal values of the linearisation state on cell (ci, cj): 16 velocity nodes, 9 pressure nodes
+static void cell_state(const nsp_mesh &M, int ci, int cj, double *Ux, double *Uy, double *Pn) {
   const Tables &T = M.T;
-  double Ux[16], Uy[16];
   for (int b = 0; b < 4; ++b)
     for (int a = 0; a < 4; ++a) {
-      Ux[b * 4 + a] = M.prm.state == 1 ? M.profile((cj + T.gll[b]) * M.hy) : 0.0;
-      Uy[b * 4 + a] = 0.0;
+      const int n = b * 4 + a;
+      if (M.prm.state == 2) {
+        const int32_t id = M.uid[(size_t)(3 * ci + a) * M.NY3 + 3 * cj + b];
+        Ux[n] = M.state_u[2 * (size_t)id];
+        Uy[n] = M.state_u[2 * (size_t)id + 1];
+      } else {
+        Ux[n] = M.prm.state == 1 ? M.profile((cj + T.gll[b]) * M.hy) : 0.0;
+        Uy[n] = 0.0;
+      }
     }
+  for (int b = 0; b < 3; ++b)
+    for (int a = 0; a < 3; ++a)
+      Pn[b * 3 + a] = M.prm.state == 2 ? M.state_p[(size_t)M.pid[(size_t)(2 * ci + a) * M.NY2 + 2 * cj + b]] : 0.0;
+}
+
+// Convective element matrix of one cell (NSSolverStationary.cpp:408-428): both Frechet terms of (u . grad) u
+static void conv_element(const nsp_mesh &M, int ci, int cj, double *C /*32x32*/) {
+  const Tables &T = M.T;
+  double Ux[16], Uy[16], Pn[9];
+  cell_state(M, ci, cj, Ux, Uy, Pn);
   std::memset(C, 0, sizeof(double) * 32 * 32);
   for (int q = 0; q < 16; ++q) {
     double u[2] = {0, 0}, g[2][2] = {{0, 0}, {0, 0}};
@@ -285,31 +310,29 @@ static void conv_element(const nsp_mesh &M, int cj, double *C /*32x32*/) {
   }
 }
 
-// residual contribution of one cell to its 32 velocity and 9 pressure rows (NS mode)
-static void rhs_element(const nsp_mesh &M, int cj, double *Ru /*32*/, double *Rp /*9*/) {
+// residual contribution of one cell to its 32 velocity and 9 pressure rows (NS mode, :456-494)
+static void rhs_element(const nsp_mesh &M, int ci, int cj, double *Ru /*32*/, double *Rp /*9*/) {
   const Tables &T = M.T;
-  double Ux[16], Uy[16];
-  for (int b = 0; b < 4; ++b)
-    for (int a = 0; a < 4; ++a) {
-      Ux[b * 4 + a] = M.prm.state == 1 ? M.profile((cj + T.gll[b]) * M.hy) : 0.0;
-      Uy[b * 4 + a] = 0.0;
-    }
+  double Ux[16], Uy[16], Pn[9];
+  cell_state(M, ci, cj, Ux, Uy, Pn);
   std::memset(Ru, 0, sizeof(double) * 32);
   std::memset(Rp, 0, sizeof(double) * 9);
   for (int q = 0; q < 16; ++q) {
-    double u[2] = {0, 0}, g[2][2] = {{0, 0}, {0, 0}};
+    double u[2] = {0, 0}, g[2][2] = {{0, 0}, {0, 0}}, pq = 0.0;
     for (int n = 0; n < 16; ++n) {
       u[0] += Ux[n] * T.phi[n][q]; u[1] += Uy[n] * T.phi[n][q];
       g[0][0] += Ux[n] * T.dpx[n][q]; g[0][1] += Ux[n] * T.dpy[n][q];
       g[1][0] += Uy[n] * T.dpx[n][q]; g[1][1] += Uy[n] * T.dpy[n][q];
     }
+    for (int m = 0; m < 9; ++m) pq += Pn[m] * T.psi[m][q];
     const double w = T.jxw[q];
     const double divu = g[0][0] + g[1][1];
     for (int n = 0; n < 16; ++n)
       for (int c = 0; c < 2; ++c) {
         double r = -M.prm.nu * (g[c][0] * T.dpx[n][q] + g[c][1] * T.dpy[n][q]);   // -a(u,v)
         r -= (u[0] * g[c][0] + u[1] * g[c][1]) * T.phi[n][q];                      // -c(u;u,v)
-        // + b(v,p) with p = 0; time term with u == u_old vanishes
+        r += pq * (c == 0 ? T.dpx[n][q] : T.dpy[n][q]);                            // + b(v,p)
+        // the time term with u == u_old vanishes
         Ru[n * 2 + c] += w * r;
       }
     for (int m = 0; m < 9; ++m) Rp[m] += w * divu * T.psi[m][q];  // + b(u,q)
@@ -337,7 +360,7 @@ static int row_F(const nsp_mesh &M, int ix, int iy, int c, bool want, double d0,
   const bool dir = M.udir[self] != 0;
   for (int k = 0; k < nt; ++k) {
     const int n = t[k].b * 4 + t[k].a;
-    const double *C = M.prm.mode == 1 ? &M.conv[(size_t)t[k].cj * 1024 + (size_t)(n * 2 + c) * 32] : nullptr;
+    const double *C = M.prm.mode == 1 ? &M.conv[M.cache_index(t[k].ci, t[k].cj) * 1024 + (size_t)(n * 2 + c) * 32] : nullptr;
     for (int bm = 0; bm < 4; ++bm)
       for (int am = 0; am < 4; ++am) {
         const int wx = 3 * t[k].ci + am - wx0, wy = 3 * t[k].cj + bm - wy0;
@@ -572,6 +595,13 @@ void nsp_mesh_ranges(const nsp_mesh *m, int64_t *out_u, int64_t *out_p) {
   for (int r = 0; r <= m->nranks; ++r) { out_u[r] = m->urange[r]; out_p[r] = m->prange[r]; }
 }
 
+int nsp_set_state(nsp_mesh *m, const double *u_global, const double *p_global) {
+  if (!m || !u_global || !p_global) return -1;
+  m->state_u.assign(u_global, u_global + 2 * (size_t)m->n_unodes);
+  m->state_p.assign(p_global, p_global + (size_t)m->n_pnodes);
+  return 0;
+}
+
 int nsp_assemble(nsp_mesh *mp, const nsp_params *p) {
   nsp_mesh &M = *mp;
   M.prm = *p;
@@ -581,16 +611,33 @@ int nsp_assemble(nsp_mesh *mp, const nsp_params *p) {
   const int64_t p0 = M.prange[M.rank], p1 = M.prange[M.rank + 1];
   const int64_t nu_own = u1 - u0, np_own = p1 - p0;
 
+  if (p->state == 2 && (M.state_u.size() != (size_t)2 * M.n_unodes || M.state_p.size() != (size_t)M.n_pnodes)) return -3;
+  const int ncache = M.cache_cells(), cc0 = M.cache_c0();
+  auto cache_cell = [&](int k, int &ci, int &cj) {  // k-th cached cell; false when the cell was removed
+    if (p->state == 2) { ci = cc0 + k / M.ny; cj = k % M.ny; }
+    else { ci = 0; cj = k; }
+    return p->state != 2 || M.cell_kept(ci, cj);
+  };
   if (p->mode == 1) {
-    M.conv.resize((size_t)M.ny * 1024);
+    M.conv.assign((size_t)ncache * 1024, 0.0);
 #pragma omp parallel for schedule(static)
-    for (int cj = 0; cj < M.ny; ++cj) conv_element(M, cj, &M.conv[(size_t)cj * 1024]);
+    for (int k = 0; k < ncache; ++k) {
+      int ci, cj;
+      if (cache_cell(k, ci, cj)) conv_element(M, ci, cj, &M.conv[(size_t)k * 1024]);
+    }
   } else M.conv.clear();
 
   // diagonal placed on Dirichlet rows: |first non-zero diagonal entry| = row 0 before clearing
   // (MatrixTools::apply_boundary_values, NSSolverStationary.cpp:574-575)
   double d0 = p->nu * T.K[0][0] + p->inv_dt * T.M3[0][0];
-  if (p->mode == 1) d0 += M.conv[0];
+  if (p->mode == 1) {
+    // row 0 is component 0 of lattice node (0,0): only cell (0,0), local node 0, touches it
+    if (p->state == 2 && cc0 != 0) {
+      std::vector<double> C0(1024);
+      conv_element(M, 0, 0, C0.data());
+      d0 += C0[0];
+    } else d0 += M.conv[0];
+  }
   d0 = std::fabs(d0);
 
   // owned row lists in DoF order
@@ -655,10 +702,13 @@ int nsp_assemble(nsp_mesh *mp, const nsp_params *p) {
   M.x0_u.assign((size_t)nu_own, 0.0);
   M.x0_p.assign((size_t)np_own, 0.0);
   M.dir_owned.assign((size_t)nu_own, 0);
-  std::vector<double> Ru((size_t)M.ny * 32, 0.0), Rp((size_t)M.ny * 9, 0.0);
+  std::vector<double> Ru((size_t)ncache * 32, 0.0), Rp((size_t)ncache * 9, 0.0);
   if (p->mode == 1) {
 #pragma omp parallel for schedule(static)
-    for (int cj = 0; cj < M.ny; ++cj) rhs_element(M, cj, &Ru[(size_t)cj * 32], &Rp[(size_t)cj * 9]);
+    for (int k = 0; k < ncache; ++k) {
+      int ci, cj;
+      if (cache_cell(k, ci, cj)) rhs_element(M, ci, cj, &Ru[(size_t)k * 32], &Rp[(size_t)k * 9]);
+    }
   }
 #pragma omp parallel for schedule(static)
   for (int64_t r = 0; r < nu_own; ++r) {
@@ -676,7 +726,7 @@ int nsp_assemble(nsp_mesh *mp, const nsp_params *p) {
     const int nt = M.touching(s.ix, s.iy, 3, t);
     double v = 0.0;
     for (int k = 0; k < nt; ++k) {
-      if (p->mode == 1) v += Ru[(size_t)t[k].cj * 32 + (t[k].b * 4 + t[k].a) * 2 + s.c];
+      if (p->mode == 1) v += Ru[M.cache_index(t[k].ci, t[k].cj) * 32 + (t[k].b * 4 + t[k].a) * 2 + s.c];
       // outlet Neumann term: -p_out * ∫ n.v on x = 2.2 faces, n = (1,0)
       if (s.c == 0 && t[k].ci == M.nx - 1 && t[k].a == 3) v -= p->p_out * M.hy * T.face_w3[t[k].b];
     }
@@ -689,7 +739,7 @@ int nsp_assemble(nsp_mesh *mp, const nsp_params *p) {
       Touch t[4];
       const int nt = M.touching(s.ix, s.iy, 2, t);
       double v = 0.0;
-      for (int k = 0; k < nt; ++k) v += Rp[(size_t)t[k].cj * 9 + t[k].b * 3 + t[k].a];
+      for (int k = 0; k < nt; ++k) v += Rp[M.cache_index(t[k].ci, t[k].cj) * 9 + t[k].b * 3 + t[k].a];
       M.rhs_p[r] = v;
     }
   }

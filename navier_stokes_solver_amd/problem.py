@@ -47,6 +47,7 @@ def lib() -> C.CDLL:
         L.nsp_mesh_info.argtypes = [C.c_void_p, C.POINTER(_Info)]
         L.nsp_mesh_ranges.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.nsp_assemble.argtypes = [C.c_void_p, C.POINTER(_Params)]
+        L.nsp_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.nsp_assemble.restype = C.c_int
         for f in ("nsp_block_rows", "nsp_block_cols", "nsp_block_nnz"):
             getattr(L, f).restype = C.c_int64
@@ -151,15 +152,26 @@ def mesh_info(nx: int, ny: int, nranks: int = 1, rank: int = 0) -> dict:
     return {k: getattr(info, k) for k, _ in _Info._fields_}
 
 
-def generate(nx: int, ny: int, *, nu: float, mode: int = 1, state: int = 1, inlet_bc: int = 0,
+def generate(nx: int, ny: int, *, nu: float, mode: int = 1, state=1, inlet_bc: int = 0,
              inv_dt: float = 0.0, U: float = 0.1, p_out: float = 1.0, nranks: int = 1, rank: int = 0,
              copy: bool = True) -> LocalProblem:
-    """Assemble rank ``rank``'s share of the nx x ny problem."""
+    """Assemble rank ``rank``'s share of the nx x ny problem.  ``state``: 0 / 1 (analytic) or a pair
+    (u, p) of GLOBAL velocity / pressure vectors to linearise about (the Newton loop's `solution`)."""
     L = lib()
     h = L.nsp_mesh_create(nx, ny, nranks, rank)
     if not h:
         raise ValueError("nsp_mesh_create rejected the arguments")
     try:
+        if not isinstance(state, (int, np.integer)):
+            info = _Info()
+            L.nsp_mesh_info(h, C.byref(info))
+            su = np.ascontiguousarray(state[0], dtype=np.float64)
+            spv = np.ascontiguousarray(state[1], dtype=np.float64)
+            if su.shape != (info.n_u_global,) or spv.shape != (info.n_p_global,):
+                raise ValueError("state vectors must have the global sizes (n_u_global, n_p_global)")
+            if L.nsp_set_state(h, su.ctypes.data, spv.ctypes.data) != 0:
+                raise RuntimeError("nsp_set_state failed")
+            state = 2
         prm = _Params(mode=mode, state=state, inlet_bc=inlet_bc, reserved=0, nu=nu, inv_dt=inv_dt, U=U, p_out=p_out)
         rc = L.nsp_assemble(h, C.byref(prm))
         if rc != 0:
@@ -189,7 +201,7 @@ def generate(nx: int, ny: int, *, nu: float, mode: int = 1, state: int = 1, inle
             ghost_p=_arr(L.nsp_ghost_p(h), info.n_ghost_p, np.int32, True),
             dirichlet_u=_arr(L.nsp_dirichlet_u(h), n_u, np.uint8, True),
             u_ranges=np.array(list(ur), dtype=np.int64), p_ranges=np.array(list(pr), dtype=np.int64),
-            params=dict(nx=nx, ny=ny, nu=nu, mode=mode, state=state, inlet_bc=inlet_bc, inv_dt=inv_dt, U=U,
+            params=dict(nx=nx, ny=ny, nu=nu, mode=mode, state=int(state), inlet_bc=inlet_bc, inv_dt=inv_dt, U=U,
                         p_out=p_out))
         return out
     finally:

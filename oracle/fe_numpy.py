@@ -95,8 +95,12 @@ def assemble(nx, ny, nu, mode=1, state=1, inlet_bc=0, inv_dt=0.0, U=0.1, p_out=1
             pn = np.array([pid[2 * i + a, 2 * j + b] for b in range(3) for a in range(3)])
             dofs = np.concatenate([np.stack([2 * un, 2 * un + 1], 1).ravel(), n_u + pn])
             ys = np.array([(j + gll[b]) * hy for b in range(4) for a in range(4)])
-            Ux = profile(ys) if state == 1 else np.zeros(16)
-            Uy = np.zeros(16)
+            if isinstance(state, (int, np.integer)):
+                Ux = profile(ys) if state == 1 else np.zeros(16)
+                Uy = np.zeros(16)
+                Pn = np.zeros(9)
+            else:   # (u, p) in global DoF numbering: the Newton loop's `solution`
+                Ux, Uy, Pn = state[0][2 * un], state[0][2 * un + 1], state[1][pn]
             u = np.stack([Ux @ phi, Uy @ phi])                                  # [k, q]
             g = np.array([[Ux @ dpx, Ux @ dpy], [Uy @ dpx, Uy @ dpy]])           # [k, l, q]
             Ke = np.zeros((41, 41))
@@ -121,6 +125,9 @@ def assemble(nx, ny, nu, mode=1, state=1, inlet_bc=0, inv_dt=0.0, U=0.1, p_out=1
                 for c in range(2):
                     re[c:32:2] = -nu * ((jxw * g[c, 0]) @ dpx.T + (jxw * g[c, 1]) @ dpy.T) \
                                  - (jxw * (u[0] * g[c, 0] + u[1] * g[c, 1])) @ phi.T
+                pq = Pn @ psi
+                re[0:32:2] += (jxw * pq) @ dpx.T                                  # + b(v,p)
+                re[1:32:2] += (jxw * pq) @ dpy.T
                 re[32:] = (jxw * (g[0, 0] + g[1, 1])) @ psi.T
             if i == nx - 1:
                 for b in range(4):

@@ -89,7 +89,8 @@ def test_multi_rank_path_over_gloo(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,prec,variant,ordering", [(2, 2, 1, 0), (3, 2, 1, 1), (2, 2, 0, 1), (2, 0, 0, 0)])
+@pytest.mark.parametrize("world,prec,variant,ordering", [(2, 2, 1, 0), (3, 2, 1, 1), (2, 2, 0, 1), (2, 0, 0, 0),
+                                                         (2, 1, 0, 1)])
 def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering):
     """N rank threads on one GPU: ghost import, global reductions, D^-1 halo, SpGEMM with imported
     (0,1) rows, rank-local ILU, full FGMRES solve — against the oracle with N emulated ranks."""
@@ -141,7 +142,8 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering):
         pk = "perm_S" if prec == 2 else "perm_Mp"
         kw[pk] = np.concatenate([r["perm_p"] + parts[0].p_ranges[k] for k, r in enumerate(res)])
     op = O.OracleProblem.from_local(pr, **kw)
-    dst, rc = op.prec_apply(np.concatenate([xu, xp]), prec=prec, variant=variant, alpha=0.5)
+    amg = int((prec, variant) == (1, 0))   # stationary blockTriangular: rank-local AMG hierarchies for F
+    dst, rc = op.prec_apply(np.concatenate([xu, xp]), prec=prec, variant=variant, alpha=0.5, velocity_amg=amg)
     assert rc == 0 and all(r["rc"] == 0 for r in res)
     tol = 1e-10 if (prec, variant) == (2, 1) else 1e-7
     assert rel_err(np.concatenate([cat("du"), cat("dp")]), dst) <= tol
@@ -150,7 +152,8 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering):
     assert all(r["src"] == 0 for r in res) and len({r["its"] for r in res}) == 1
     assert np.linalg.norm(b - J @ x) <= 1.05e-12
     assert rel_err(x, spl.splu(J).solve(b)) <= 1e-7
-    xo, info = op.solve(b, np.concatenate([pr.x0_u, pr.x0_p]), solver=1, prec=prec, variant=variant, tol=1e-12)
+    xo, info = op.solve(b, np.concatenate([pr.x0_u, pr.x0_p]), solver=1, prec=prec, variant=variant, tol=1e-12,
+                        velocity_amg=amg)
     assert info["status"] == 0 and rel_err(x, xo) <= 1e-7
     assert abs(res[0]["its"] - info["iters"]) <= max(3, 0.2 * info["iters"])
 

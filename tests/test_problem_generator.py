@@ -62,6 +62,28 @@ def test_against_independent_numpy_assembly(name):
     assert np.array_equal(pr.dirichlet_u.astype(bool), ref["dirichlet"])
 
 
+def test_arbitrary_linearisation_state_against_numpy_assembly():
+    """state = (u, p): the Jacobian's convective part and the Newton residual (incl. b(v,p)) about a given
+    `solution` (NSSolverStationary.cpp:370-374, 408-494), on one rank and stitched from two."""
+    from oracle import fe_numpy
+    nx, ny, nu = 16, 10, 0.05
+    i = P.mesh_info(nx, ny)
+    rng = np.random.default_rng(5)
+    su, spv = 0.1 * rng.standard_normal(i["n_u_global"]), rng.standard_normal(i["n_p_global"])
+    ref = fe_numpy.assemble(nx, ny, nu, mode=1, state=(su, spv))
+    scale = abs(ref["J"]).max()
+    pr = P.generate(nx, ny, nu=nu, mode=1, state=(su, spv))
+    assert abs(pr.jacobian_scipy() - ref["J"]).max() <= 1e-12 * scale
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    assert np.abs(b - ref["rhs"]).max() <= 1e-12 * np.abs(ref["rhs"]).max()
+    # differs from the analytic state, i.e. the vectors are really used
+    assert abs(pr.jacobian_scipy() - problem("ns16").jacobian_scipy()).max() > 1e-3 * scale
+    parts = [P.generate(nx, ny, nu=nu, mode=1, state=(su, spv), nranks=2, rank=r) for r in range(2)]
+    assert np.array_equal(np.concatenate([p.rhs_u for p in parts]), pr.rhs_u)
+    assert np.array_equal(np.concatenate([p.rhs_p for p in parts]), pr.rhs_p)
+    assert np.array_equal(np.concatenate([p.F.val for p in parts]), pr.F.val)   # same rows, ghost columns renumbered
+
+
 def test_block_structure_signs():
     """Appendix C: Stokes mode is symmetric on free rows with both off-diagonal blocks negative;
     Newton mode flips the (1,0) block."""
