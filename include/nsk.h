@@ -157,6 +157,40 @@ int nsk_precond_vmult(nsk_handle h, const double *src_u, const double *src_p, do
 int64_t nsk_block_nnz(nsk_handle h, int blk);
 int nsk_get_block(nsk_handle h, int blk, int32_t *rowptr, int32_t *col, double *val);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Device assembly of the Newton system and the Newton-loop state.
+ * Replaces NSSolverStationary::assemble_system(false, false) (NSSolverStationary.cpp:317-577) for meshes of
+ * congruent Q3/Q2 cells (the reference's generated `-m nx,ny` meshes), and the vector updates of solve_newton()
+ * (:710-735).  jacobian(0,0) and residual_vector are recomputed on the device from the resident `solution`;
+ * blocks (0,1), (1,0) and pressure_mass do not depend on the state and stay as handed over.
+ *
+ * nsk_assembly_set_cells: the cell loop's connectivity — per cell 16 local velocity NODE ids (local DoF id / 2,
+ *   n = b*4 + a) and 9 local pressure DoF ids (what cell->get_dof_indices returns, :532), flags (bit 0: face on
+ *   boundary id 8), and the tabulation FEValues / FEFaceValues hold for the congruent cell (:323-331): 944 doubles
+ *   phi[16][16], dphi/dx[16][16], dphi/dy[16][16], psi[9][16], JxW[16], outlet-face integrals[16].
+ *   cell_of_dof0: local index of the cell whose node 0 is global DoF 0 (-1 on the other ranks); its (0,0) entry
+ *   is the value MatrixTools::apply_boundary_values puts on Dirichlet diagonals (:574-575).
+ * nsk_assembly_set_dirichlet: flags per owned velocity DoF (boundary ids 6, 7, 10; :540-571) and, optionally,
+ *   inhomogeneous values (the inlet profile of the very first iteration).
+ * nsk_state_*: `solution` on the device.  set/get move owned entries; save = `evaluation_point = solution`;
+ *   update(alpha) = `solution = evaluation_point + alpha * delta_owned` with delta the resident result of the
+ *   last solve (:718-721).  Ghost entries are refreshed by a halo exchange.
+ * nsk_assemble: fills block (0,0) (+ Dirichlet clearing), the resident right-hand side and the Dirichlet entries
+ *   of the resident initial guess, and returns residual_vector.l2_norm() (:701).  Collective.
+ *   Call nsk_setup_preconditioner afterwards, as solve_system() builds its preconditioner from the new matrix. */
+int nsk_assembly_set_cells(nsk_handle h, int64_t n_cells, const int32_t *cell_u_nodes, const int32_t *cell_p_dofs,
+                           const uint8_t *cell_flags, const double *tables944, int32_t cell_of_dof0);
+int nsk_assembly_set_dirichlet(nsk_handle h, const uint8_t *dirichlet_u, const double *bc_u /* or NULL */);
+int nsk_state_set(nsk_handle h, const double *u_owned, const double *p_owned);
+int nsk_state_get(nsk_handle h, double *u_owned, double *p_owned);
+int nsk_state_save(nsk_handle h);
+int nsk_state_update(nsk_handle h, double alpha);
+int nsk_assemble(nsk_handle h, double nu, double inv_dt, double p_out, int inhomogeneous_bc, double *residual_norm);
+/* resident right-hand side (residual_vector) to the host */
+int nsk_download_rhs(nsk_handle h, double *rhs_u, double *rhs_p);
+/* device time of one assembly (all kernels), averaged over reps */
+int nsk_time_assemble(nsk_handle h, double nu, double inv_dt, int reps, double *avg_ms);
+
 int nsk_get_stats(nsk_handle h, nsk_stats *out);
 int nsk_reset_stats(nsk_handle h);
 

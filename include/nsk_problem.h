@@ -88,6 +88,20 @@ const int32_t *nsp_ghost_u(const nsp_mesh *m); /* global u-DoF ids of ghost colu
 const int32_t *nsp_ghost_p(const nsp_mesh *m);
 const uint8_t *nsp_dirichlet_u(const nsp_mesh *m); /* 1 per owned u-DoF that is a Dirichlet row */
 
+
+/* Assembly hand-off (valid after nsp_assemble): the cells touching an owned DoF with their LOCAL ids
+ * — what `cell->get_dof_indices` (NSSolverStationary.cpp:532) and FEValues (:323-331) give the reference's
+ * assembly loop.  cell_u_nodes: 16 velocity NODE ids per cell (local DoF id / 2; n = b*4 + a, a along x);
+ * cell_p_dofs: 9 pressure DoF ids per cell (m = b*3 + a); cell_flags bit 0: the cell has a face on the outlet
+ * (boundary id 8).  nsp_cell_tables fills 944 doubles: phi[16][16], dphi/dx[16][16], dphi/dy[16][16] (velocity
+ * basis n at quadrature point q), psi[9][16], JxW[16] and the outlet-face integrals of the 16 basis functions. */
+int64_t nsp_n_cells_local(const nsp_mesh *m);
+const int32_t *nsp_cell_u_nodes(const nsp_mesh *m);
+const int32_t *nsp_cell_p_dofs(const nsp_mesh *m);
+const uint8_t *nsp_cell_flags(const nsp_mesh *m);
+int32_t nsp_cell_of_dof0(const nsp_mesh *m); /* local index of the cell holding global DoF 0 as its node 0, or -1 */
+void nsp_cell_tables(const nsp_mesh *m, double *out944);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,33 @@
+// nsk_assembly.hpp — device assembly of the Newton system (jacobian(0,0) values and residual_vector) and the
+// Newton-loop state kept on the device.  Reference: NSSolverStationary::assemble_system(false, false)
+// (lab_new/src/NSSolverStationary.cpp:317-577) and the solution / evaluation_point / delta_owned updates of
+// solve_newton() (:710-735).  See nsk_assembly_kernels.hip for the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nsk {
+
+struct AsmMesh {  // device pointers
+  long n_cells;
+  int n_unodes, n_pdofs;   // owned velocity nodes / pressure DoFs
+  int cell_of_dof0;        // local cell whose node 0 is global DoF 0, or -1
+  const int *cell_u;       // [n_cells][16] local velocity node ids (owned first, ghosts after)
+  const int *cell_p;       // [n_cells][9] local pressure DoF ids
+  const unsigned char *cell_flags;  // bit 0: outlet face
+  const int *node_cells;   // [n_unodes][4]: cell * 16 + local node, or -1
+  const unsigned char *node_off;    // [n_unodes][64]: block position of (cell k, column node m) in the node's row
+  const int *node_self;    // [n_unodes]: block position of the diagonal block
+  const int *pdof_cells;   // [n_pdofs][4]: cell * 9 + local node, or -1
+  const unsigned char *dirichlet;   // per owned velocity DoF
+  const double *tables;    // phi, dphi/dx, dphi/dy, psi, JxW, outlet face integrals, K, M3 (1456 doubles)
+};
+
+void asm_cell_state(hipStream_t s, const AsmMesh &M, const double *su, const double *sp, double *cq);
+void asm_d0(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double inv_dt, double *out);
+void asm_F_rows(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double inv_dt, const double *d0,
+                const int *rowptr, double *val);
+void asm_rhs_u(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double p_out, const double *d0,
+               const double *bc, double *rhs, double *x0);
+void asm_rhs_p(hipStream_t s, const AsmMesh &M, const double *cq, double *rhs);
+
+}  // namespace nsk

@@ -15,6 +15,7 @@
 #include "../../include/nsk.h"
 #include "nsk_solver.hpp"
 #include "nsk_amg.hpp"
+#include "nsk_assembly.hpp"
 #include "nsk_tri.hpp"
 
 using namespace nsk;
@@ -97,6 +98,23 @@ struct nsk_handle_s {
   double *rhs_b = nullptr, *x_b = nullptr;
   long inner_u = 0, inner_p = 0, prec_applies = 0, outer_iters = 0;
   double setup_ms = 0, solve_ms = 0;
+
+  // ---- device assembly and Newton state (nsk_assembly_*, nsk_state_*, nsk_assemble) ----
+  struct AsmData {
+    bool ready = false, dirichlet_set = false, have_bc = false, state_set = false;
+    long n_cells = 0;
+    int cell_of_dof0 = -1;
+    DBuf<int> cell_u, cell_p, node_cells, node_self, pdof_cells;
+    DBuf<unsigned char> cell_flags, node_off, dirichlet;
+    DBuf<double> tables, cq, bc;
+    double *sol_u = nullptr, *sol_p = nullptr, *eval_u = nullptr, *eval_p = nullptr;  // pool vectors [owned | ghost]
+    double assemble_ms = 0;
+  } asmd;
+  AsmMesh asm_view() const {
+    return AsmMesh{asmd.n_cells, sp[0].n / 2, sp[1].n, asmd.cell_of_dof0, asmd.cell_u.p, asmd.cell_p.p, asmd.cell_flags.p,
+                   asmd.node_cells.p, asmd.node_off.p, asmd.node_self.p, asmd.pdof_cells.p, asmd.dirichlet.p,
+                   asmd.tables.p};
+  }
 
   int n_u() const { return sp[0].n; }
   int n_p() const { return sp[1].n; }
@@ -749,6 +767,243 @@ int nsk_dot(nsk_handle h, int n, const double *x, const double *y, double *dot_o
   if (dot_out) *dot_out = r[0];
   if (norm_out) *norm_out = r[2];
   h->ctx.slot_top = sl;
+  return 0;
+  NSK_CATCH(h)
+}
+
+// ------------------------------------------------------------------ device assembly + Newton state
+int nsk_assembly_set_cells(nsk_handle h, int64_t n_cells, const int32_t *cell_u_nodes, const int32_t *cell_p_dofs,
+                           const uint8_t *cell_flags, const double *tables944, int32_t cell_of_dof0) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  h->ensure_pools();
+  if (n_cells <= 0 || !cell_u_nodes || !cell_p_dofs || !cell_flags || !tables944) throw Error(-60, "nsk_assembly_set_cells: bad arguments");
+  Csr &F = h->blk[NSK_BLK_F];
+  const int nu = h->n_u(), np = h->n_p();
+  if (nu % 2 || h->sp[0].ng % 2) throw Error(-61, "assembly needs both velocity components of every node");
+  const int n_nodes = nu / 2, n_nodes_all = (nu + h->sp[0].ng) / 2, n_p_all = np + h->sp[1].ng;
+  if (cell_of_dof0 >= n_cells) throw Error(-60, "nsk_assembly_set_cells: cell_of_dof0 out of range");
+  std::vector<int> node_cells((size_t)n_nodes * 4, -1), pdof_cells((size_t)np * 4, -1), cnt_u((size_t)n_nodes, 0), cnt_p((size_t)np, 0);
+  for (int64_t c = 0; c < n_cells; ++c) {
+    for (int n = 0; n < 16; ++n) {
+      const int node = cell_u_nodes[c * 16 + n];
+      if (node < 0 || node >= n_nodes_all) throw Error(-62, "assembly: velocity node id out of range");
+      if (node < n_nodes) {
+        if (cnt_u[node] >= 4) throw Error(-63, "assembly: more than 4 cells touch one velocity node");
+        node_cells[(size_t)node * 4 + cnt_u[node]++] = (int)(c * 16 + n);
+      }
+    }
+    for (int m = 0; m < 9; ++m) {
+      const int d = cell_p_dofs[c * 9 + m];
+      if (d < 0 || d >= n_p_all) throw Error(-62, "assembly: pressure DoF id out of range");
+      if (d < np) {
+        if (cnt_p[d] >= 4) throw Error(-63, "assembly: more than 4 cells touch one pressure DoF");
+        pdof_cells[(size_t)d * 4 + cnt_p[d]++] = (int)(c * 9 + m);
+      }
+    }
+  }
+  // where each (row node, cell, column node) block lives in the node's rows of jacobian(0,0)
+  std::vector<unsigned char> node_off((size_t)n_nodes * 64, 0);
+  std::vector<int> node_self((size_t)n_nodes, 0);
+  bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+  for (int r = 0; r < n_nodes; ++r) {
+    const int a0 = F.h_rowptr[2 * r], a1 = F.h_rowptr[2 * r + 1], a2 = F.h_rowptr[2 * r + 2];
+    if (cnt_u[r] == 0 || a1 - a0 != a2 - a1 || (a1 - a0) % 2 || (a1 - a0) / 2 > 49) { ok = false; continue; }
+    auto find = [&](int node) {
+      for (int k = a0; k + 1 < a1; k += 2)
+        if (F.h_col[k] == 2 * node && F.h_col[k + 1] == 2 * node + 1) return (k - a0) / 2;
+      return -1;
+    };
+    const int self = find(r);
+    if (self < 0) { ok = false; continue; }
+    node_self[r] = self;
+    for (int k = 0; k < cnt_u[r]; ++k) {
+      const int64_t cell = node_cells[(size_t)r * 4 + k] / 16;
+      for (int m = 0; m < 16; ++m) {
+        const int off = find(cell_u_nodes[cell * 16 + m]);
+        if (off < 0) { ok = false; break; }
+        node_off[(size_t)r * 64 + k * 16 + m] = (unsigned char)off;
+      }
+    }
+  }
+  if (!ok) throw Error(-64, "assembly: a cell couples DoFs that are not in the sparsity pattern of block (0,0)");
+  for (int d = 0; d < np; ++d)
+    if (cnt_p[d] == 0) throw Error(-64, "assembly: an owned pressure DoF belongs to no cell");
+  // reference-cell tables + the state-independent element matrices K (viscosity) and M3 (mass)
+  std::vector<double> tab(1456);
+  std::copy(tables944, tables944 + 944, tab.begin());
+  const double *phi = tables944, *dpx = tables944 + 256, *dpy = tables944 + 512, *jxw = tables944 + 912;
+  for (int n = 0; n < 16; ++n)
+    for (int m = 0; m < 16; ++m) {
+      double kk = 0.0, mm = 0.0;
+      for (int q = 0; q < 16; ++q) {
+        kk += jxw[q] * (dpx[n * 16 + q] * dpx[m * 16 + q] + dpy[n * 16 + q] * dpy[m * 16 + q]);
+        mm += jxw[q] * phi[n * 16 + q] * phi[m * 16 + q];
+      }
+      tab[944 + n * 16 + m] = kk;
+      tab[1200 + n * 16 + m] = mm;
+    }
+  auto &A = h->asmd;
+  hipStream_t s = h->s();
+  A.n_cells = (long)n_cells;
+  A.cell_of_dof0 = cell_of_dof0;
+  A.cell_u.upload(cell_u_nodes, (size_t)n_cells * 16, s);
+  A.cell_p.upload(cell_p_dofs, (size_t)n_cells * 9, s);
+  A.cell_flags.upload(cell_flags, (size_t)n_cells, s);
+  A.node_cells.upload(node_cells, s);
+  A.node_self.upload(node_self, s);
+  A.node_off.upload(node_off, s);
+  A.pdof_cells.upload(pdof_cells, s);
+  A.tables.upload(tab, s);
+  A.cq.alloc((size_t)n_cells * 112);
+  if (!A.sol_u) { A.sol_u = h->pool_u.get(true); A.eval_u = h->pool_u.get(true); A.sol_p = h->pool_p.get(true); A.eval_p = h->pool_p.get(true); }
+  h->ctx.sync();
+  A.ready = true;
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_assembly_set_dirichlet(nsk_handle h, const uint8_t *dirichlet_u, const double *bc_u) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  h->ensure_pools();
+  if (!dirichlet_u) throw Error(-60, "nsk_assembly_set_dirichlet: bad arguments");
+  for (int r = 0; r + 1 < h->n_u(); r += 2)
+    if ((dirichlet_u[r] != 0) != (dirichlet_u[r + 1] != 0)) throw Error(-65, "assembly: Dirichlet flags must cover both components of a node");
+  h->asmd.dirichlet.upload(dirichlet_u, (size_t)h->n_u(), h->s());
+  h->asmd.have_bc = bc_u != nullptr;
+  if (bc_u) h->asmd.bc.upload(bc_u, (size_t)h->n_u(), h->s());
+  h->ctx.sync();
+  h->asmd.dirichlet_set = true;
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_state_set(nsk_handle h, const double *u_owned, const double *p_owned) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  auto &A = h->asmd;
+  if (!A.ready) throw Error(-66, "call nsk_assembly_set_cells first");
+  NSK_HIP(hipMemcpyAsync(A.sol_u, u_owned, sizeof(double) * (size_t)h->n_u(), hipMemcpyHostToDevice, h->s()));
+  NSK_HIP(hipMemcpyAsync(A.sol_p, p_owned, sizeof(double) * (size_t)h->n_p(), hipMemcpyHostToDevice, h->s()));
+  h->halo(0, h->pool_u.view(A.sol_u));   // solution = solution_owned: refresh the ghost entries
+  h->halo(1, h->pool_p.view(A.sol_p));
+  h->ctx.sync();
+  A.state_set = true;
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_state_get(nsk_handle h, double *u_owned, double *p_owned) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  auto &A = h->asmd;
+  if (!A.state_set) throw Error(-66, "no state on the device");
+  NSK_HIP(hipMemcpyAsync(u_owned, A.sol_u, sizeof(double) * (size_t)h->n_u(), hipMemcpyDeviceToHost, h->s()));
+  NSK_HIP(hipMemcpyAsync(p_owned, A.sol_p, sizeof(double) * (size_t)h->n_p(), hipMemcpyDeviceToHost, h->s()));
+  h->ctx.sync();
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_state_save(nsk_handle h) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  auto &A = h->asmd;
+  if (!A.state_set) throw Error(-66, "no state on the device");
+  vec_copy(h->s(), h->n_u(), A.sol_u, A.eval_u);
+  vec_copy(h->s(), h->n_p(), A.sol_p, A.eval_p);
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_state_update(nsk_handle h, double alpha) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  auto &A = h->asmd;
+  if (!A.state_set) throw Error(-66, "no state on the device");
+  // solution_owned = evaluation_point; solution_owned.add(alpha, delta_owned); solution = solution_owned
+  vec_copy(h->s(), h->n_u(), A.eval_u, A.sol_u);
+  vec_copy(h->s(), h->n_p(), A.eval_p, A.sol_p);
+  vec_axpy(h->s(), h->n_u(), sref(alpha), h->x_b, A.sol_u);
+  vec_axpy(h->s(), h->n_p(), sref(alpha), h->x_b + h->n_u(), A.sol_p);
+  h->halo(0, h->pool_u.view(A.sol_u));
+  h->halo(1, h->pool_p.view(A.sol_p));
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_assemble(nsk_handle h, double nu, double inv_dt, double p_out, int inhomogeneous_bc, double *residual_norm) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  auto &A = h->asmd;
+  if (!A.ready || !A.dirichlet_set || !A.state_set) throw Error(-66, "nsk_assemble needs cells, Dirichlet flags and a state");
+  if (!(nu > 0.0)) throw Error(-60, "nsk_assemble: nu must be positive");
+  if (inhomogeneous_bc && !A.have_bc) throw Error(-60, "nsk_assemble: no boundary values were given");
+  Csr &F = h->blk[NSK_BLK_F];
+  hipStream_t s = h->s();
+  const double t0 = wall_ms();
+  const AsmMesh M = h->asm_view();
+  const int sl = h->ctx.alloc_slots(3);
+  struct Rel { Ctx &c; int sl; ~Rel() { c.slot_top = sl; } } rel{h->ctx, sl};
+  asm_cell_state(s, M, A.sol_u, A.sol_p, A.cq.p);
+  asm_d0(s, M, A.cq.p, nu, inv_dt, h->ctx.slot(sl));
+  h->ctx.comm.allreduce_sum(h->ctx.slot(sl), 1, s);   // the rank owning global DoF 0 wrote it, the others 0
+  asm_F_rows(s, M, A.cq.p, nu, inv_dt, h->ctx.slot(sl), F.rowptr.p, F.val.p);
+  F.refresh_blocked(s);
+  asm_rhs_u(s, M, A.cq.p, nu, p_out, h->ctx.slot(sl), inhomogeneous_bc ? A.bc.p : nullptr, h->rhs_b, h->x_b);
+  asm_rhs_p(s, M, A.cq.p, h->rhs_b + h->n_u());
+  h->ctx.norm2(h->N(), h->rhs_b, sl + 1);
+  const double nrm = h->ctx.read_slots(sl + 2, 1)[0];
+  if (residual_norm) *residual_norm = nrm;
+  A.assemble_ms = wall_ms() - t0;
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_download_rhs(nsk_handle h, double *ru, double *rp) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  h->ensure_pools();
+  NSK_HIP(hipMemcpyAsync(ru, h->rhs_b, sizeof(double) * (size_t)h->n_u(), hipMemcpyDeviceToHost, h->s()));
+  NSK_HIP(hipMemcpyAsync(rp, h->rhs_b + h->n_u(), sizeof(double) * (size_t)h->n_p(), hipMemcpyDeviceToHost, h->s()));
+  h->ctx.sync();
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_time_assemble(nsk_handle h, double nu, double inv_dt, int reps, double *avg_ms) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  auto &A = h->asmd;
+  if (!A.ready || !A.dirichlet_set || !A.state_set || reps <= 0) throw Error(-66, "nsk_time_assemble: nothing to time");
+  Csr &F = h->blk[NSK_BLK_F];
+  hipStream_t s = h->s();
+  const AsmMesh M = h->asm_view();
+  const int sl = h->ctx.alloc_slots(1);
+  hipEvent_t e0, e1;
+  NSK_HIP(hipEventCreate(&e0));
+  NSK_HIP(hipEventCreate(&e1));
+  auto once = [&]() {
+    asm_cell_state(s, M, A.sol_u, A.sol_p, A.cq.p);
+    asm_d0(s, M, A.cq.p, nu, inv_dt, h->ctx.slot(sl));
+    asm_F_rows(s, M, A.cq.p, nu, inv_dt, h->ctx.slot(sl), F.rowptr.p, F.val.p);
+    F.refresh_blocked(s);
+    asm_rhs_u(s, M, A.cq.p, nu, 1.0, h->ctx.slot(sl), nullptr, h->rhs_b, h->x_b);
+    asm_rhs_p(s, M, A.cq.p, h->rhs_b + h->n_u());
+  };
+  once();
+  NSK_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < reps; ++i) once();
+  NSK_HIP(hipEventRecord(e1, s));
+  NSK_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  NSK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  h->ctx.slot_top = sl;
+  if (avg_ms) *avg_ms = ms / reps;
   return 0;
   NSK_CATCH(h)
 }

@@ -150,6 +150,10 @@ struct nsp_mesh {
   std::vector<int32_t> ghost_u, ghost_p;
   std::vector<uint8_t> dir_owned;
   std::vector<double> conv;  // [cell cache index][32][32]
+  // cell connectivity of the assembly hand-off (cells touching an owned DoF), local ids
+  std::vector<int32_t> cell_u_nodes, cell_p_dofs;
+  std::vector<uint8_t> cell_flags;
+  int32_t cell_of_dof0 = -1;
   std::vector<double> state_u, state_p;  // linearisation state in global DoF numbering (params.state == 2)
   nsp_params prm;
 
@@ -732,6 +736,50 @@ int nsp_assemble(nsp_mesh *mp, const nsp_params *p) {
     }
     M.rhs_u[r] = v;
   }
+  // cell -> local DoF lists (what cell->get_dof_indices gives the reference's assembly loop, .cpp:532)
+  {
+    M.cell_u_nodes.clear(); M.cell_p_dofs.clear(); M.cell_flags.clear();
+    M.cell_of_dof0 = -1;
+    auto local_u = [&](int64_t g) -> int64_t {  // global u-DoF -> local id (owned first, ghosts appended), -1 if absent
+      if (g >= u0 && g < u1) return g - u0;
+      auto it = std::lower_bound(M.ghost_u.begin(), M.ghost_u.end(), (int32_t)g);
+      return (it != M.ghost_u.end() && *it == g) ? nu_own + (it - M.ghost_u.begin()) : -1;
+    };
+    auto local_p = [&](int64_t g) -> int64_t {
+      if (g >= p0 && g < p1) return g - p0;
+      auto it = std::lower_bound(M.ghost_p.begin(), M.ghost_p.end(), (int32_t)g);
+      return (it != M.ghost_p.end() && *it == g) ? np_own + (it - M.ghost_p.begin()) : -1;
+    };
+    const int ca = std::max(0, M.ccol[M.rank] - 1), cb = std::min(M.nx, M.ccol[M.rank + 1] + 1);
+    for (int ci = ca; ci < cb; ++ci)
+      for (int cj = 0; cj < M.ny; ++cj) {
+        if (!M.cell_kept(ci, cj)) continue;
+        int32_t un[16], pn[9];
+        bool touches = false, complete = true;
+        for (int b = 0; b < 4; ++b)
+          for (int a = 0; a < 4; ++a) {
+            const int64_t g = 2 * (int64_t)M.uid[(size_t)(3 * ci + a) * M.NY3 + 3 * cj + b];
+            const int64_t l = local_u(g);
+            touches |= g >= u0 && g < u1;
+            complete &= l >= 0;
+            un[b * 4 + a] = (int32_t)(l / 2);
+          }
+        for (int b = 0; b < 3; ++b)
+          for (int a = 0; a < 3; ++a) {
+            const int64_t g = M.pid[(size_t)(2 * ci + a) * M.NY2 + 2 * cj + b];
+            const int64_t l = local_p(g);
+            touches |= g >= p0 && g < p1;
+            complete &= l >= 0;
+            pn[b * 3 + a] = (int32_t)l;
+          }
+        if (!touches) continue;
+        if (!complete) return -4;  // cannot happen: every DoF of a cell touching an owned row is a column of that row
+        if (ci == 0 && cj == 0 && u0 == 0) M.cell_of_dof0 = (int32_t)M.cell_flags.size();
+        M.cell_u_nodes.insert(M.cell_u_nodes.end(), un, un + 16);
+        M.cell_p_dofs.insert(M.cell_p_dofs.end(), pn, pn + 9);
+        M.cell_flags.push_back(ci == M.nx - 1 ? 1 : 0);
+      }
+  }
   if (p->mode == 1) {
 #pragma omp parallel for schedule(static)
     for (int64_t r = 0; r < np_own; ++r) {
@@ -759,5 +807,21 @@ const double *nsp_x0_p(const nsp_mesh *m) { return m->x0_p.data(); }
 const int32_t *nsp_ghost_u(const nsp_mesh *m) { return m->ghost_u.data(); }
 const int32_t *nsp_ghost_p(const nsp_mesh *m) { return m->ghost_p.data(); }
 const uint8_t *nsp_dirichlet_u(const nsp_mesh *m) { return m->dir_owned.data(); }
+int64_t nsp_n_cells_local(const nsp_mesh *m) { return (int64_t)m->cell_flags.size(); }
+const int32_t *nsp_cell_u_nodes(const nsp_mesh *m) { return m->cell_u_nodes.data(); }
+const int32_t *nsp_cell_p_dofs(const nsp_mesh *m) { return m->cell_p_dofs.data(); }
+const uint8_t *nsp_cell_flags(const nsp_mesh *m) { return m->cell_flags.data(); }
+int32_t nsp_cell_of_dof0(const nsp_mesh *m) { return m->cell_of_dof0; }
+void nsp_cell_tables(const nsp_mesh *m, double *out) {
+  const Tables &T = m->T;
+  std::memcpy(out, T.phi, sizeof(T.phi)); out += 256;
+  std::memcpy(out, T.dpx, sizeof(T.dpx)); out += 256;
+  std::memcpy(out, T.dpy, sizeof(T.dpy)); out += 256;
+  std::memcpy(out, T.psi, sizeof(T.psi)); out += 144;
+  std::memcpy(out, T.jxw, sizeof(T.jxw)); out += 16;
+  // outlet face (x = 2.2, normal (1,0)): integral of the velocity basis functions over the face
+  for (int b = 0; b < 4; ++b)
+    for (int a = 0; a < 4; ++a) out[b * 4 + a] = a == 3 ? m->hy * T.face_w3[b] : 0.0;
+}
 
 }  // extern "C"

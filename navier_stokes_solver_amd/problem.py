@@ -57,9 +57,15 @@ def lib() -> C.CDLL:
             getattr(L, f).argtypes = [C.c_void_p, C.c_int]
         for f, t in (("nsp_rhs_u", C.c_double), ("nsp_rhs_p", C.c_double), ("nsp_x0_u", C.c_double),
                      ("nsp_x0_p", C.c_double), ("nsp_ghost_u", C.c_int32), ("nsp_ghost_p", C.c_int32),
-                     ("nsp_dirichlet_u", C.c_uint8)):
+                     ("nsp_dirichlet_u", C.c_uint8), ("nsp_cell_u_nodes", C.c_int32), ("nsp_cell_p_dofs", C.c_int32),
+                     ("nsp_cell_flags", C.c_uint8)):
             getattr(L, f).restype = C.POINTER(t)
             getattr(L, f).argtypes = [C.c_void_p]
+        L.nsp_n_cells_local.restype = C.c_int64
+        L.nsp_n_cells_local.argtypes = [C.c_void_p]
+        L.nsp_cell_of_dof0.restype = C.c_int32
+        L.nsp_cell_of_dof0.argtypes = [C.c_void_p]
+        L.nsp_cell_tables.argtypes = [C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -108,6 +114,12 @@ class LocalProblem:
     u_ranges: np.ndarray
     p_ranges: np.ndarray
     params: dict = field(default_factory=dict)
+    # assembly hand-off: cells touching an owned DoF (local ids), reference-cell tabulation
+    cell_u_nodes: np.ndarray = None   # [n_cells, 16] velocity node ids (local DoF id / 2)
+    cell_p_dofs: np.ndarray = None    # [n_cells, 9]
+    cell_flags: np.ndarray = None     # [n_cells] bit 0: outlet face
+    cell_of_dof0: int = -1
+    cell_tables: np.ndarray = None    # 944 doubles, see nsk_problem.h
 
     @property
     def n_u(self) -> int:
@@ -203,6 +215,14 @@ def generate(nx: int, ny: int, *, nu: float, mode: int = 1, state=1, inlet_bc: i
             u_ranges=np.array(list(ur), dtype=np.int64), p_ranges=np.array(list(pr), dtype=np.int64),
             params=dict(nx=nx, ny=ny, nu=nu, mode=mode, state=int(state), inlet_bc=inlet_bc, inv_dt=inv_dt, U=U,
                         p_out=p_out))
+        nc = int(L.nsp_n_cells_local(h))
+        out.cell_u_nodes = _arr(L.nsp_cell_u_nodes(h), nc * 16, np.int32, True).reshape(nc, 16)
+        out.cell_p_dofs = _arr(L.nsp_cell_p_dofs(h), nc * 9, np.int32, True).reshape(nc, 9)
+        out.cell_flags = _arr(L.nsp_cell_flags(h), nc, np.uint8, True)
+        out.cell_of_dof0 = int(L.nsp_cell_of_dof0(h))
+        tab = np.empty(944)
+        L.nsp_cell_tables(h, tab.ctypes.data)
+        out.cell_tables = tab
         return out
     finally:
         L.nsp_mesh_destroy(h)

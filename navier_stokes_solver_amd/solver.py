@@ -34,7 +34,8 @@ EXPORTS = [
     "nsk_set_block_csr", "nsk_update_values", "nsk_set_option", "nsk_setup_preconditioner", "nsk_solve",
     "nsk_upload_system", "nsk_solve_resident", "nsk_download_solution", "nsk_spmv", "nsk_jacobian_vmult", "nsk_dot",
     "nsk_tri_apply", "nsk_amg_info", "nsk_tri_get_perm", "nsk_precond_vmult", "nsk_block_nnz", "nsk_get_block", "nsk_get_stats",
-    "nsk_reset_stats", "nsk_time_op", "nsk_profile_begin", "nsk_profile_read", "nsk_profile_end",
+    "nsk_reset_stats", "nsk_assembly_set_cells", "nsk_assembly_set_dirichlet", "nsk_state_set", "nsk_state_get",
+    "nsk_state_save", "nsk_state_update", "nsk_assemble", "nsk_download_rhs", "nsk_time_assemble", "nsk_time_op", "nsk_profile_begin", "nsk_profile_read", "nsk_profile_end",
 ]
 
 
@@ -97,6 +98,15 @@ def lib() -> C.CDLL:
         L.nsk_spmv.argtypes = [vp, C.c_int, f64p, f64p, C.c_int]
         L.nsk_jacobian_vmult.argtypes = [vp, f64p, f64p, f64p, f64p]
         L.nsk_dot.argtypes = [vp, C.c_int, f64p, f64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.nsk_assembly_set_cells.argtypes = [vp, C.c_int64, i32p, i32p, vp, f64p, C.c_int32]
+        L.nsk_assembly_set_dirichlet.argtypes = [vp, vp, f64p]
+        L.nsk_state_set.argtypes = [vp, f64p, f64p]
+        L.nsk_state_get.argtypes = [vp, f64p, f64p]
+        L.nsk_state_save.argtypes = [vp]
+        L.nsk_state_update.argtypes = [vp, C.c_double]
+        L.nsk_assemble.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
+        L.nsk_download_rhs.argtypes = [vp, f64p, f64p]
+        L.nsk_time_assemble.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
         L.nsk_amg_info.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                    C.POINTER(C.c_double)]
         L.nsk_tri_apply.argtypes = [vp, C.c_int, f64p, f64p]
@@ -300,6 +310,50 @@ class LinearSolver:
         rp, col, val = np.empty(n_rows + 1, np.int32), np.empty(nnz, np.int32), np.empty(nnz)
         self._ck(self.L.nsk_get_block(self.h, blk, rp.ctypes.data, col.ctypes.data, val.ctypes.data))
         return rp, col, val
+
+    # ---- device assembly and Newton state ----
+    def set_assembly(self, pr, bc_u=None):
+        """Cell connectivity, reference-cell tables and Dirichlet flags of a LocalProblem."""
+        cu = np.ascontiguousarray(pr.cell_u_nodes, np.int32)
+        cp = np.ascontiguousarray(pr.cell_p_dofs, np.int32)
+        cf = np.ascontiguousarray(pr.cell_flags, np.uint8)
+        tab = _f64(pr.cell_tables)
+        self._ck(self.L.nsk_assembly_set_cells(self.h, cu.shape[0], cu.ctypes.data, cp.ctypes.data, cf.ctypes.data,
+                                               tab.ctypes.data, pr.cell_of_dof0))
+        d = np.ascontiguousarray(pr.dirichlet_u, np.uint8)
+        bc = None if bc_u is None else _f64(bc_u)
+        self._ck(self.L.nsk_assembly_set_dirichlet(self.h, d.ctypes.data, None if bc is None else bc.ctypes.data))
+
+    def state_set(self, u, p):
+        u, p = _f64(u), _f64(p)
+        self._ck(self.L.nsk_state_set(self.h, u.ctypes.data, p.ctypes.data))
+
+    def state_get(self):
+        u, p = np.empty(self.n_u), np.empty(self.n_p)
+        self._ck(self.L.nsk_state_get(self.h, u.ctypes.data, p.ctypes.data))
+        return u, p
+
+    def state_save(self):
+        self._ck(self.L.nsk_state_save(self.h))
+
+    def state_update(self, alpha):
+        self._ck(self.L.nsk_state_update(self.h, float(alpha)))
+
+    def assemble(self, nu, inv_dt=0.0, p_out=1.0, inhomogeneous_bc=False):
+        """Device assembly of block (0,0) and the residual about the resident state; returns ||residual||."""
+        nrm = C.c_double()
+        self._ck(self.L.nsk_assemble(self.h, nu, inv_dt, p_out, int(inhomogeneous_bc), C.byref(nrm)))
+        return nrm.value
+
+    def download_rhs(self):
+        ru, rp = np.empty(self.n_u), np.empty(self.n_p)
+        self._ck(self.L.nsk_download_rhs(self.h, ru.ctypes.data, rp.ctypes.data))
+        return ru, rp
+
+    def time_assemble(self, nu, inv_dt=0.0, reps=10):
+        ms = C.c_double()
+        self._ck(self.L.nsk_time_assemble(self.h, nu, inv_dt, reps, C.byref(ms)))
+        return ms.value
 
     def amg_levels(self, shard=0):
         """[(rows, nnz, lambda_max)] of the velocity AMG of the current setup ([] when there is none)."""

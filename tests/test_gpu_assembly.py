@@ -1,0 +1,169 @@
+"""Device assembly of the Newton system against the host hand-off producer, which is
+itself checked against an independent NumPy assembly (tests/test_problem_generator.py)."""
+import threading
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spl
+
+from navier_stokes_solver_amd import partition as PT
+from navier_stokes_solver_amd import problem as P
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(nx, ny, seed=3):
+    i = P.mesh_info(nx, ny)
+    rng = np.random.default_rng(seed)
+    return 0.1 * rng.standard_normal(i["n_u_global"]), rng.standard_normal(i["n_p_global"])
+
+
+@pytest.mark.parametrize("nx,ny,nu,inv_dt", [(16, 10, 0.05, 0.0), (60, 20, 1 / 90, 0.0), (16, 10, 0.02, 100.0)])
+def test_jacobian_block_and_residual_match_the_host_assembly(nx, ny, nu, inv_dt):
+    """F values (incl. cleared Dirichlet rows with the reference diagonal), residual and its norm; tolerance 1e-12
+    relative to the largest entry (same products, different summation order)."""
+    from navier_stokes_solver_amd import solver as S
+    su, sp = _state(nx, ny)
+    ref = P.generate(nx, ny, nu=nu, mode=1, state=(su, sp), inv_dt=inv_dt)
+    base = P.generate(nx, ny, nu=nu, mode=1, state=1, inv_dt=inv_dt)   # pattern + some other values
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(base)
+        ls.set_assembly(base)
+        ls.state_set(su, sp)
+        nrm = ls.assemble(nu, inv_dt, 1.0)
+        rp, col, val = ls.get_block(S.BLK_F)
+        assert np.array_equal(rp, ref.F.rowptr) and np.array_equal(col, ref.F.col)
+        assert np.abs(val - ref.F.val).max() <= 1e-12 * np.abs(ref.F.val).max()
+        ru, rpp = ls.download_rhs()
+        scale = max(np.abs(ref.rhs_u).max(), np.abs(ref.rhs_p).max())
+        assert np.abs(ru - ref.rhs_u).max() <= 1e-12 * scale and np.abs(rpp - ref.rhs_p).max() <= 1e-12 * scale
+        assert abs(nrm - np.sqrt(ref.rhs_u @ ref.rhs_u + ref.rhs_p @ ref.rhs_p)) <= 1e-12 * nrm
+        # the SpMV that follows uses the node-block copy of the new values
+        x = np.random.default_rng(1).standard_normal(ref.n_u)
+        assert rel_err(ls.spmv(S.BLK_F, x), ref.F.to_scipy() @ x) <= 1e-12
+        # deterministic: a second assembly gives the same bits
+        ls.assemble(nu, inv_dt, 1.0)
+        assert np.array_equal(ls.get_block(S.BLK_F)[2], val)
+    finally:
+        ls.close()
+
+
+def test_inhomogeneous_dirichlet_values_and_state_round_trip():
+    from navier_stokes_solver_amd import solver as S
+    nx, ny, nu = 16, 10, 0.1
+    su, sp = _state(nx, ny, 9)
+    ref = P.generate(nx, ny, nu=nu, mode=1, state=(su, sp), inlet_bc=1)
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(ref)
+        ls.set_assembly(ref, bc_u=ref.x0_u)       # x0_u holds the inlet profile on Dirichlet rows
+        ls.state_set(su, sp)
+        u, p = ls.state_get()
+        assert np.array_equal(u, su) and np.array_equal(p, sp)
+        ls.assemble(nu, 0.0, 1.0, inhomogeneous_bc=True)
+        ru, _ = ls.download_rhs()
+        assert np.abs(ru - ref.rhs_u).max() <= 1e-12 * np.abs(ref.rhs_u).max()
+        xu, xp = ls.download_solution()
+        d = ref.dirichlet_u.astype(bool)
+        assert np.array_equal(xu[d], ref.x0_u[d])
+        with pytest.raises(RuntimeError):
+            ls2 = S.LinearSolver()
+            try:
+                ls2.set_problem(ref)
+                ls2.assemble(nu)                     # no cells / state yet
+            finally:
+                ls2.close()
+    finally:
+        ls.close()
+
+
+def test_newton_iteration_on_the_device_converges_like_a_direct_newton():
+    """assemble -> solve_system -> solution += delta, all resident (solve_newton(), NSSolverStationary.cpp:687-735),
+    against a Newton iteration done with the host assembly and sparse-direct solves.
+
+    Start: the Stokes solution, as in the reference (first continuation step).  That matters: the reference's
+    continuity residual has the sign of its Jacobian block (+b(u,q) against +B, .cpp:437-439 and :491-493), so one
+    Newton step DOUBLES div(u) instead of removing it; the iteration only works from a discretely divergence-free
+    state, where that residual is rounding noise.  Restated faithfully (and visible below: the pressure-row
+    residual doubles from 1e-15)."""
+    from navier_stokes_solver_amd import solver as S
+    nx, ny, nu = 16, 10, 0.1
+    st = P.generate(nx, ny, nu=nu, mode=0, state=0, inlet_bc=1)
+    x = spl.splu(st.jacobian_scipy().tocsc()).solve(np.concatenate([st.rhs_u, st.rhs_p]))
+    u, p = x[:st.n_u].copy(), x[st.n_u:].copy()
+    base = P.generate(nx, ny, nu=nu, mode=1, state=1)
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(base)
+        ls.set_assembly(base)
+        ls.state_set(u, p)
+        uh, ph = u.copy(), p.copy()
+        norms_gpu, norms_cpu = [], []
+        for it in range(3):
+            norms_gpu.append(ls.assemble(nu, 0.0, 1.0))
+            ref = P.generate(nx, ny, nu=nu, mode=1, state=(uh, ph))
+            b = np.concatenate([ref.rhs_u, ref.rhs_p])
+            norms_cpu.append(np.linalg.norm(b))
+            ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+            its, res, rc = ls.solve_resident(S.FGMRES, 1e-13, 20000)
+            assert rc == 0
+            ls.state_save()
+            ls.state_update(1.0)
+            delta = spl.splu(ref.jacobian_scipy().tocsc()).solve(b)
+            uh, ph = uh + delta[:ref.n_u], ph + delta[ref.n_u:]
+        ug, pg = ls.state_get()
+        assert 1e-4 < norms_gpu[0] < 1e-3 and norms_gpu[1] < 1e-4 * norms_gpu[0] and norms_gpu[2] < 1e-11   # quadratic
+        assert np.allclose(norms_gpu[:2], norms_cpu[:2], rtol=1e-4)
+        assert rel_err(np.concatenate([ug, pg]), np.concatenate([uh, ph])) <= 1e-9
+        # line search step of the reference: solution = evaluation_point + alpha * delta
+        ls.state_update(0.1)
+        u01, _ = ls.state_get()
+        ls.state_update(1.0)
+        u10, _ = ls.state_get()
+        xu, _ = ls.download_solution()              # delta of the last solve
+        assert np.array_equal(u10, ug)
+        assert np.abs((u10 - u01) - 0.9 * xu).max() <= 1e-15 * max(1.0, np.abs(u10).max())
+    finally:
+        ls.close()
+
+
+def test_two_ranks_assemble_the_same_system():
+    """Local-group transport: ghost state entries arrive through the halo exchange, d0 through the all-reduce."""
+    from navier_stokes_solver_amd import solver as S
+    nx, ny, nu, world = 16, 10, 0.05, 2
+    su, sp = _state(nx, ny, 4)
+    glob = P.generate(nx, ny, nu=nu, mode=1, state=(su, sp))
+    parts = [P.generate(nx, ny, nu=nu, mode=1, state=1, nranks=world, rank=r) for r in range(world)]
+    refs = [P.generate(nx, ny, nu=nu, mode=1, state=(su, sp), nranks=world, rank=r) for r in range(world)]
+    plans = [{S.SPACE_U: PT.build_halo_plan(r, parts[0].u_ranges, [q.ghost_u for q in parts]),
+              S.SPACE_P: PT.build_halo_plan(r, parts[0].p_ranges, [q.ghost_p for q in parts])} for r in range(world)]
+    uid = S.local_group_id(world)
+    out, errs = [None] * world, []
+
+    def run(r):
+        try:
+            ls = S.LinearSolver(r, world, 0, uid)
+            pr = parts[r]
+            ls.set_problem(pr, plans[r])
+            ls.set_assembly(pr)
+            ur, pg = pr.u_ranges, pr.p_ranges
+            ls.state_set(su[ur[r]:ur[r + 1]], sp[pg[r]:pg[r + 1]])
+            nrm = ls.assemble(nu, 0.0, 1.0)
+            out[r] = (ls.get_block(S.BLK_F)[2], ls.download_rhs(), nrm)
+            ls.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    assert not errs, errs
+    gn = np.sqrt(glob.rhs_u @ glob.rhs_u + glob.rhs_p @ glob.rhs_p)
+    for r in range(world):
+        val, (ru, rp), nrm = out[r]
+        assert np.abs(val - refs[r].F.val).max() <= 1e-12 * np.abs(glob.F.val).max()
+        assert np.abs(ru - refs[r].rhs_u).max() <= 1e-12 * np.abs(glob.rhs_u).max()
+        assert np.abs(rp - refs[r].rhs_p).max() <= 1e-12 * np.abs(glob.rhs_u).max()
+        assert abs(nrm - gn) <= 1e-12 * gn
