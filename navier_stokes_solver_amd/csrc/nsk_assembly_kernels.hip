@@ -66,24 +66,39 @@ __global__ __launch_bounds__(BLK) void asm_F_rows_kernel(AsmMesh M, const double
                                                          const double *__restrict__ d0p, const int *__restrict__ rowptr,
                                                          double *__restrict__ val) {
   __shared__ double rb[4][49 * 4];
-  __shared__ double tab[T_FACE];  // phi, dpx, dpy, psi, jxw
-  for (int i = threadIdx.x; i < T_FACE; i += BLK) tab[i] = M.tables[i];
+  __shared__ double tphi[256], tjxw[16];  // phi[n][q] (n is uniform over 16 lanes: broadcast reads)
+  __shared__ double tT[3][256];           // phi, dphi/dx, dphi/dy transposed to [q][m]: lanes m read consecutive words
+  __shared__ double cs[4][4][96];         // per wave: the quadrature-point state (u, grad u) of its <= 4 cells
+  {
+    const int i = threadIdx.x;             // BLK == 256 == one table
+    tphi[i] = M.tables[T_PHI + i];
+    const int mm = i >> 4, qq = i & 15;
+    tT[0][qq * 16 + mm] = M.tables[T_PHI + i];
+    tT[1][qq * 16 + mm] = M.tables[T_DPX + i];
+    tT[2][qq * 16 + mm] = M.tables[T_DPY + i];
+    if (i < 16) tjxw[i] = M.tables[T_JXW + i];
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = (int)blockIdx.x * 4 + wave;  // owned velocity node
   const bool have = r < M.n_unodes;
   for (int i = lane; i < 49 * 4; i += 64) rb[wave][i] = 0.0;
-  __syncthreads();
   const int k = lane >> 4, m = lane & 15;
   const int cn = have ? M.node_cells[(size_t)r * 4 + k] : -1;
+  if (cn >= 0) {  // the 16 lanes of cell k fetch its 96 values once (6 each)
+    const double *c = cq + (size_t)(cn >> 4) * 112;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) cs[wave][k][f * 16 + m] = c[f * 16 + m];
+  }
+  __syncthreads();
   double b00 = 0, b01 = 0, b10 = 0, b11 = 0;
   if (cn >= 0) {
-    const int cell = cn >> 4, n = cn & 15;
-    const double *c = cq + (size_t)cell * 112;
+    const int n = cn & 15;
+    const double *c = cs[wave][k];
 #pragma unroll 4
     for (int q = 0; q < 16; ++q) {
-      const double w = tab[T_JXW + q] * tab[T_PHI + n * 16 + q];
-      const double pm = tab[T_PHI + m * 16 + q];
-      const double adv = c[q] * tab[T_DPX + m * 16 + q] + c[16 + q] * tab[T_DPY + m * 16 + q];  // (u_old . grad) phi_m
+      const double w = tjxw[q] * tphi[n * 16 + q];
+      const double pm = tT[0][q * 16 + m];
+      const double adv = c[q] * tT[1][q * 16 + m] + c[16 + q] * tT[2][q * 16 + m];  // (u_old . grad) phi_m
       b00 += w * (adv + c[32 + q] * pm);
       b01 += w * (c[48 + q] * pm);
       b10 += w * (c[64 + q] * pm);
