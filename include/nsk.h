@@ -177,6 +177,8 @@ int nsk_get_block(nsk_handle h, int blk, int32_t *rowptr, int32_t *col, double *
  *   last solve (:718-721).  Ghost entries are refreshed by a halo exchange.
  * nsk_assemble: fills block (0,0) (+ Dirichlet clearing), the resident right-hand side and the Dirichlet entries
  *   of the resident initial guess, and returns residual_vector.l2_norm() (:701).  Collective.
+ *   stokes != 0 is the reference's Stokes phase (`computing_stokes`, :383-406, :455-458): no convective part,
+ *   no residual (right-hand side = outlet term + Dirichlet values).
  *   Call nsk_setup_preconditioner afterwards, as solve_system() builds its preconditioner from the new matrix. */
 int nsk_assembly_set_cells(nsk_handle h, int64_t n_cells, const int32_t *cell_u_nodes, const int32_t *cell_p_dofs,
                            const uint8_t *cell_flags, const double *tables944, int32_t cell_of_dof0);
@@ -185,7 +187,11 @@ int nsk_state_set(nsk_handle h, const double *u_owned, const double *p_owned);
 int nsk_state_get(nsk_handle h, double *u_owned, double *p_owned);
 int nsk_state_save(nsk_handle h);
 int nsk_state_update(nsk_handle h, double alpha);
-int nsk_assemble(nsk_handle h, double nu, double inv_dt, double p_out, int inhomogeneous_bc, double *residual_norm);
+int nsk_assemble(nsk_handle h, int stokes, double nu, double inv_dt, double p_out, int inhomogeneous_bc,
+                 double *residual_norm);
+/* values of a resident block times a factor: pressure_mass is assembled with 1/nu (:404, :450), block (1,0)
+ * changes sign between the Stokes and the Newton phase (:397 against :444) */
+int nsk_scale_values(nsk_handle h, int blk, double factor);
 /* resident right-hand side (residual_vector) to the host */
 int nsk_download_rhs(nsk_handle h, double *rhs_u, double *rhs_p);
 /* device time of one assembly (all kernels), averaged over reps */

@@ -46,13 +46,13 @@ __global__ __launch_bounds__(BLK) void asm_cell_state_kernel(AsmMesh M, const do
 
 // |jacobian(0,0) before clearing|: the value MatrixTools::apply_boundary_values puts on Dirichlet rows.
 // Written by the rank that owns global DoF 0 (others write 0; the caller all-reduces).
-__global__ void asm_d0_kernel(AsmMesh M, const double *__restrict__ cq, double nu, double inv_dt, double *out) {
+__global__ void asm_d0_kernel(AsmMesh M, const double *__restrict__ cq, double nu, double inv_dt, int stokes, double *out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double v = 0.0;
   if (M.cell_of_dof0 >= 0) {
     const double *T = M.tables, *c = cq + (size_t)M.cell_of_dof0 * 112;
     v = nu * T[T_K] + inv_dt * T[T_M3];
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < 16 && !stokes; ++q) {
       const double ph = T[T_PHI + q];
       const double adv = c[q] * T[T_DPX + q] + c[16 + q] * T[T_DPY + q];
       v += T[T_JXW + q] * ph * (adv + c[32 + q] * ph);
@@ -63,8 +63,8 @@ __global__ void asm_d0_kernel(AsmMesh M, const double *__restrict__ cq, double n
 
 // jacobian(0,0): one wavefront per owned velocity node, lane = touching cell k (4) x column node m (16)
 __global__ __launch_bounds__(BLK) void asm_F_rows_kernel(AsmMesh M, const double *__restrict__ cq, double nu, double inv_dt,
-                                                         const double *__restrict__ d0p, const int *__restrict__ rowptr,
-                                                         double *__restrict__ val) {
+                                                         int stokes, const double *__restrict__ d0p,
+                                                         const int *__restrict__ rowptr, double *__restrict__ val) {
   __shared__ double rb[4][49 * 4];
   __shared__ double tphi[256], tjxw[16];  // phi[n][q] (n is uniform over 16 lanes: broadcast reads)
   __shared__ double tT[3][256];           // phi, dphi/dx, dphi/dy transposed to [q][m]: lanes m read consecutive words
@@ -94,8 +94,9 @@ __global__ __launch_bounds__(BLK) void asm_F_rows_kernel(AsmMesh M, const double
   if (cn >= 0) {
     const int n = cn & 15;
     const double *c = cs[wave][k];
+    // Stokes phase (assemble_system(.., true), .cpp:383-406): no convective part
 #pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < (stokes ? 0 : 16); ++q) {
       const double w = tjxw[q] * tphi[n * 16 + q];
       const double pm = tT[0][q * 16 + m];
       const double adv = c[q] * tT[1][q * 16 + m] + c[16 + q] * tT[2][q * 16 + m];  // (u_old . grad) phi_m
@@ -135,8 +136,9 @@ __global__ __launch_bounds__(BLK) void asm_F_rows_kernel(AsmMesh M, const double
 
 // residual_vector, velocity rows: -a(u,v) - c(u;u,v) + b(v,p) - outlet Neumann term; Dirichlet rows d0 * value
 __global__ __launch_bounds__(BLK) void asm_rhs_u_kernel(AsmMesh M, const double *__restrict__ cq, double nu, double p_out,
-                                                        const double *__restrict__ d0p, const double *__restrict__ bc,
-                                                        double *__restrict__ rhs, double *__restrict__ x0) {
+                                                        int stokes, const double *__restrict__ d0p,
+                                                        const double *__restrict__ bc, double *__restrict__ rhs,
+                                                        double *__restrict__ x0) {
   const int r = (int)(blockIdx.x * BLK + threadIdx.x);
   if (r >= M.n_unodes) return;
   const double *T = M.tables;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(BLK) void asm_rhs_u_kernel(AsmMesh M, const double 
     if (cn < 0) continue;
     const int cell = cn >> 4, n = cn & 15;
     const double *c = cq + (size_t)cell * 112;
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < (stokes ? 0 : 16); ++q) {   // the Stokes phase skips the residual (`continue`, .cpp:455-458)
       const double w = T[T_JXW + q], ph = T[T_PHI + n * 16 + q], dx = T[T_DPX + n * 16 + q], dy = T[T_DPY + n * 16 + q];
       const double u0 = c[q], u1 = c[16 + q], g00 = c[32 + q], g01 = c[48 + q], g10 = c[64 + q], g11 = c[80 + q],
                    p = c[96 + q];
@@ -167,9 +169,11 @@ __global__ __launch_bounds__(BLK) void asm_rhs_u_kernel(AsmMesh M, const double 
 }
 
 // residual_vector, pressure rows: + b(u,q)
-__global__ __launch_bounds__(BLK) void asm_rhs_p_kernel(AsmMesh M, const double *__restrict__ cq, double *__restrict__ rhs) {
+__global__ __launch_bounds__(BLK) void asm_rhs_p_kernel(AsmMesh M, const double *__restrict__ cq, int stokes,
+                                                        double *__restrict__ rhs) {
   const int r = (int)(blockIdx.x * BLK + threadIdx.x);
   if (r >= M.n_pdofs) return;
+  if (stokes) { rhs[r] = 0.0; return; }
   const double *T = M.tables;
   double v = 0.0;
   for (int k = 0; k < 4; ++k) {
@@ -188,24 +192,24 @@ void asm_cell_state(hipStream_t s, const AsmMesh &M, const double *su, const dou
   const long n = (long)M.n_cells * 16;
   if (n > 0) hipLaunchKernelGGL(asm_cell_state_kernel, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, s, M, su, sp, cq);
 }
-void asm_d0(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double inv_dt, double *out) {
-  hipLaunchKernelGGL(asm_d0_kernel, dim3(1), dim3(64), 0, s, M, cq, nu, inv_dt, out);
+void asm_d0(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double inv_dt, int stokes, double *out) {
+  hipLaunchKernelGGL(asm_d0_kernel, dim3(1), dim3(64), 0, s, M, cq, nu, inv_dt, stokes, out);
 }
-void asm_F_rows(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double inv_dt, const double *d0,
+void asm_F_rows(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double inv_dt, int stokes, const double *d0,
                 const int *rowptr, double *val) {
   if (M.n_unodes > 0)
-    hipLaunchKernelGGL(asm_F_rows_kernel, dim3((unsigned)((M.n_unodes + 3) / 4)), dim3(BLK), 0, s, M, cq, nu, inv_dt, d0,
-                       rowptr, val);
+    hipLaunchKernelGGL(asm_F_rows_kernel, dim3((unsigned)((M.n_unodes + 3) / 4)), dim3(BLK), 0, s, M, cq, nu, inv_dt,
+                       stokes, d0, rowptr, val);
 }
-void asm_rhs_u(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double p_out, const double *d0,
+void asm_rhs_u(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double p_out, int stokes, const double *d0,
                const double *bc, double *rhs, double *x0) {
   if (M.n_unodes > 0)
     hipLaunchKernelGGL(asm_rhs_u_kernel, dim3((unsigned)((M.n_unodes + BLK - 1) / BLK)), dim3(BLK), 0, s, M, cq, nu, p_out,
-                       d0, bc, rhs, x0);
+                       stokes, d0, bc, rhs, x0);
 }
-void asm_rhs_p(hipStream_t s, const AsmMesh &M, const double *cq, double *rhs) {
+void asm_rhs_p(hipStream_t s, const AsmMesh &M, const double *cq, int stokes, double *rhs) {
   if (M.n_pdofs > 0)
-    hipLaunchKernelGGL(asm_rhs_p_kernel, dim3((unsigned)((M.n_pdofs + BLK - 1) / BLK)), dim3(BLK), 0, s, M, cq, rhs);
+    hipLaunchKernelGGL(asm_rhs_p_kernel, dim3((unsigned)((M.n_pdofs + BLK - 1) / BLK)), dim3(BLK), 0, s, M, cq, stokes, rhs);
 }
 
 }  // namespace nsk

@@ -934,7 +934,8 @@ int nsk_state_update(nsk_handle h, double alpha) {
   NSK_CATCH(h)
 }
 
-int nsk_assemble(nsk_handle h, double nu, double inv_dt, double p_out, int inhomogeneous_bc, double *residual_norm) {
+int nsk_assemble(nsk_handle h, int stokes, double nu, double inv_dt, double p_out, int inhomogeneous_bc,
+                 double *residual_norm) {
   NSK_TRY(h)
   (void)hipSetDevice(h->ctx.device);
   auto &A = h->asmd;
@@ -948,16 +949,28 @@ int nsk_assemble(nsk_handle h, double nu, double inv_dt, double p_out, int inhom
   const int sl = h->ctx.alloc_slots(3);
   struct Rel { Ctx &c; int sl; ~Rel() { c.slot_top = sl; } } rel{h->ctx, sl};
   asm_cell_state(s, M, A.sol_u, A.sol_p, A.cq.p);
-  asm_d0(s, M, A.cq.p, nu, inv_dt, h->ctx.slot(sl));
+  stokes = stokes != 0;
+  asm_d0(s, M, A.cq.p, nu, inv_dt, stokes, h->ctx.slot(sl));
   h->ctx.comm.allreduce_sum(h->ctx.slot(sl), 1, s);   // the rank owning global DoF 0 wrote it, the others 0
-  asm_F_rows(s, M, A.cq.p, nu, inv_dt, h->ctx.slot(sl), F.rowptr.p, F.val.p);
+  asm_F_rows(s, M, A.cq.p, nu, inv_dt, stokes, h->ctx.slot(sl), F.rowptr.p, F.val.p);
   F.refresh_blocked(s);
-  asm_rhs_u(s, M, A.cq.p, nu, p_out, h->ctx.slot(sl), inhomogeneous_bc ? A.bc.p : nullptr, h->rhs_b, h->x_b);
-  asm_rhs_p(s, M, A.cq.p, h->rhs_b + h->n_u());
+  asm_rhs_u(s, M, A.cq.p, nu, p_out, stokes, h->ctx.slot(sl), inhomogeneous_bc ? A.bc.p : nullptr, h->rhs_b, h->x_b);
+  asm_rhs_p(s, M, A.cq.p, stokes, h->rhs_b + h->n_u());
   h->ctx.norm2(h->N(), h->rhs_b, sl + 1);
   const double nrm = h->ctx.read_slots(sl + 2, 1)[0];
   if (residual_norm) *residual_norm = nrm;
   A.assemble_ms = wall_ms() - t0;
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_scale_values(nsk_handle h, int blk, double factor) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  if (blk < 0 || blk > NSK_BLK_S || !h->blk[blk].present) throw Error(-52, "nsk_scale_values: no such block");
+  Csr &A = h->blk[blk];
+  vec_scale(h->s(), (int)A.nnz, sref(factor), A.val.p);
+  A.refresh_blocked(h->s());
   return 0;
   NSK_CATCH(h)
 }
@@ -987,11 +1000,11 @@ int nsk_time_assemble(nsk_handle h, double nu, double inv_dt, int reps, double *
   NSK_HIP(hipEventCreate(&e1));
   auto once = [&]() {
     asm_cell_state(s, M, A.sol_u, A.sol_p, A.cq.p);
-    asm_d0(s, M, A.cq.p, nu, inv_dt, h->ctx.slot(sl));
-    asm_F_rows(s, M, A.cq.p, nu, inv_dt, h->ctx.slot(sl), F.rowptr.p, F.val.p);
+    asm_d0(s, M, A.cq.p, nu, inv_dt, 0, h->ctx.slot(sl));
+    asm_F_rows(s, M, A.cq.p, nu, inv_dt, 0, h->ctx.slot(sl), F.rowptr.p, F.val.p);
     F.refresh_blocked(s);
-    asm_rhs_u(s, M, A.cq.p, nu, 1.0, h->ctx.slot(sl), nullptr, h->rhs_b, h->x_b);
-    asm_rhs_p(s, M, A.cq.p, h->rhs_b + h->n_u());
+    asm_rhs_u(s, M, A.cq.p, nu, 1.0, 0, h->ctx.slot(sl), nullptr, h->rhs_b, h->x_b);
+    asm_rhs_p(s, M, A.cq.p, 0, h->rhs_b + h->n_u());
   };
   once();
   NSK_HIP(hipEventRecord(e0, s));

@@ -1,0 +1,153 @@
+"""The reference's Newton / continuation / line-search driver (`NSSolverStationary::solve_newton()`,
+lab_new/src/NSSolverStationary.cpp:649-758) over device-resident state.
+
+`solve_newton(backend, Re)` is the control flow only — continuation ladder 10, 30, ... <= Re, the (cosmetic)
+inlet ramp, at most 15 Newton iterations per pass, backtracking alpha = 1, 0.1, ... > 1e-12, the `break` on a
+0-iteration linear solve — restated line by line, including its quirks.  Everything
+numerical is delegated to a backend:
+
+    assemble(first, stokes, nu) -> ||residual||     assemble_system(global_first_iter, computing_stokes)
+    solve() -> iterations                           solve_system()
+    save()                                          evaluation_point = solution
+    update(alpha)                                   solution = evaluation_point + alpha * delta_owned
+
+`DeviceBackend` keeps solution, delta and residual on the GPU (nsk_assemble / nsk_solve_resident / nsk_state_*);
+the host only sees norms and iteration counts.
+"""
+from __future__ import annotations
+
+N_MAX_ITERS = 15             # NSSolverStationary.cpp:653
+RESIDUAL_TOLERANCE = 1e-9    # :654
+
+
+class InletVelocity:
+    """`InletVelocity::incrementVelocity` (NSSolverStationary.hpp:95-108): u = 0.1, +0.15 per call up to 1.0."""
+
+    def __init__(self, u=0.1, u_max=1.0):
+        self.u, self.u_max = u, u_max
+
+    def reynolds(self, nu):
+        """get_reynolds() (.cpp:760-763) with get_avg_inlet_velocity() = 2 U(0, H/2) / 3 (:899-903)."""
+        return (2.0 * self.u / 3.0) * 0.1 / nu
+
+    def increment(self, re):
+        if self.u == self.u_max:
+            return True
+        self.u += 0.15
+        if re == 0.0:
+            self.u = 0.01
+        if self.u > self.u_max:
+            self.u = self.u_max
+        return False
+
+
+def solve_newton(backend, Re, log=print):
+    """Returns a list of records, one per Newton iteration: (Re level, pass, iteration, ||r|| before the solve,
+    linear iterations, accepted alpha, ||r|| after the update)."""
+    history = []
+    inlet = InletVelocity()
+    global_first_iter, computing_stokes = True, True
+    log("===============================================")
+    log(f"Target Re = {Re:g}")
+    current_re = 10.0
+    while current_re <= Re:                                   # :662
+        log("===============================================")
+        nu = 1.0 / current_re
+        inlet_reached = False
+        log(f"Solving for nu = {nu:g}, Re = {inlet.reynolds(nu):g}")
+        n_pass = 0
+        while not inlet_reached:                              # :669
+            log(f"Solving for inlet velocity: {inlet.u:g}")
+            log("Solving Stokes adding BCs" if global_first_iter else
+                "Solving Stokes without adding BCs" if computing_stokes else "Solving NS")
+            n_iter = 0
+            residual_norm = RESIDUAL_TOLERANCE + 1
+            prev_residual = None
+            while n_iter < N_MAX_ITERS and residual_norm > RESIDUAL_TOLERANCE:   # :683
+                if global_first_iter:
+                    global_first_iter = False
+                    residual_norm = backend.assemble(True, True, nu)
+                else:
+                    residual_norm = backend.assemble(False, computing_stokes, nu)
+                if n_iter == 0:
+                    prev_residual = residual_norm + 1
+                line = f"Newton iteration {n_iter}/{N_MAX_ITERS} - ||r|| = {residual_norm:.6e}"
+                if residual_norm > RESIDUAL_TOLERANCE:
+                    r_before = residual_norm
+                    its = backend.solve()
+                    log(line + f"   {its} solver iterations")
+                    if its == 0:                              # :712
+                        history.append((current_re, n_pass, n_iter, r_before, 0, None, r_before))
+                        break
+                    backend.save()                            # evaluation_point = solution
+                    alpha, accepted = 1.0, None
+                    while alpha > 1e-12:                      # :718
+                        backend.update(alpha)
+                        residual_norm = backend.assemble(False, computing_stokes, nu)
+                        log(f"  Evaluating alpha={alpha:g}, ||r||={residual_norm:g}")
+                        accepted = alpha
+                        if residual_norm < prev_residual:     # :733 (strict)
+                            break
+                        alpha *= 0.1
+                    prev_residual = residual_norm
+                    history.append((current_re, n_pass, n_iter, r_before, its, accepted, residual_norm))
+                else:
+                    log(line + " < tolerance")
+                    break
+                n_iter += 1
+            inlet_reached = inlet.increment(inlet.reynolds(nu))
+            if inlet_reached:
+                computing_stokes = False
+            n_pass += 1
+        current_re += 20.0
+    log("===============================================")
+    return history
+
+
+class DeviceBackend:
+    """Everything resident on the GPU.  `pr` is the hand-off of the first assembly (pattern, constant blocks at
+    viscosity `pr.params['nu']`, Stokes signs, inhomogeneous inlet values in x0_u)."""
+
+    def __init__(self, ls, pr, solver, preconditioner, tolerance, max_iter=20000, alpha=0.5):
+        from . import solver as S
+        self.S, self.ls = S, ls
+        self.solver, self.prec, self.tol, self.max_iter, self.alpha = solver, preconditioner, tolerance, max_iter, alpha
+        assert pr.params["mode"] == 0, "start from the Stokes hand-off (block (1,0) = -B)"
+        self.nu_mp = pr.params["nu"]          # pressure_mass currently holds 1/nu_mp * M
+        self.stokes_signs = True
+        self.p_out = pr.params["p_out"]
+        ls.set_problem(pr)
+        ls.set_assembly(pr, bc_u=pr.x0_u)     # x0_u: inlet profile on the inlet DoFs, 0 elsewhere
+        import numpy as np
+        ls.state_set(np.zeros(pr.n_u), np.zeros(pr.n_p))     # solution = 0 (setup(), .cpp:308-311)
+        self.total_linear_iterations = 0
+        self.assemblies = 0
+
+    def assemble(self, first, stokes, nu):
+        S, ls = self.S, self.ls
+        if nu != self.nu_mp:                  # pressure_mass is assembled with 1/nu (:404, :450)
+            ls.scale_values(S.BLK_MP, self.nu_mp / nu)
+            self.nu_mp = nu
+        if self.stokes_signs != bool(stokes):  # block (1,0): -B in the Stokes phase, +B afterwards (:397, :444)
+            ls.scale_values(S.BLK_B, -1.0)
+            self.stokes_signs = bool(stokes)
+        self.assemblies += 1
+        return ls.assemble(nu, 0.0, self.p_out, inhomogeneous_bc=first, stokes=stokes)
+
+    def solve(self):
+        ls = self.ls
+        ls.setup_preconditioner(self.prec, self.S.STATIONARY, self.alpha)   # a fresh preconditioner per solve_system()
+        its, res, rc = ls.solve_resident(self.solver, self.tol, self.max_iter)
+        if rc != 0:
+            raise RuntimeError(f"solve_system: no convergence (status {rc}) after {its} iterations, residual {res:g}")
+        self.total_linear_iterations += its
+        return its
+
+    def save(self):
+        self.ls.state_save()
+
+    def update(self, alpha):
+        self.ls.state_update(alpha)
+
+    def solution(self):
+        return self.ls.state_get()

@@ -35,7 +35,7 @@ EXPORTS = [
     "nsk_upload_system", "nsk_solve_resident", "nsk_download_solution", "nsk_spmv", "nsk_jacobian_vmult", "nsk_dot",
     "nsk_tri_apply", "nsk_amg_info", "nsk_tri_get_perm", "nsk_precond_vmult", "nsk_block_nnz", "nsk_get_block", "nsk_get_stats",
     "nsk_reset_stats", "nsk_assembly_set_cells", "nsk_assembly_set_dirichlet", "nsk_state_set", "nsk_state_get",
-    "nsk_state_save", "nsk_state_update", "nsk_assemble", "nsk_download_rhs", "nsk_time_assemble", "nsk_time_op", "nsk_profile_begin", "nsk_profile_read", "nsk_profile_end",
+    "nsk_state_save", "nsk_state_update", "nsk_assemble", "nsk_scale_values", "nsk_download_rhs", "nsk_time_assemble", "nsk_time_op", "nsk_profile_begin", "nsk_profile_read", "nsk_profile_end",
 ]
 
 
@@ -104,7 +104,8 @@ def lib() -> C.CDLL:
         L.nsk_state_get.argtypes = [vp, f64p, f64p]
         L.nsk_state_save.argtypes = [vp]
         L.nsk_state_update.argtypes = [vp, C.c_double]
-        L.nsk_assemble.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
+        L.nsk_assemble.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
+        L.nsk_scale_values.argtypes = [vp, C.c_int, C.c_double]
         L.nsk_download_rhs.argtypes = [vp, f64p, f64p]
         L.nsk_time_assemble.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
         L.nsk_amg_info.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
@@ -339,11 +340,14 @@ class LinearSolver:
     def state_update(self, alpha):
         self._ck(self.L.nsk_state_update(self.h, float(alpha)))
 
-    def assemble(self, nu, inv_dt=0.0, p_out=1.0, inhomogeneous_bc=False):
+    def assemble(self, nu, inv_dt=0.0, p_out=1.0, inhomogeneous_bc=False, stokes=False):
         """Device assembly of block (0,0) and the residual about the resident state; returns ||residual||."""
         nrm = C.c_double()
-        self._ck(self.L.nsk_assemble(self.h, nu, inv_dt, p_out, int(inhomogeneous_bc), C.byref(nrm)))
+        self._ck(self.L.nsk_assemble(self.h, int(stokes), nu, inv_dt, p_out, int(inhomogeneous_bc), C.byref(nrm)))
         return nrm.value
+
+    def scale_values(self, blk, factor):
+        self._ck(self.L.nsk_scale_values(self.h, blk, float(factor)))
 
     def download_rhs(self):
         ru, rp = np.empty(self.n_u), np.empty(self.n_p)
