@@ -6,11 +6,12 @@
 Flags, defaults, help text and the configuration echo follow `lab_new/src/testStationary.cpp:7-123`
 and `lab_new/src/test.cpp:8-146` (getopt string "M:m:r:s:t:p:h" / "T:M:m:r:s:t:p:h", so `-M` swallows
 the next token exactly as in the reference).  What runs is the hot path only: for every continuation
-level the reference would visit (`NSSolverStationary.cpp:662-665`, `NSSolver.cpp:684`) the driver
-hands `solve_system()` one system — the first level gets the reference's own first system (Stokes
-with the inlet data, `.cpp:685-689`); later levels get the Newton system linearised about the
-synthetic state (inlet profile extended along x), because the Newton/line-search loop and the FE
-assembly for arbitrary states are outside this path.  `-M` (gmsh meshes) is rejected.
+level the reference would visit (`NSSolverStationary.cpp:662-665`, `NSSolver.cpp:684`):
+`StationaryNSSolver` runs the reference's whole `solve_newton()` (continuation, Stokes phase, Newton iterations
+with backtracking) with assembly, linear solves and vector updates resident on the GPU (`newton.py`);
+`NSSolver` hands `solve_system()` one system per level of one time step — the first level gets the reference's
+own first system (Stokes with the inlet data), later levels the Newton system linearised about the synthetic
+state (inlet profile extended along x); its time loop is a caller of the path.  `-M` (gmsh meshes) is rejected.
 """
 from __future__ import annotations
 
@@ -108,6 +109,24 @@ def run(cfg, unsteady: bool) -> int:
     print(f"    velocity = {info['n_u_global']}\n    pressure = {info['n_p_global']}\n"
           f"    total    = {info['n_u_global'] + info['n_p_global']}")
     print("-----------------------------------------------")
+    if not unsteady:
+        # the reference's solve_newton() over device-resident state: assembly, linear solves and updates on the GPU
+        from . import newton as N
+        ls = S.LinearSolver()
+        ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
+        first_system = P.generate(nx, ny, nu=0.1, mode=0, state=0, inlet_bc=1, U=0.1)   # first level: nu = 1/10
+        backend = N.DeviceBackend(ls, first_system, cfg["solver"], cfg["prec"], cfg["tol"])
+        t0 = time.time()
+        try:
+            N.solve_newton(backend, cfg["Re"])
+        finally:
+            dt = time.time() - t0
+            n = info["n_u_global"] + info["n_p_global"]
+            its = backend.total_linear_iterations
+            print(f"[nsk] {backend.assemblies} assemblies, {its} outer iterations of solve_system(), {dt:.3f} s in "
+                  f"solve_newton -> {n * its / max(dt, 1e-12):.4g} DoF*iters/s")
+            ls.close()
+        return 0
     first, step = (1.0, 10.0) if unsteady else (10.0, 20.0)
     levels = []
     re = first

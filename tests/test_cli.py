@@ -59,6 +59,9 @@ def test_stationary_driver_runs_reference_cpu_config():
     text = out.getvalue()
     assert rc == 0
     assert "total    = 26832" in text and "Solving Stokes adding BCs" in text and "solver iterations" in text
+    # the whole solve_newton() ran: inlet ramp passes of the Stokes phase, backtracking, device assemblies
+    assert "Solving Stokes without adding BCs" in text and "Solving for inlet velocity: 1" in text
+    assert "Evaluating alpha=1," in text and "[nsk]" in text and "Solving NS" not in text   # -r 20: level 10 only
 
 
 def _bin(name):
