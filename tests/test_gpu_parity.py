@@ -214,7 +214,12 @@ def test_solve_matches_oracle_and_direct(handles, name, solver, prec, variant, t
     xs = spl.splu(J).solve(b)
     assert rel_err(x, xo) <= 1e-7, (rel_err(x, xo), its, info["iters"])
     assert rel_err(x, xs) <= 1e-7
-    assert abs(its - info["iters"]) <= max(3, 0.2 * info["iters"]), (its, info["iters"])
+    # The unsteady systems (mass-dominated, fixed or nearly switched-off preconditioners: absolute inner tolerance
+    # 1e-1, NSSolver.hpp:159-169) make restarted FGMRES(30) stagnate for thousands of iterations; the count then
+    # depends on the last bits of the matrix (10 831 ... 14 028 and 2 095 ... 2 754 seen for the same two systems
+    # after a 1-ulp change of the input).  The solution checks above are the parity statement; elsewhere 20 % holds.
+    slack = 0.5 if variant == 1 else 0.2
+    assert abs(its - info["iters"]) <= max(3, slack * info["iters"]), (its, info["iters"])
 
 
 @pytest.mark.parametrize("name,subdomains", [("ns16", 1), ("ns60", 1), ("ns60", 3)])
