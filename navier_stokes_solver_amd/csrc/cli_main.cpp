@@ -4,11 +4,13 @@
 // Flag surface, defaults, help text and the configuration echo follow the reference's drivers
 // (lab_new/src/testStationary.cpp:7-123, lab_new/src/test.cpp:8-146; README.md:56-67): same getopt
 // string ("M:m:r:s:t:p:h", plus "T:" for the unsteady driver — so -M swallows the next token exactly
-// as there), same integer codes for -s / -p.  What runs is the hot path only: one solve_system() per
-// continuation level the reference would visit (NSSolverStationary.cpp:662-665 / NSSolver.cpp:684);
-// the first level gets the reference's own first system (Stokes with the inlet data), later levels the
-// Newton system about the synthetic state.  Newton / line search / assembly for arbitrary states and
-// VTU output are callers / consumers of the path and are not part of it.
+// as there), same integer codes for -s / -p.
+//   StationaryNSSolver runs the reference's whole solve_newton() (NSSolverStationary.cpp:649-758: continuation
+//   ladder, Stokes phase, <= 15 Newton iterations with backtracking) with assembly (nsk_assemble), linear solves
+//   (nsk_solve_resident) and vector updates (nsk_state_*) resident on the GPU — SURVEY 8f rows 1 and 3.
+//   NSSolver hands solve_system() one system per continuation level of one time step (NSSolver.cpp:684): the first
+//   level gets the reference's own first system (Stokes with the inlet data), later levels the Newton system about
+//   the synthetic state; its time loop is a caller of the path.  VTU output is a consumer and not part of it.
 //
 // Built twice from this file: -DNSK_UNSTEADY=0 -> StationaryNSSolver, -DNSK_UNSTEADY=1 -> NSSolver.
 #include <getopt.h>
@@ -45,6 +47,101 @@ static void print_help() {
 static void check(nsk_handle h, int rc, const char *what) {
   if (rc < 0) throw std::runtime_error(std::string(what) + ": " + nsk_last_error(h));
 }
+
+
+#if !NSK_UNSTEADY
+// NSSolverStationary::solve_newton() (NSSolverStationary.cpp:649-758) over device-resident state.
+struct InletVelocity {  // NSSolverStationary.hpp:59-111
+  double u = 0.1;
+  const double U_m = 1.0;
+  double reynolds(double nu) const { return (2.0 * u / 3.0) * 0.1 / nu; }  // get_reynolds(), .cpp:760-763, 899-903
+  bool incrementVelocity(double re) {
+    if (u == U_m) return true;
+    u += 0.15;
+    if (re == 0.0) u = 0.01;
+    if (u > U_m) u = U_m;
+    return false;
+  }
+};
+
+struct NewtonDriver {
+  nsk_handle h;
+  int solver_type, preconditioner;
+  double tolerance, p_out;
+  double nu_mp;          // pressure_mass currently holds 1/nu_mp * M
+  bool stokes_signs = true;
+  long total_its = 0;
+  int assemblies = 0;
+
+  double assemble(bool first, bool stokes, double nu) {  // assemble_system(global_first_iter, computing_stokes)
+    if (nu != nu_mp) { check(h, nsk_scale_values(h, NSK_BLK_MP, nu_mp / nu), "nsk_scale_values"); nu_mp = nu; }
+    if (stokes_signs != stokes) { check(h, nsk_scale_values(h, NSK_BLK_B, -1.0), "nsk_scale_values"); stokes_signs = stokes; }
+    double nrm = 0.0;
+    check(h, nsk_assemble(h, stokes ? 1 : 0, nu, 0.0, p_out, first ? 1 : 0, &nrm), "nsk_assemble");
+    ++assemblies;
+    return nrm;
+  }
+  int solve_system() {
+    check(h, nsk_setup_preconditioner(h, preconditioner, NSK_VARIANT_STATIONARY, 0.5), "nsk_setup_preconditioner");
+    int iters = 0;
+    double res = 0.0;
+    const int rc = nsk_solve_resident(h, solver_type, tolerance, 20000, &iters, &res);
+    check(h, rc, "nsk_solve_resident");
+    if (rc > 0)
+      throw std::runtime_error("Iterative method reported convergence failure in step " + std::to_string(iters) +
+                               ". The residual in the last step was " + std::to_string(res) + ".");
+    total_its += iters;
+    return iters;
+  }
+  void run(double target_Re) {
+    const unsigned n_max_iters = 15;
+    const double residual_tolerance = 1e-9;
+    bool global_first_iter = true, computing_stokes = true, inlet_reached = false;
+    InletVelocity inlet_velocity;
+    for (double current_Re = 10.0; current_Re <= target_Re; current_Re += 20.0) {
+      std::cout << "===============================================" << std::endl;
+      const double nu = 1.0 / current_Re;
+      inlet_reached = false;
+      std::cout << "Solving for nu = " << nu << ", Re = " << inlet_velocity.reynolds(nu) << std::endl;
+      while (!inlet_reached) {
+        std::cout << "Solving for inlet velocity: " << inlet_velocity.u << std::endl;
+        if (global_first_iter) std::cout << "Solving Stokes adding BCs" << std::endl;
+        else if (computing_stokes) std::cout << "Solving Stokes without adding BCs" << std::endl;
+        else std::cout << "Solving NS" << std::endl;
+        unsigned n_iter = 0;
+        double residual_norm = residual_tolerance + 1, prev_residual = 0.0;
+        while (n_iter < n_max_iters && residual_norm > residual_tolerance) {
+          if (global_first_iter) { global_first_iter = false; residual_norm = assemble(true, true, nu); }
+          else residual_norm = assemble(false, computing_stokes, nu);
+          prev_residual = n_iter == 0 ? residual_norm + 1 : prev_residual;
+          std::printf("Newton iteration %u/%u - ||r|| = %.6e", n_iter, n_max_iters, residual_norm);
+          std::fflush(stdout);
+          if (residual_norm > residual_tolerance) {
+            const int GMRES_iter = solve_system();
+            std::cout << "   " << GMRES_iter << " solver iterations" << std::endl;
+            if (GMRES_iter == 0) break;
+            check(h, nsk_state_save(h), "nsk_state_save");          // evaluation_point = solution
+            for (double alpha = 1; alpha > 1e-12; alpha *= 0.1) {
+              check(h, nsk_state_update(h, alpha), "nsk_state_update");
+              residual_norm = assemble(false, computing_stokes, nu);
+              std::cout << "  Evaluating alpha=" << alpha << ", ||r||=" << residual_norm << std::endl;
+              if (residual_norm < prev_residual) break;
+            }
+            prev_residual = residual_norm;
+          } else {
+            std::cout << " < tolerance" << std::endl;
+            break;
+          }
+          ++n_iter;
+        }
+        inlet_reached = inlet_velocity.incrementVelocity(inlet_velocity.reynolds(nu));
+        if (inlet_reached) computing_stokes = false;
+      }
+    }
+    std::cout << "===============================================" << std::endl;
+  }
+};
+#endif
 
 int main(int argc, char *argv[]) {
   bool read_mesh_from_file = false;
@@ -131,6 +228,41 @@ int main(int argc, char *argv[]) {
 
     h = nsk_create(0, 1, 0, nullptr);
     if (!h) throw std::runtime_error("nsk_create failed: no usable GPU (there is no CPU fallback)");
+#if !NSK_UNSTEADY
+    {
+      // first hand-off: pattern, the state-independent blocks at the first level's viscosity (Stokes signs), the
+      // cell connectivity and the inlet values; everything after that happens on the device
+      nsp_params prm;
+      std::memset(&prm, 0, sizeof(prm));
+      prm.mode = 0; prm.state = 0; prm.inlet_bc = 1; prm.nu = 0.1; prm.U = 0.1; prm.p_out = 1.0;
+      if (nsp_assemble(mesh, &prm) != 0) throw std::runtime_error("nsp_assemble failed");
+      const int n_u = (int)nsp_block_rows(mesh, NSP_BLK_F), n_p = (int)nsp_block_rows(mesh, NSP_BLK_B);
+      check(h, nsk_set_partition(h, NSK_SPACE_U, 0, n_u, 0, nullptr), "nsk_set_partition");
+      check(h, nsk_set_partition(h, NSK_SPACE_P, 0, n_p, 0, nullptr), "nsk_set_partition");
+      const int blks[4] = {NSP_BLK_F, NSP_BLK_BT, NSP_BLK_B, NSP_BLK_MP};
+      for (int b : blks)
+        check(h, nsk_set_block_csr(h, b, (int)nsp_block_rows(mesh, b), (int)nsp_block_cols(mesh, b),
+                                   nsp_block_rowptr(mesh, b), nsp_block_col(mesh, b), nsp_block_val(mesh, b)),
+              "nsk_set_block_csr");
+      double tables[944];
+      nsp_cell_tables(mesh, tables);
+      check(h, nsk_assembly_set_cells(h, nsp_n_cells_local(mesh), nsp_cell_u_nodes(mesh), nsp_cell_p_dofs(mesh),
+                                      nsp_cell_flags(mesh), tables, nsp_cell_of_dof0(mesh)), "nsk_assembly_set_cells");
+      check(h, nsk_assembly_set_dirichlet(h, nsp_dirichlet_u(mesh), nsp_x0_u(mesh)), "nsk_assembly_set_dirichlet");
+      std::vector<double> zu((size_t)n_u, 0.0), zp((size_t)n_p, 0.0);
+      check(h, nsk_state_set(h, zu.data(), zp.data()), "nsk_state_set");   // solution = 0
+      NewtonDriver drv{h, solver_type, preconditioner, tolerance, 1.0, 0.1};
+      const auto t0 = std::chrono::steady_clock::now();
+      drv.run(Re);
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      const double n = (double)(info.n_u_global + info.n_p_global);
+      std::printf("[nsk] %d assemblies, %ld outer iterations of solve_system(), %.3f s in solve_newton -> %.4g DoF*iters/s\n",
+                  drv.assemblies, drv.total_its, dt, n * drv.total_its / (dt > 0 ? dt : 1e-12));
+      nsk_destroy(h);
+      nsp_mesh_destroy(mesh);
+      return 0;
+    }
+#endif
     const int variant = NSK_UNSTEADY ? NSK_VARIANT_UNSTEADY : NSK_VARIANT_STATIONARY;
     const int max_iter = NSK_UNSTEADY ? 100000 : 20000;
     long total_its = 0;

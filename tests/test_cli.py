@@ -96,6 +96,31 @@ def test_cpp_stationary_driver_runs_reference_cpu_config():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "Mesh size: 60x20" in out.stdout and "total    = 26832" in out.stdout and "solver iterations" in out.stdout
+    assert "Solving Stokes without adding BCs" in out.stdout and "Evaluating alpha=1," in out.stdout and "[nsk]" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_and_python_newton_drivers_agree():
+    """Both drivers run solve_newton() over the same C ABI: same residual history through the Stokes and the
+    Newton phase (-r 30: levels 10 and 30), quadratic convergence at the end."""
+    import re
+    import subprocess
+    args = ["-m", "16,10", "-r", "30", "-s", "1", "-p", "2", "-t", "1e-11"]
+    cpp = subprocess.run([_bin("StationaryNSSolver")] + args, capture_output=True, text=True, timeout=300)
+    assert cpp.returncode == 0, cpp.stderr
+    out = io.StringIO()
+    with redirect_stdout(out):
+        assert cli.main(["StationaryNSSolver"] + args) == 0
+    pat = re.compile(r"Newton iteration (\d+)/15 - \|\|r\|\| = ([0-9.e+-]+)")
+    a, b = pat.findall(cpp.stdout), pat.findall(out.getvalue())
+    assert "Solving NS" in cpp.stdout and len(a) >= 4
+    ns_a = [float(v) for _, v in a][-2:]
+    ns_b = [float(v) for _, v in b][-2:]
+    assert ns_a[0] > 1e-3 and ns_a[1] < 1e-5 * ns_a[0]             # Newton phase: 2.8e-2 -> 7e-8 (-> 3e-15)
+    for x, y in zip(ns_a, ns_b):
+        assert abs(x - y) <= 1e-5 * max(x, y)
+    last = [float(v) for v in re.findall(r"Evaluating alpha=1, \|\|r\|\|=([0-9.e+-]+)", cpp.stdout)][-1]
+    assert last < 1e-9                                              # below residual_tolerance: the loop ends
 
 
 @pytest.mark.gpu
