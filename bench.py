@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--sync-free", type=int, default=1, help="0 per-level launches, 1 single-launch S/Mp solves, 2 also F")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mesh", type=str, default="300,100")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--converge", type=float, default=0.0, help="if > 0: also run a full solve to this tolerance")
     return ap.parse_args()
