@@ -257,7 +257,8 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"stationary {nx}x{ny} Q3/Q2, Re={args.reynolds:g} (nu=1/{1 / nu:g}) Newton system, "
+                "workload": f"{'stationary' if args.variant == 0 else 'unsteady (dt=0.01)'} {nx}x{ny} Q3/Q2, "
+                            f"Re={args.reynolds:g} (nu=1/{1 / nu:g}) Newton system, "
                             f"solver {['GMRES', 'FGMRES', 'Bicgstab'][args.solver]} + "
                             f"{['blockDiagonal', 'blockTriangular', 'aSIMPLE'][args.preconditioner]}",
                 "dofs": n_global, "n_u_local": pr.n_u, "n_p_local": pr.n_p, "nnz_F_local": pr.F.nnz,
