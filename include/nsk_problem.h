@@ -69,6 +69,10 @@ void nsp_mesh_ranges(const nsp_mesh *m, int64_t *out_u, int64_t *out_p);
  * (n_u_global and n_p_global entries; every rank passes the same vectors).  Copied. */
 int nsp_set_state(nsp_mesh *m, const double *u_global, const double *p_global);
 
+/* solution_old of the time loop (NSSolver.cpp:813) in global DoF numbering, or NULL for none: with state == 2 and
+ * inv_dt != 0 the residual gets the time term -(u - u_old)/dt . v (NSSolver.cpp:460-463).  Copied. */
+int nsp_set_state_old(nsp_mesh *m, const double *u_old_global);
+
 /* Assemble all blocks, rhs and initial guess for this rank.  0 on success,
  * <0 on error (e.g. local nnz overflows int32). */
 int nsp_assemble(nsp_mesh *m, const nsp_params *p);

@@ -155,6 +155,7 @@ struct nsp_mesh {
   std::vector<uint8_t> cell_flags;
   int32_t cell_of_dof0 = -1;
   std::vector<double> state_u, state_p;  // linearisation state in global DoF numbering (params.state == 2)
+  std::vector<double> state_u_old;       // solution_old of the time loop (NSSolver.cpp:813), same numbering; empty = none
   nsp_params prm;
 
   // Element data depends on the cell row only for the analytic states (0, 1) and on the cell for a state
@@ -317,8 +318,15 @@ static void conv_element(const nsp_mesh &M, int ci, int cj, double *C /*32x32*/)
 // residual contribution of one cell to its 32 velocity and 9 pressure rows (NS mode, :456-494)
 static void rhs_element(const nsp_mesh &M, int ci, int cj, double *Ru /*32*/, double *Rp /*9*/) {
   const Tables &T = M.T;
-  double Ux[16], Uy[16], Pn[9];
+  double Ux[16], Uy[16], Pn[9], Ox[16], Oy[16];
   cell_state(M, ci, cj, Ux, Uy, Pn);
+  const bool timed = M.prm.state == 2 && M.prm.inv_dt != 0.0 && !M.state_u_old.empty();
+  for (int b = 0; b < 4 && timed; ++b)
+    for (int a = 0; a < 4; ++a) {
+      const int32_t id = M.uid[(size_t)(3 * ci + a) * M.NY3 + 3 * cj + b];
+      Ox[b * 4 + a] = M.state_u_old[2 * (size_t)id];
+      Oy[b * 4 + a] = M.state_u_old[2 * (size_t)id + 1];
+    }
   std::memset(Ru, 0, sizeof(double) * 32);
   std::memset(Rp, 0, sizeof(double) * 9);
   for (int q = 0; q < 16; ++q) {
@@ -329,6 +337,11 @@ static void rhs_element(const nsp_mesh &M, int ci, int cj, double *Ru /*32*/, do
       g[1][0] += Uy[n] * T.dpx[n][q]; g[1][1] += Uy[n] * T.dpy[n][q];
     }
     for (int m = 0; m < 9; ++m) pq += Pn[m] * T.psi[m][q];
+    double du[2] = {0, 0};  // u - u_old at the quadrature point
+    for (int n = 0; n < 16 && timed; ++n) {
+      du[0] += (Ux[n] - Ox[n]) * T.phi[n][q];
+      du[1] += (Uy[n] - Oy[n]) * T.phi[n][q];
+    }
     const double w = T.jxw[q];
     const double divu = g[0][0] + g[1][1];
     for (int n = 0; n < 16; ++n)
@@ -336,7 +349,7 @@ static void rhs_element(const nsp_mesh &M, int ci, int cj, double *Ru /*32*/, do
         double r = -M.prm.nu * (g[c][0] * T.dpx[n][q] + g[c][1] * T.dpy[n][q]);   // -a(u,v)
         r -= (u[0] * g[c][0] + u[1] * g[c][1]) * T.phi[n][q];                      // -c(u;u,v)
         r += pq * (c == 0 ? T.dpx[n][q] : T.dpy[n][q]);                            // + b(v,p)
-        // the time term with u == u_old vanishes
+        if (timed) r -= M.prm.inv_dt * du[c] * T.phi[n][q];                        // -(u - u_old)/dt . v (NSSolver.cpp:460-463)
         Ru[n * 2 + c] += w * r;
       }
     for (int m = 0; m < 9; ++m) Rp[m] += w * divu * T.psi[m][q];  // + b(u,q)
@@ -603,6 +616,13 @@ int nsp_set_state(nsp_mesh *m, const double *u_global, const double *p_global) {
   if (!m || !u_global || !p_global) return -1;
   m->state_u.assign(u_global, u_global + 2 * (size_t)m->n_unodes);
   m->state_p.assign(p_global, p_global + (size_t)m->n_pnodes);
+  return 0;
+}
+
+int nsp_set_state_old(nsp_mesh *m, const double *u_old_global) {
+  if (!m) return -1;
+  if (!u_old_global) { m->state_u_old.clear(); return 0; }
+  m->state_u_old.assign(u_old_global, u_old_global + 2 * (size_t)m->n_unodes);
   return 0;
 }
 

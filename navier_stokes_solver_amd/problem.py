@@ -48,6 +48,7 @@ def lib() -> C.CDLL:
         L.nsp_mesh_ranges.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.nsp_assemble.argtypes = [C.c_void_p, C.POINTER(_Params)]
         L.nsp_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nsp_set_state_old.argtypes = [C.c_void_p, C.c_void_p]
         L.nsp_assemble.restype = C.c_int
         for f in ("nsp_block_rows", "nsp_block_cols", "nsp_block_nnz"):
             getattr(L, f).restype = C.c_int64
@@ -166,9 +167,10 @@ def mesh_info(nx: int, ny: int, nranks: int = 1, rank: int = 0) -> dict:
 
 def generate(nx: int, ny: int, *, nu: float, mode: int = 1, state=1, inlet_bc: int = 0,
              inv_dt: float = 0.0, U: float = 0.1, p_out: float = 1.0, nranks: int = 1, rank: int = 0,
-             copy: bool = True) -> LocalProblem:
+             copy: bool = True, state_old=None) -> LocalProblem:
     """Assemble rank ``rank``'s share of the nx x ny problem.  ``state``: 0 / 1 (analytic) or a pair
-    (u, p) of GLOBAL velocity / pressure vectors to linearise about (the Newton loop's `solution`)."""
+    (u, p) of GLOBAL velocity / pressure vectors to linearise about (the Newton loop's `solution`);
+    ``state_old``: GLOBAL velocity of the previous time step (`solution_old`) for the residual's time term."""
     L = lib()
     h = L.nsp_mesh_create(nx, ny, nranks, rank)
     if not h:
@@ -184,6 +186,11 @@ def generate(nx: int, ny: int, *, nu: float, mode: int = 1, state=1, inlet_bc: i
             if L.nsp_set_state(h, su.ctypes.data, spv.ctypes.data) != 0:
                 raise RuntimeError("nsp_set_state failed")
             state = 2
+            if state_old is not None:
+                so = np.ascontiguousarray(state_old, dtype=np.float64)
+                if so.shape != (info.n_u_global,):
+                    raise ValueError("state_old must have n_u_global entries")
+                L.nsp_set_state_old(h, so.ctypes.data)
         prm = _Params(mode=mode, state=state, inlet_bc=inlet_bc, reserved=0, nu=nu, inv_dt=inv_dt, U=U, p_out=p_out)
         rc = L.nsp_assemble(h, C.byref(prm))
         if rc != 0:

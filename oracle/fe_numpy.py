@@ -28,7 +28,7 @@ def _deval(coef, x):
     return np.polynomial.polynomial.polyval(x, d.T)
 
 
-def assemble(nx, ny, nu, mode=1, state=1, inlet_bc=0, inv_dt=0.0, U=0.1, p_out=1.0):
+def assemble(nx, ny, nu, mode=1, state=1, inlet_bc=0, inv_dt=0.0, U=0.1, p_out=1.0, state_old=None):
     hx, hy = LX / nx, LY / ny
     gll = np.array([0.0, 0.5 * (1 - 1 / np.sqrt(5)), 0.5 * (1 + 1 / np.sqrt(5)), 1.0])
     q2 = np.array([0.0, 0.5, 1.0])
@@ -126,6 +126,10 @@ def assemble(nx, ny, nu, mode=1, state=1, inlet_bc=0, inv_dt=0.0, U=0.1, p_out=1
                     re[c:32:2] = -nu * ((jxw * g[c, 0]) @ dpx.T + (jxw * g[c, 1]) @ dpy.T) \
                                  - (jxw * (u[0] * g[c, 0] + u[1] * g[c, 1])) @ phi.T
                 pq = Pn @ psi
+                if state_old is not None and inv_dt != 0.0:                       # -(u - u_old)/dt . v
+                    du = np.stack([(Ux - state_old[2 * un]) @ phi, (Uy - state_old[2 * un + 1]) @ phi])
+                    re[0:32:2] -= inv_dt * (jxw * du[0]) @ phi.T
+                    re[1:32:2] -= inv_dt * (jxw * du[1]) @ phi.T
                 re[0:32:2] += (jxw * pq) @ dpx.T                                  # + b(v,p)
                 re[1:32:2] += (jxw * pq) @ dpy.T
                 re[32:] = (jxw * (g[0, 0] + g[1, 1])) @ psi.T

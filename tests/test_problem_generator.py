@@ -84,6 +84,23 @@ def test_arbitrary_linearisation_state_against_numpy_assembly():
     assert np.array_equal(np.concatenate([p.F.val for p in parts]), pr.F.val)   # same rows, ghost columns renumbered
 
 
+def test_time_term_of_the_unsteady_residual():
+    """-(u - u_old)/dt . v (NSSolver.cpp:460-463) and M/dt in the matrix (:443-446) about given states."""
+    from oracle import fe_numpy
+    nx, ny, nu, inv_dt = 16, 10, 1.0, 100.0
+    i = P.mesh_info(nx, ny)
+    rng = np.random.default_rng(8)
+    su, spv = 0.1 * rng.standard_normal(i["n_u_global"]), rng.standard_normal(i["n_p_global"])
+    so = su + 0.01 * rng.standard_normal(i["n_u_global"])
+    ref = fe_numpy.assemble(nx, ny, nu, mode=1, state=(su, spv), inv_dt=inv_dt, state_old=so)
+    pr = P.generate(nx, ny, nu=nu, mode=1, state=(su, spv), inv_dt=inv_dt, state_old=so)
+    assert abs(pr.jacobian_scipy() - ref["J"]).max() <= 1e-12 * abs(ref["J"]).max()
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    assert np.abs(b - ref["rhs"]).max() <= 1e-12 * np.abs(ref["rhs"]).max()
+    no_old = P.generate(nx, ny, nu=nu, mode=1, state=(su, spv), inv_dt=inv_dt)
+    assert np.abs(no_old.rhs_u - pr.rhs_u).max() > 1e-4 * np.abs(pr.rhs_u).max()   # the old state is really used
+
+
 def test_block_structure_signs():
     """Appendix C: Stokes mode is symmetric on free rows with both off-diagonal blocks negative;
     Newton mode flips the (1,0) block."""
