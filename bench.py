@@ -59,8 +59,8 @@ def cpu_baseline(args, nu):
     from navier_stokes_solver_amd import problem as P
     from oracle import oracle as O
     nx, ny = (int(v) for v in args.cpu_mesh.split(","))
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(args.cpu_threads or min(avail, 16), nx // 4))   # a one-GPU box's CPU share is 16 cores
+    from navier_stokes_solver_amd._threads import cpu_budget
+    cores = max(1, min(args.cpu_threads or min(cpu_budget(), 16), nx // 4))   # a one-GPU box's CPU share is 16 cores
     pr = P.generate(nx, ny, nu=nu, mode=1, state=1)
     ranges = P.generate(nx, ny, nu=nu, mode=1, state=1, nranks=cores, rank=0) if cores > 1 else None
     kw = dict(u_shard_off=ranges.u_ranges, p_shard_off=ranges.p_ranges) if ranges is not None else {}
@@ -95,15 +95,12 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
-        # torch.distributed.run pins OMP_NUM_THREADS=1; the host-side hand-off generation and the one-off
-        # symbolic analysis are OpenMP loops, so give every rank its share of the cores (set before any
-        # OpenMP runtime is loaded)
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except (AttributeError, OSError):
-            cores = os.cpu_count() or 1
-        os.environ["OMP_NUM_THREADS"] = str(max(1, min(32, cores // world)))
+    if "OMP_NUM_THREADS" not in os.environ or (world > 1 and os.environ["OMP_NUM_THREADS"] == "1"):
+        # The host-side hand-off generation, the one-off symbolic analysis and the CPU baseline are OpenMP loops:
+        # size their teams after the cgroup CPU quota (the boxes show 256 CPUs for a 16-core share), split over
+        # the ranks of this node (torch.distributed.run pins OMP_NUM_THREADS=1).  Set before any OpenMP runtime loads.
+        from navier_stokes_solver_amd._threads import cpu_budget
+        os.environ["OMP_NUM_THREADS"] = str(max(1, min(32, cpu_budget() // world)))
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -187,6 +187,10 @@ int nsk_state_set(nsk_handle h, const double *u_owned, const double *p_owned);
 int nsk_state_get(nsk_handle h, double *u_owned, double *p_owned);
 int nsk_state_save(nsk_handle h);
 int nsk_state_update(nsk_handle h, double alpha);
+/* solution_old = solution (NSSolver::solve(), NSSolver.cpp:813).  With a saved old state and inv_dt != 0,
+ * nsk_assemble adds the time term -(u - u_old)/dt . v to the residual (NSSolver.cpp:460-463); the mass term
+ * M/dt of the matrix (:443-446) only needs inv_dt. */
+int nsk_state_save_old(nsk_handle h);
 int nsk_assemble(nsk_handle h, int stokes, double nu, double inv_dt, double p_out, int inhomogeneous_bc,
                  double *residual_norm);
 /* values of a resident block times a factor: pressure_mass is assembled with 1/nu (:404, :450), block (1,0)

@@ -9,9 +9,8 @@ the next token exactly as in the reference).  What runs is the hot path only: fo
 level the reference would visit (`NSSolverStationary.cpp:662-665`, `NSSolver.cpp:684`):
 `StationaryNSSolver` runs the reference's whole `solve_newton()` (continuation, Stokes phase, Newton iterations
 with backtracking) with assembly, linear solves and vector updates resident on the GPU (`newton.py`);
-`NSSolver` hands `solve_system()` one system per level of one time step — the first level gets the reference's
-own first system (Stokes with the inlet data), later levels the Newton system linearised about the synthetic
-state (inlet profile extended along x); its time loop is a caller of the path.  `-M` (gmsh meshes) is rejected.
+`NSSolver` runs the reference's time loop (`NSSolver::solve()`, one `solve_newton()` per step with the mass term
+and the `solution_old` term in the device assembly).  `-M` (gmsh meshes) is rejected.
 """
 from __future__ import annotations
 
@@ -127,53 +126,23 @@ def run(cfg, unsteady: bool) -> int:
                   f"solve_newton -> {n * its / max(dt, 1e-12):.4g} DoF*iters/s")
             ls.close()
         return 0
-    first, step = (1.0, 10.0) if unsteady else (10.0, 20.0)
-    levels = []
-    re = first
-    while re <= cfg["Re"]:
-        levels.append(re)
-        re += step
-    print("===============================================")
-    print(f"Target Re = {cfg['Re']:g}")
+    # NSSolver: the reference's time loop (NSSolver::solve(), NSSolver.cpp:799-837) with one solve_newton() per step
+    from . import newton as N
     ls = S.LinearSolver()
-    ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)   # GPU-friendly ILU/SGS ordering
-    variant = S.UNSTEADY if unsteady else S.STATIONARY
-    U = 0.3 if unsteady else 0.1
-    inv_dt = 1.0 / cfg["dt"] if unsteady else 0.0
-    total_its, n_solves, t_solve = 0, 0, 0.0
-    n_steps = max(1, int(round(cfg["T"] / cfg["dt"]))) if unsteady else 1
-    n_steps = min(n_steps, 1)  # the time loop is a caller of the path; one representative step
-    for _ in range(n_steps):
-        for li, re in enumerate(levels):
-            nu = 1.0 / re
-            print("===============================================")
-            print(f"Solving for nu = {nu:g}")
-            stokes = (li == 0)
-            pr = P.generate(nx, ny, nu=nu, mode=0 if stokes else 1, state=0 if stokes else 1,
-                            inlet_bc=1 if stokes else 0, inv_dt=inv_dt, U=U)
-            print("Solving Stokes adding BCs" if stokes else "Solving NS")
-            if li == 0:
-                ls.set_problem(pr)
-            else:
-                for blk, csr in ((S.BLK_F, pr.F), (S.BLK_BT, pr.Bt), (S.BLK_B, pr.B), (S.BLK_MP, pr.Mp)):
-                    ls.update_values(blk, csr.val)
-            rnorm = float(np.sqrt(np.dot(pr.rhs_u, pr.rhs_u) + np.dot(pr.rhs_p, pr.rhs_p)))
-            sys.stdout.write(f"Newton iteration 0/{10 if unsteady else 15} - ||r|| = {rnorm:.6e}")
-            sys.stdout.flush()
-            if unsteady:
-                print(f"\nSolver tolerance: {cfg['tol']:g}")
-            du, dp = pr.x0_u.copy(), pr.x0_p.copy()
-            t0 = time.time()
-            its = ls.solve_system(cfg["solver"], cfg["prec"], cfg["tol"], pr.rhs_u, pr.rhs_p, du, dp, variant=variant)
-            t_solve += time.time() - t0
-            print(f"   {its} {'iterations' if unsteady else 'solver iterations'}")
-            total_its += its
-            n_solves += 1
-    n = info["n_u_global"] + info["n_p_global"]
-    print("===============================================")
-    print(f"[nsk] {n_solves} solve_system() calls, {total_its} outer iterations, {t_solve:.3f} s in solve_system "
-          f"(setup + solve) -> {n * total_its / max(t_solve, 1e-12):.4g} DoF*iters/s")
-    ls.close()
+    ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
+    first_system = P.generate(nx, ny, nu=1.0, mode=0, state=0, inlet_bc=1, U=0.3)        # first level: nu = 1/1
+    backend = N.DeviceBackend(ls, first_system, cfg["solver"], cfg["prec"], cfg["tol"], max_iter=100000,
+                              inv_dt=1.0 / cfg["dt"])
+    t0 = time.time()
+    try:
+        N.time_loop(backend, cfg["T"], cfg["dt"], cfg["Re"])
+    finally:
+        dt = time.time() - t0
+        n = info["n_u_global"] + info["n_p_global"]
+        its = backend.total_linear_iterations
+        print(f"[nsk] {backend.assemblies} assemblies, {its} outer iterations of solve_system(), {dt:.3f} s in the time "
+              f"loop -> {n * its / max(dt, 1e-12):.4g} DoF*iters/s")
+        ls.close()
     return 0
 
 

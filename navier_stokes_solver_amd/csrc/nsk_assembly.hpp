@@ -22,14 +22,16 @@ struct AsmMesh {  // device pointers
   const double *tables;    // phi, dphi/dx, dphi/dy, psi, JxW, outlet face integrals, K, M3 (1456 doubles)
 };
 
-void asm_cell_state(hipStream_t s, const AsmMesh &M, const double *su, const double *sp, double *cq);
+constexpr int kAsmCellDoubles = 144;  // cq entries per cell: 9 fields x 16 quadrature points
+// so: solution_old (velocity) or nullptr
+void asm_cell_state(hipStream_t s, const AsmMesh &M, const double *su, const double *sp, const double *so, double *cq);
 // stokes != 0: the Stokes phase of the reference (assemble_system(.., computing_stokes = true)): no convective
 // part in the matrix, no residual in the right-hand side (only the outlet term and the Dirichlet values)
 void asm_d0(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double inv_dt, int stokes, double *out);
 void asm_F_rows(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double inv_dt, int stokes, const double *d0,
                 const int *rowptr, double *val);
-void asm_rhs_u(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double p_out, int stokes, const double *d0,
-               const double *bc, double *rhs, double *x0);
+void asm_rhs_u(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double inv_dt, double p_out, int stokes,
+               const double *d0, const double *bc, double *rhs, double *x0);
 void asm_rhs_p(hipStream_t s, const AsmMesh &M, const double *cq, int stokes, double *rhs);
 
 }  // namespace nsk

@@ -20,28 +20,34 @@ constexpr int BLK = 256;
 // tables (doubles): phi 0, dpx 256, dpy 512, psi 768, jxw 912, face 928, K 944, M3 1200
 constexpr int T_PHI = 0, T_DPX = 256, T_DPY = 512, T_PSI = 768, T_JXW = 912, T_FACE = 928, T_K = 944, T_M3 = 1200;
 
-// state at the quadrature points of every cell: cq[cell][f][q], f = u0 u1 g00 g01 g10 g11 p
+// state at the quadrature points of every cell: cq[cell][f][q], f = u0 u1 g00 g01 g10 g11 p uold0 uold1
 // (fe_values[velocity].get_function_values / get_function_gradients, fe_values[pressure].get_function_values)
+constexpr int CQ = 144;  // doubles per cell
 __global__ __launch_bounds__(BLK) void asm_cell_state_kernel(AsmMesh M, const double *__restrict__ su,
-                                                             const double *__restrict__ sp, double *__restrict__ cq) {
+                                                             const double *__restrict__ sp,
+                                                             const double *__restrict__ so, double *__restrict__ cq) {
   const long t = (long)blockIdx.x * BLK + threadIdx.x;
   const long cell = t >> 4;
   const int q = (int)(t & 15);
   if (cell >= M.n_cells) return;
   const double *T = M.tables;
-  double u0 = 0, u1 = 0, g00 = 0, g01 = 0, g10 = 0, g11 = 0, p = 0;
+  double u0 = 0, u1 = 0, g00 = 0, g01 = 0, g10 = 0, g11 = 0, p = 0, o0 = 0, o1 = 0;
 #pragma unroll 4
   for (int n = 0; n < 16; ++n) {
     const int node = M.cell_u[cell * 16 + n];
     const double2 uv = *reinterpret_cast<const double2 *>(su + 2 * (size_t)node);
     const double ph = T[T_PHI + n * 16 + q], dx = T[T_DPX + n * 16 + q], dy = T[T_DPY + n * 16 + q];
+    if (so) {  // solution_old (time loop)
+      const double2 ov = *reinterpret_cast<const double2 *>(so + 2 * (size_t)node);
+      o0 += ov.x * ph; o1 += ov.y * ph;
+    }
     u0 += uv.x * ph; u1 += uv.y * ph;
     g00 += uv.x * dx; g01 += uv.x * dy;
     g10 += uv.y * dx; g11 += uv.y * dy;
   }
   for (int m = 0; m < 9; ++m) p += sp[M.cell_p[cell * 9 + m]] * T[T_PSI + m * 16 + q];
-  double *o = cq + (size_t)cell * 112 + q;
-  o[0] = u0; o[16] = u1; o[32] = g00; o[48] = g01; o[64] = g10; o[80] = g11; o[96] = p;
+  double *o = cq + (size_t)cell * CQ + q;
+  o[0] = u0; o[16] = u1; o[32] = g00; o[48] = g01; o[64] = g10; o[80] = g11; o[96] = p; o[112] = o0; o[128] = o1;
 }
 
 // |jacobian(0,0) before clearing|: the value MatrixTools::apply_boundary_values puts on Dirichlet rows.
@@ -50,7 +56,7 @@ __global__ void asm_d0_kernel(AsmMesh M, const double *__restrict__ cq, double n
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double v = 0.0;
   if (M.cell_of_dof0 >= 0) {
-    const double *T = M.tables, *c = cq + (size_t)M.cell_of_dof0 * 112;
+    const double *T = M.tables, *c = cq + (size_t)M.cell_of_dof0 * CQ;
     v = nu * T[T_K] + inv_dt * T[T_M3];
     for (int q = 0; q < 16 && !stokes; ++q) {
       const double ph = T[T_PHI + q];
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(BLK) void asm_F_rows_kernel(AsmMesh M, const double
   const int k = lane >> 4, m = lane & 15;
   const int cn = have ? M.node_cells[(size_t)r * 4 + k] : -1;
   if (cn >= 0) {  // the 16 lanes of cell k fetch its 96 values once (6 each)
-    const double *c = cq + (size_t)(cn >> 4) * 112;
+    const double *c = cq + (size_t)(cn >> 4) * CQ;
 #pragma unroll
     for (int f = 0; f < 6; ++f) cs[wave][k][f * 16 + m] = c[f * 16 + m];
   }
@@ -135,8 +141,8 @@ __global__ __launch_bounds__(BLK) void asm_F_rows_kernel(AsmMesh M, const double
 }
 
 // residual_vector, velocity rows: -a(u,v) - c(u;u,v) + b(v,p) - outlet Neumann term; Dirichlet rows d0 * value
-__global__ __launch_bounds__(BLK) void asm_rhs_u_kernel(AsmMesh M, const double *__restrict__ cq, double nu, double p_out,
-                                                        int stokes, const double *__restrict__ d0p,
+__global__ __launch_bounds__(BLK) void asm_rhs_u_kernel(AsmMesh M, const double *__restrict__ cq, double nu, double inv_dt,
+                                                        double p_out, int stokes, const double *__restrict__ d0p,
                                                         const double *__restrict__ bc, double *__restrict__ rhs,
                                                         double *__restrict__ x0) {
   const int r = (int)(blockIdx.x * BLK + threadIdx.x);
@@ -154,13 +160,14 @@ __global__ __launch_bounds__(BLK) void asm_rhs_u_kernel(AsmMesh M, const double 
     const int cn = M.node_cells[(size_t)r * 4 + k];
     if (cn < 0) continue;
     const int cell = cn >> 4, n = cn & 15;
-    const double *c = cq + (size_t)cell * 112;
+    const double *c = cq + (size_t)cell * CQ;
     for (int q = 0; q < (stokes ? 0 : 16); ++q) {   // the Stokes phase skips the residual (`continue`, .cpp:455-458)
       const double w = T[T_JXW + q], ph = T[T_PHI + n * 16 + q], dx = T[T_DPX + n * 16 + q], dy = T[T_DPY + n * 16 + q];
       const double u0 = c[q], u1 = c[16 + q], g00 = c[32 + q], g01 = c[48 + q], g10 = c[64 + q], g11 = c[80 + q],
                    p = c[96 + q];
-      r0 += w * (-nu * (g00 * dx + g01 * dy) - (u0 * g00 + u1 * g01) * ph + p * dx);
-      r1 += w * (-nu * (g10 * dx + g11 * dy) - (u0 * g10 + u1 * g11) * ph + p * dy);
+      // -a(u,v) - c(u;u,v) + b(v,p) - (u - u_old)/dt . v   (the last one: NSSolver.cpp:460-463, inv_dt = 0 otherwise)
+      r0 += w * (-nu * (g00 * dx + g01 * dy) - (u0 * g00 + u1 * g01) * ph + p * dx - inv_dt * (u0 - c[112 + q]) * ph);
+      r1 += w * (-nu * (g10 * dx + g11 * dy) - (u0 * g10 + u1 * g11) * ph + p * dy - inv_dt * (u1 - c[128 + q]) * ph);
     }
     if (M.cell_flags[cell] & 1) r0 -= p_out * T[T_FACE + n];
   }
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(BLK) void asm_rhs_p_kernel(AsmMesh M, const double 
     const int cm = M.pdof_cells[(size_t)r * 4 + k];
     if (cm < 0) continue;
     const int cell = cm / 9, m = cm % 9;
-    const double *c = cq + (size_t)cell * 112;
+    const double *c = cq + (size_t)cell * CQ;
     for (int q = 0; q < 16; ++q) v += T[T_JXW + q] * (c[32 + q] + c[80 + q]) * T[T_PSI + m * 16 + q];
   }
   rhs[r] = v;
@@ -188,9 +195,9 @@ __global__ __launch_bounds__(BLK) void asm_rhs_p_kernel(AsmMesh M, const double 
 
 }  // namespace
 
-void asm_cell_state(hipStream_t s, const AsmMesh &M, const double *su, const double *sp, double *cq) {
+void asm_cell_state(hipStream_t s, const AsmMesh &M, const double *su, const double *sp, const double *so, double *cq) {
   const long n = (long)M.n_cells * 16;
-  if (n > 0) hipLaunchKernelGGL(asm_cell_state_kernel, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, s, M, su, sp, cq);
+  if (n > 0) hipLaunchKernelGGL(asm_cell_state_kernel, dim3((unsigned)((n + BLK - 1) / BLK)), dim3(BLK), 0, s, M, su, sp, so, cq);
 }
 void asm_d0(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double inv_dt, int stokes, double *out) {
   hipLaunchKernelGGL(asm_d0_kernel, dim3(1), dim3(64), 0, s, M, cq, nu, inv_dt, stokes, out);
@@ -201,11 +208,11 @@ void asm_F_rows(hipStream_t s, const AsmMesh &M, const double *cq, double nu, do
     hipLaunchKernelGGL(asm_F_rows_kernel, dim3((unsigned)((M.n_unodes + 3) / 4)), dim3(BLK), 0, s, M, cq, nu, inv_dt,
                        stokes, d0, rowptr, val);
 }
-void asm_rhs_u(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double p_out, int stokes, const double *d0,
-               const double *bc, double *rhs, double *x0) {
+void asm_rhs_u(hipStream_t s, const AsmMesh &M, const double *cq, double nu, double inv_dt, double p_out, int stokes,
+               const double *d0, const double *bc, double *rhs, double *x0) {
   if (M.n_unodes > 0)
-    hipLaunchKernelGGL(asm_rhs_u_kernel, dim3((unsigned)((M.n_unodes + BLK - 1) / BLK)), dim3(BLK), 0, s, M, cq, nu, p_out,
-                       stokes, d0, bc, rhs, x0);
+    hipLaunchKernelGGL(asm_rhs_u_kernel, dim3((unsigned)((M.n_unodes + BLK - 1) / BLK)), dim3(BLK), 0, s, M, cq, nu, inv_dt,
+                       p_out, stokes, d0, bc, rhs, x0);
 }
 void asm_rhs_p(hipStream_t s, const AsmMesh &M, const double *cq, int stokes, double *rhs) {
   if (M.n_pdofs > 0)

@@ -13,6 +13,8 @@
 #include <memory>
 
 #include "../../include/nsk.h"
+#include "../../include/nsk_threads.h"
+#include <omp.h>
 #include "nsk_solver.hpp"
 #include "nsk_amg.hpp"
 #include "nsk_assembly.hpp"
@@ -108,6 +110,8 @@ struct nsk_handle_s {
     DBuf<unsigned char> cell_flags, node_off, dirichlet;
     DBuf<double> tables, cq, bc;
     double *sol_u = nullptr, *sol_p = nullptr, *eval_u = nullptr, *eval_p = nullptr;  // pool vectors [owned | ghost]
+    double *old_u = nullptr;  // solution_old of the time loop (velocity part; the pressure is not used)
+    bool have_old = false;
     double assemble_ms = 0;
   } asmd;
   AsmMesh asm_view() const {
@@ -509,7 +513,17 @@ int nsk_local_group_id(int nranks, void *out128) {
   return 0;
 }
 
+static void cap_host_threads() {  // see nsk_threads.h: the symbolic phases and the AMG set-up are OpenMP loops
+  static bool done = false;
+  if (done) return;
+  done = true;
+  if (getenv("OMP_NUM_THREADS")) return;
+  const int q = nsk_cpu_budget();
+  if (q < omp_get_max_threads()) omp_set_num_threads(q);
+}
+
 nsk_handle nsk_create(int rank, int nranks, int device_id, const void *uid) {
+  cap_host_threads();
   H *h = new H();
   try {
     h->ctx.init(device_id);
@@ -856,8 +870,11 @@ int nsk_assembly_set_cells(nsk_handle h, int64_t n_cells, const int32_t *cell_u_
   A.node_off.upload(node_off, s);
   A.pdof_cells.upload(pdof_cells, s);
   A.tables.upload(tab, s);
-  A.cq.alloc((size_t)n_cells * 112);
-  if (!A.sol_u) { A.sol_u = h->pool_u.get(true); A.eval_u = h->pool_u.get(true); A.sol_p = h->pool_p.get(true); A.eval_p = h->pool_p.get(true); }
+  A.cq.alloc((size_t)n_cells * kAsmCellDoubles);
+  if (!A.sol_u) {
+    A.sol_u = h->pool_u.get(true); A.eval_u = h->pool_u.get(true); A.old_u = h->pool_u.get(true);
+    A.sol_p = h->pool_p.get(true); A.eval_p = h->pool_p.get(true);
+  }
   h->ctx.sync();
   A.ready = true;
   return 0;
@@ -918,6 +935,18 @@ int nsk_state_save(nsk_handle h) {
   NSK_CATCH(h)
 }
 
+int nsk_state_save_old(nsk_handle h) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  auto &A = h->asmd;
+  if (!A.state_set) throw Error(-66, "no state on the device");
+  // solution_old = solution (NSSolver.cpp:813), ghost entries included
+  vec_copy(h->s(), h->n_u() + h->sp[0].ng, A.sol_u, A.old_u);
+  A.have_old = true;
+  return 0;
+  NSK_CATCH(h)
+}
+
 int nsk_state_update(nsk_handle h, double alpha) {
   NSK_TRY(h)
   (void)hipSetDevice(h->ctx.device);
@@ -948,13 +977,15 @@ int nsk_assemble(nsk_handle h, int stokes, double nu, double inv_dt, double p_ou
   const AsmMesh M = h->asm_view();
   const int sl = h->ctx.alloc_slots(3);
   struct Rel { Ctx &c; int sl; ~Rel() { c.slot_top = sl; } } rel{h->ctx, sl};
-  asm_cell_state(s, M, A.sol_u, A.sol_p, A.cq.p);
+  asm_cell_state(s, M, A.sol_u, A.sol_p, A.have_old ? A.old_u : nullptr, A.cq.p);
   stokes = stokes != 0;
   asm_d0(s, M, A.cq.p, nu, inv_dt, stokes, h->ctx.slot(sl));
   h->ctx.comm.allreduce_sum(h->ctx.slot(sl), 1, s);   // the rank owning global DoF 0 wrote it, the others 0
   asm_F_rows(s, M, A.cq.p, nu, inv_dt, stokes, h->ctx.slot(sl), F.rowptr.p, F.val.p);
   F.refresh_blocked(s);
-  asm_rhs_u(s, M, A.cq.p, nu, p_out, stokes, h->ctx.slot(sl), inhomogeneous_bc ? A.bc.p : nullptr, h->rhs_b, h->x_b);
+  // the time term of the residual needs solution_old (nsk_state_save_old); without one it is left out
+  asm_rhs_u(s, M, A.cq.p, nu, A.have_old ? inv_dt : 0.0, p_out, stokes, h->ctx.slot(sl),
+            inhomogeneous_bc ? A.bc.p : nullptr, h->rhs_b, h->x_b);
   asm_rhs_p(s, M, A.cq.p, stokes, h->rhs_b + h->n_u());
   h->ctx.norm2(h->N(), h->rhs_b, sl + 1);
   const double nrm = h->ctx.read_slots(sl + 2, 1)[0];
@@ -999,11 +1030,11 @@ int nsk_time_assemble(nsk_handle h, double nu, double inv_dt, int reps, double *
   NSK_HIP(hipEventCreate(&e0));
   NSK_HIP(hipEventCreate(&e1));
   auto once = [&]() {
-    asm_cell_state(s, M, A.sol_u, A.sol_p, A.cq.p);
+    asm_cell_state(s, M, A.sol_u, A.sol_p, A.have_old ? A.old_u : nullptr, A.cq.p);
     asm_d0(s, M, A.cq.p, nu, inv_dt, 0, h->ctx.slot(sl));
     asm_F_rows(s, M, A.cq.p, nu, inv_dt, 0, h->ctx.slot(sl), F.rowptr.p, F.val.p);
     F.refresh_blocked(s);
-    asm_rhs_u(s, M, A.cq.p, nu, 1.0, 0, h->ctx.slot(sl), nullptr, h->rhs_b, h->x_b);
+    asm_rhs_u(s, M, A.cq.p, nu, A.have_old ? inv_dt : 0.0, 1.0, 0, h->ctx.slot(sl), nullptr, h->rhs_b, h->x_b);
     asm_rhs_p(s, M, A.cq.p, 0, h->rhs_b + h->n_u());
   };
   once();

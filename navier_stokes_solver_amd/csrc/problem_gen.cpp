@@ -22,6 +22,8 @@
 // adjacent (2*node + comp), as deal.II's FESystem numbering yields per support
 // point.
 #include "nsk_problem.h"
+#include "nsk_threads.h"
+#include <omp.h>
 
 #include <algorithm>
 #include <cmath>
@@ -586,7 +588,17 @@ static void sort_unique(std::vector<int32_t> &v) {
 
 extern "C" {
 
+static void cap_host_threads() {  // see nsk_threads.h
+  static bool done = false;
+  if (done) return;
+  done = true;
+  if (getenv("OMP_NUM_THREADS")) return;
+  const int q = nsk_cpu_budget();
+  if (q < omp_get_max_threads()) omp_set_num_threads(q);
+}
+
 nsp_mesh *nsp_mesh_create(int32_t nx, int32_t ny, int32_t nranks, int32_t rank) {
+  cap_host_threads();
   if (nx < 1 || ny < 1 || nranks < 1 || rank < 0 || rank >= nranks || nranks > nx) return nullptr;
   if ((int64_t)(3 * (int64_t)nx + 1) * (3 * (int64_t)ny + 1) * 2 > INT32_MAX) return nullptr;
   nsp_mesh *M = new nsp_mesh();

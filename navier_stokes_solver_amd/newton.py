@@ -104,13 +104,86 @@ def solve_newton(backend, Re, log=print):
     return history
 
 
+def solve_newton_unsteady(backend, Re, apply_first, log=print):
+    """`NSSolver::solve_newton()` (lab_new/src/NSSolver.cpp:674-754), called once per time step: continuation ladder
+    1, 11, ... <= Re, at most 10 Newton iterations per level, the first assembly of the call in `first_iter` mode
+    (Stokes-like matrix without the mass term, no residual; inhomogeneous inlet values only on the first time
+    step, `apply_first`), acceptance `<=` (:738)."""
+    history = []
+    n_max_iters = 10
+    first_iter = True
+    log("===============================================")
+    log(f"Target Re = {Re:g}")
+    current_re = 1.0
+    while current_re <= Re:
+        log("===============================================")
+        nu = 1.0 / current_re
+        log(f"Solving for Re = {0.02 / nu:g}")            # get_reynolds() = U_avg * 0.1 / nu with U_m = 0.3 (:756-759)
+        n_iter = 0
+        residual_norm = RESIDUAL_TOLERANCE + 1
+        prev_residual = None
+        while n_iter < n_max_iters and residual_norm > RESIDUAL_TOLERANCE:
+            if first_iter:
+                first_iter = False
+                residual_norm = backend.assemble(apply_first, True, nu)
+            else:
+                residual_norm = backend.assemble(False, False, nu)
+            if n_iter == 0:
+                prev_residual = residual_norm + 1
+            line = f"Newton iteration {n_iter}/{n_max_iters} - ||r|| = {residual_norm:.6e}"
+            if residual_norm > RESIDUAL_TOLERANCE:
+                r_before = residual_norm
+                its = backend.solve()
+                log(line + f"   {its} iterations")
+                if its == 0:
+                    history.append((current_re, 0, n_iter, r_before, 0, None, r_before))
+                    break
+                backend.save()
+                alpha, accepted = 1.0, None
+                while alpha > 1e-12:
+                    backend.update(alpha)
+                    residual_norm = backend.assemble(False, False, nu)
+                    log(f"  Evaluating alpha={alpha:g}, ||r||={residual_norm:g}")
+                    accepted = alpha
+                    if residual_norm <= prev_residual:     # :738
+                        break
+                    alpha *= 0.1
+                prev_residual = residual_norm
+                history.append((current_re, 0, n_iter, r_before, its, accepted, residual_norm))
+            else:
+                log(line + " < tolerance")
+                break
+            n_iter += 1
+        current_re += 10.0
+    log("===============================================")
+    return history
+
+
+def time_loop(backend, T, dt, Re, log=print, max_steps=None):
+    """`NSSolver::solve()` (NSSolver.cpp:799-837) without output / lift-drag: solution_old = solution, one Newton
+    solve per time step."""
+    history = []
+    time, step, apply_first = 0.0, 0, True
+    while time < T - 0.5 * dt and (max_steps is None or step < max_steps):
+        time += dt
+        step += 1
+        backend.push_old()                                 # solution_old = solution
+        log(f"n = {step:3d}, t = {time:5.6f}")
+        history.append(solve_newton_unsteady(backend, Re, apply_first, log))
+        apply_first = False
+        log("")
+    return history
+
+
 class DeviceBackend:
     """Everything resident on the GPU.  `pr` is the hand-off of the first assembly (pattern, constant blocks at
     viscosity `pr.params['nu']`, Stokes signs, inhomogeneous inlet values in x0_u)."""
 
-    def __init__(self, ls, pr, solver, preconditioner, tolerance, max_iter=20000, alpha=0.5):
+    def __init__(self, ls, pr, solver, preconditioner, tolerance, max_iter=20000, alpha=0.5, inv_dt=0.0):
         from . import solver as S
         self.S, self.ls = S, ls
+        self.inv_dt = inv_dt                  # 0: stationary driver; 1/delta_t: unsteady driver (NSSolver)
+        self.variant = S.STATIONARY if inv_dt == 0.0 else S.UNSTEADY
         self.solver, self.prec, self.tol, self.max_iter, self.alpha = solver, preconditioner, tolerance, max_iter, alpha
         assert pr.params["mode"] == 0, "start from the Stokes hand-off (block (1,0) = -B)"
         self.nu_mp = pr.params["nu"]          # pressure_mass currently holds 1/nu_mp * M
@@ -132,11 +205,12 @@ class DeviceBackend:
             ls.scale_values(S.BLK_B, -1.0)
             self.stokes_signs = bool(stokes)
         self.assemblies += 1
-        return ls.assemble(nu, 0.0, self.p_out, inhomogeneous_bc=first, stokes=stokes)
+        # the Stokes-like first assembly of NSSolver has no mass term either (NSSolver.cpp:381-404)
+        return ls.assemble(nu, 0.0 if stokes else self.inv_dt, self.p_out, inhomogeneous_bc=first, stokes=stokes)
 
     def solve(self):
         ls = self.ls
-        ls.setup_preconditioner(self.prec, self.S.STATIONARY, self.alpha)   # a fresh preconditioner per solve_system()
+        ls.setup_preconditioner(self.prec, self.variant, self.alpha)        # a fresh preconditioner per solve_system()
         its, res, rc = ls.solve_resident(self.solver, self.tol, self.max_iter)
         if rc != 0:
             raise RuntimeError(f"solve_system: no convergence (status {rc}) after {its} iterations, residual {res:g}")
@@ -145,6 +219,9 @@ class DeviceBackend:
 
     def save(self):
         self.ls.state_save()
+
+    def push_old(self):
+        self.ls.state_save_old()
 
     def update(self, alpha):
         self.ls.state_update(alpha)

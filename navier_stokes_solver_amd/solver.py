@@ -35,7 +35,7 @@ EXPORTS = [
     "nsk_upload_system", "nsk_solve_resident", "nsk_download_solution", "nsk_spmv", "nsk_jacobian_vmult", "nsk_dot",
     "nsk_tri_apply", "nsk_amg_info", "nsk_tri_get_perm", "nsk_precond_vmult", "nsk_block_nnz", "nsk_get_block", "nsk_get_stats",
     "nsk_reset_stats", "nsk_assembly_set_cells", "nsk_assembly_set_dirichlet", "nsk_state_set", "nsk_state_get",
-    "nsk_state_save", "nsk_state_update", "nsk_assemble", "nsk_scale_values", "nsk_download_rhs", "nsk_time_assemble", "nsk_time_op", "nsk_profile_begin", "nsk_profile_read", "nsk_profile_end",
+    "nsk_state_save", "nsk_state_save_old", "nsk_state_update", "nsk_assemble", "nsk_scale_values", "nsk_download_rhs", "nsk_time_assemble", "nsk_time_op", "nsk_profile_begin", "nsk_profile_read", "nsk_profile_end",
 ]
 
 
@@ -103,6 +103,7 @@ def lib() -> C.CDLL:
         L.nsk_state_set.argtypes = [vp, f64p, f64p]
         L.nsk_state_get.argtypes = [vp, f64p, f64p]
         L.nsk_state_save.argtypes = [vp]
+        L.nsk_state_save_old.argtypes = [vp]
         L.nsk_state_update.argtypes = [vp, C.c_double]
         L.nsk_assemble.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
         L.nsk_scale_values.argtypes = [vp, C.c_int, C.c_double]
@@ -336,6 +337,9 @@ class LinearSolver:
 
     def state_save(self):
         self._ck(self.L.nsk_state_save(self.h))
+
+    def state_save_old(self):
+        self._ck(self.L.nsk_state_save_old(self.h))
 
     def state_update(self, alpha):
         self._ck(self.L.nsk_state_update(self.h, float(alpha)))

@@ -7,6 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Before any OpenMP runtime loads: size the teams after the cgroup CPU quota, not after the 256 CPUs the GPU boxes
+# show (a 1 ms generator call takes 3 s with 256 threads on a 16-core share).
+from navier_stokes_solver_amd._threads import cpu_budget  # noqa: E402
+
+os.environ.setdefault("OMP_NUM_THREADS", str(cpu_budget()))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

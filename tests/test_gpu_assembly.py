@@ -50,6 +50,30 @@ def test_jacobian_block_and_residual_match_the_host_assembly(nx, ny, nu, inv_dt)
         ls.close()
 
 
+def test_time_term_with_a_saved_old_state():
+    """solution_old = solution (NSSolver.cpp:813), then a different solution: -(u - u_old)/dt . v in the residual."""
+    from navier_stokes_solver_amd import solver as S
+    nx, ny, nu, inv_dt = 16, 10, 1.0, 100.0
+    su, sp = _state(nx, ny, 6)
+    so = su + 0.01 * np.random.default_rng(7).standard_normal(su.size)
+    ref = P.generate(nx, ny, nu=nu, mode=1, state=(su, sp), inv_dt=inv_dt, state_old=so)
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(ref)
+        ls.set_assembly(ref)
+        ls.state_set(so, sp)
+        ls.state_save_old()
+        ls.state_set(su, sp)
+        nrm = ls.assemble(nu, inv_dt, 1.0)
+        ru, rp = ls.download_rhs()
+        scale = np.abs(ref.rhs_u).max()
+        assert np.abs(ru - ref.rhs_u).max() <= 1e-12 * scale and np.abs(rp - ref.rhs_p).max() <= 1e-12 * scale
+        assert np.abs(ls.get_block(S.BLK_F)[2] - ref.F.val).max() <= 1e-12 * np.abs(ref.F.val).max()
+        assert abs(nrm - np.sqrt(ref.rhs_u @ ref.rhs_u + ref.rhs_p @ ref.rhs_p)) <= 1e-12 * nrm
+    finally:
+        ls.close()
+
+
 def test_inhomogeneous_dirichlet_values_and_state_round_trip():
     from navier_stokes_solver_amd import solver as S
     nx, ny, nu = 16, 10, 0.1

@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 class HostBackend:
     """Test infrastructure: the four backend operations with host assembly + splu (no Krylov tolerance)."""
 
-    def __init__(self, nx, ny, tol):
-        self.nx, self.ny, self.tol = nx, ny, tol
+    def __init__(self, nx, ny, tol, inv_dt=0.0, U=0.1):
+        self.nx, self.ny, self.tol, self.inv_dt, self.U = nx, ny, tol, inv_dt, U
+        self.old = None
         i = P.mesh_info(nx, ny)
         self.u, self.p = np.zeros(i["n_u_global"]), np.zeros(i["n_p_global"])
         self.delta = np.zeros(i["n_u_global"] + i["n_p_global"])
@@ -23,9 +24,10 @@ class HostBackend:
 
     def assemble(self, first, stokes, nu):
         if stokes:
-            pr = P.generate(self.nx, self.ny, nu=nu, mode=0, state=0, inlet_bc=int(first))
+            pr = P.generate(self.nx, self.ny, nu=nu, mode=0, state=0, inlet_bc=int(first), U=self.U)
         else:
-            pr = P.generate(self.nx, self.ny, nu=nu, mode=1, state=(self.u, self.p))
+            pr = P.generate(self.nx, self.ny, nu=nu, mode=1, state=(self.u, self.p), inv_dt=self.inv_dt,
+                            state_old=self.old, U=self.U)
         self.J = pr.jacobian_scipy().tocsc()
         self.b = np.concatenate([pr.rhs_u, pr.rhs_p])
         d = pr.dirichlet_u.astype(bool)
@@ -44,6 +46,9 @@ class HostBackend:
     def update(self, alpha):
         self.u = self.eu + alpha * self.delta[:self.n_u]
         self.p = self.ep + alpha * self.delta[self.n_u:]
+
+    def push_old(self):
+        self.old = self.u.copy()
 
 
 def test_inlet_ramp_matches_the_reference_sequence():
@@ -86,3 +91,30 @@ def test_newton_driver_on_the_device_matches_the_host_driver():
     chk = P.generate(nx, ny, nu=1 / 30.0, mode=1, state=(u, p))
     free = chk.dirichlet_u == 0
     assert np.linalg.norm(chk.rhs_u[free]) < 1e-8
+
+
+def test_unsteady_time_loop_on_the_device_matches_the_host_driver():
+    """NSSolver::solve() + solve_newton() (NSSolver.cpp:674-754, 799-837): two time steps, levels Re = 1 and 11,
+    mass term and -(u - u_old)/dt in the device assembly, `<=` acceptance."""
+    from navier_stokes_solver_amd import solver as S
+    nx, ny, Re, tol, dt = 16, 10, 11.0, 1e-12, 0.01
+    host = HostBackend(nx, ny, tol, inv_dt=1.0 / dt, U=0.3)
+    h_hist = N.time_loop(host, 2 * dt, dt, Re, log=lambda *_: None)
+    first = P.generate(nx, ny, nu=1.0, mode=0, state=0, inlet_bc=1, U=0.3)
+    ls = S.LinearSolver()
+    try:
+        dev = N.DeviceBackend(ls, first, S.FGMRES, S.ASIMPLE, tol, max_iter=100000, inv_dt=1.0 / dt)
+        lines = []
+        d_hist = N.time_loop(dev, 2 * dt, dt, Re, log=lines.append)
+        u, p = dev.solution()
+    finally:
+        ls.close()
+    assert len(d_hist) == len(h_hist) == 2
+    for dstep, hstep in zip(d_hist, h_hist):
+        dw, hw = [r for r in dstep if r[4] > 0], [r for r in hstep if r[4] > 0]
+        assert [(r[0], r[2], r[5]) for r in dw] == [(r[0], r[2], r[5]) for r in hw]
+        for dr, hr in zip(dw, hw):
+            assert abs(dr[3] - hr[3]) <= 1e-6 * max(hr[3], 1e-6), (dr, hr)
+    assert rel_err(np.concatenate([u, p]), np.concatenate([host.u, host.p])) <= 1e-7
+    text = "\n".join(str(x) for x in lines)
+    assert "n =   2" in text and "Solving for Re = 0.22" in text
