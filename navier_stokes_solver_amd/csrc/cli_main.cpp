@@ -8,9 +8,9 @@
 //   StationaryNSSolver runs the reference's whole solve_newton() (NSSolverStationary.cpp:649-758: continuation
 //   ladder, Stokes phase, <= 15 Newton iterations with backtracking) with assembly (nsk_assemble), linear solves
 //   (nsk_solve_resident) and vector updates (nsk_state_*) resident on the GPU — SURVEY 8f rows 1 and 3.
-//   NSSolver hands solve_system() one system per continuation level of one time step (NSSolver.cpp:684): the first
-//   level gets the reference's own first system (Stokes with the inlet data), later levels the Newton system about
-//   the synthetic state; its time loop is a caller of the path.  VTU output is a consumer and not part of it.
+//   NSSolver runs the reference's time loop (NSSolver::solve(), NSSolver.cpp:799-837) with one solve_newton()
+//   (NSSolver.cpp:674-754) per step; the device assembly carries the mass term and the solution_old term.
+//   VTU output and lift/drag are consumers and not part of it.
 //
 // Built twice from this file: -DNSK_UNSTEADY=0 -> StationaryNSSolver, -DNSK_UNSTEADY=1 -> NSSolver.
 #include <getopt.h>
@@ -49,8 +49,7 @@ static void check(nsk_handle h, int rc, const char *what) {
 }
 
 
-#if !NSK_UNSTEADY
-// NSSolverStationary::solve_newton() (NSSolverStationary.cpp:649-758) over device-resident state.
+// solve_newton() of both reference drivers over device-resident state.
 struct InletVelocity {  // NSSolverStationary.hpp:59-111
   double u = 0.1;
   const double U_m = 1.0;
@@ -69,6 +68,7 @@ struct NewtonDriver {
   int solver_type, preconditioner;
   double tolerance, p_out;
   double nu_mp;          // pressure_mass currently holds 1/nu_mp * M
+  double inv_dt = 0.0;   // 1/delta_t for the unsteady driver
   bool stokes_signs = true;
   long total_its = 0;
   int assemblies = 0;
@@ -77,15 +77,17 @@ struct NewtonDriver {
     if (nu != nu_mp) { check(h, nsk_scale_values(h, NSK_BLK_MP, nu_mp / nu), "nsk_scale_values"); nu_mp = nu; }
     if (stokes_signs != stokes) { check(h, nsk_scale_values(h, NSK_BLK_B, -1.0), "nsk_scale_values"); stokes_signs = stokes; }
     double nrm = 0.0;
-    check(h, nsk_assemble(h, stokes ? 1 : 0, nu, 0.0, p_out, first ? 1 : 0, &nrm), "nsk_assemble");
+    // the Stokes-like first assembly has no mass term either (NSSolver.cpp:381-404)
+    check(h, nsk_assemble(h, stokes ? 1 : 0, nu, stokes ? 0.0 : inv_dt, p_out, first ? 1 : 0, &nrm), "nsk_assemble");
     ++assemblies;
     return nrm;
   }
   int solve_system() {
-    check(h, nsk_setup_preconditioner(h, preconditioner, NSK_VARIANT_STATIONARY, 0.5), "nsk_setup_preconditioner");
+    check(h, nsk_setup_preconditioner(h, preconditioner, NSK_UNSTEADY ? NSK_VARIANT_UNSTEADY : NSK_VARIANT_STATIONARY, 0.5),
+          "nsk_setup_preconditioner");
     int iters = 0;
     double res = 0.0;
-    const int rc = nsk_solve_resident(h, solver_type, tolerance, 20000, &iters, &res);
+    const int rc = nsk_solve_resident(h, solver_type, tolerance, NSK_UNSTEADY ? 100000 : 20000, &iters, &res);
     check(h, rc, "nsk_solve_resident");
     if (rc > 0)
       throw std::runtime_error("Iterative method reported convergence failure in step " + std::to_string(iters) +
@@ -140,8 +142,63 @@ struct NewtonDriver {
     }
     std::cout << "===============================================" << std::endl;
   }
+
+  // NSSolver::solve_newton() (NSSolver.cpp:674-754), once per time step
+  void run_unsteady(double target_Re, bool apply_first) {
+    const unsigned n_max_iters = 10;
+    const double residual_tolerance = 1e-9;
+    bool first_iter = true;
+    std::cout << "===============================================\nTarget Re = " << target_Re << std::endl;
+    for (double current_Re = 1.0; current_Re <= target_Re; current_Re += 10.0) {
+      std::cout << "===============================================" << std::endl;
+      const double nu = 1.0 / current_Re;
+      std::cout << "Solving for Re = " << 0.02 / nu << std::endl;   // get_reynolds(), NSSolver.cpp:756-759
+      unsigned n_iter = 0;
+      double residual_norm = residual_tolerance + 1, prev_residual = 0.0;
+      while (n_iter < n_max_iters && residual_norm > residual_tolerance) {
+        if (first_iter) { first_iter = false; residual_norm = assemble(apply_first, true, nu); }
+        else residual_norm = assemble(false, false, nu);
+        prev_residual = n_iter == 0 ? residual_norm + 1 : prev_residual;
+        std::printf("Newton iteration %u/%u - ||r|| = %.6e", n_iter, n_max_iters, residual_norm);
+        std::fflush(stdout);
+        if (residual_norm > residual_tolerance) {
+          const int GMRES_iter = solve_system();
+          std::cout << "   " << GMRES_iter << " iterations" << std::endl;
+          if (GMRES_iter == 0) break;
+          check(h, nsk_state_save(h), "nsk_state_save");
+          for (double alpha = 1; alpha > 1e-12; alpha *= 0.1) {
+            check(h, nsk_state_update(h, alpha), "nsk_state_update");
+            residual_norm = assemble(false, false, nu);
+            std::cout << "  Evaluating alpha=" << alpha << ", ||r||=" << residual_norm << std::endl;
+            if (residual_norm <= prev_residual) break;               // NSSolver.cpp:738
+          }
+          prev_residual = residual_norm;
+        } else {
+          std::cout << " < tolerance" << std::endl;
+          break;
+        }
+        ++n_iter;
+      }
+    }
+    std::cout << "===============================================" << std::endl;
+  }
+
+  // NSSolver::solve() (NSSolver.cpp:799-837) without output / lift-drag
+  void time_loop(double T, double delta_t, double target_Re) {
+    double time = 0.0;
+    unsigned time_step = 0;
+    bool apply_first = true;
+    while (time < T - 0.5 * delta_t) {
+      time += delta_t;
+      ++time_step;
+      check(h, nsk_state_save_old(h), "nsk_state_save_old");          // solution_old = solution
+      std::printf("n = %3u, t = %5.6f\n", time_step, time);
+      run_unsteady(target_Re, apply_first);
+      apply_first = false;
+      std::cout << std::endl;
+    }
+  }
 };
-#endif
 
 int main(int argc, char *argv[]) {
   bool read_mesh_from_file = false;
@@ -228,13 +285,13 @@ int main(int argc, char *argv[]) {
 
     h = nsk_create(0, 1, 0, nullptr);
     if (!h) throw std::runtime_error("nsk_create failed: no usable GPU (there is no CPU fallback)");
-#if !NSK_UNSTEADY
     {
       // first hand-off: pattern, the state-independent blocks at the first level's viscosity (Stokes signs), the
       // cell connectivity and the inlet values; everything after that happens on the device
+      const double nu0 = NSK_UNSTEADY ? 1.0 : 0.1;   // first continuation level: Re = 1 / Re = 10
       nsp_params prm;
       std::memset(&prm, 0, sizeof(prm));
-      prm.mode = 0; prm.state = 0; prm.inlet_bc = 1; prm.nu = 0.1; prm.U = 0.1; prm.p_out = 1.0;
+      prm.mode = 0; prm.state = 0; prm.inlet_bc = 1; prm.nu = nu0; prm.U = NSK_UNSTEADY ? 0.3 : 0.1; prm.p_out = 1.0;
       if (nsp_assemble(mesh, &prm) != 0) throw std::runtime_error("nsp_assemble failed");
       const int n_u = (int)nsp_block_rows(mesh, NSP_BLK_F), n_p = (int)nsp_block_rows(mesh, NSP_BLK_B);
       check(h, nsk_set_partition(h, NSK_SPACE_U, 0, n_u, 0, nullptr), "nsk_set_partition");
@@ -251,83 +308,16 @@ int main(int argc, char *argv[]) {
       check(h, nsk_assembly_set_dirichlet(h, nsp_dirichlet_u(mesh), nsp_x0_u(mesh)), "nsk_assembly_set_dirichlet");
       std::vector<double> zu((size_t)n_u, 0.0), zp((size_t)n_p, 0.0);
       check(h, nsk_state_set(h, zu.data(), zp.data()), "nsk_state_set");   // solution = 0
-      NewtonDriver drv{h, solver_type, preconditioner, tolerance, 1.0, 0.1};
+      NewtonDriver drv{h, solver_type, preconditioner, tolerance, 1.0, nu0, NSK_UNSTEADY ? 1.0 / time_step : 0.0};
       const auto t0 = std::chrono::steady_clock::now();
-      drv.run(Re);
+      if (NSK_UNSTEADY) drv.time_loop(time_span, time_step, Re);
+      else drv.run(Re);
       const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       const double n = (double)(info.n_u_global + info.n_p_global);
-      std::printf("[nsk] %d assemblies, %ld outer iterations of solve_system(), %.3f s in solve_newton -> %.4g DoF*iters/s\n",
-                  drv.assemblies, drv.total_its, dt, n * drv.total_its / (dt > 0 ? dt : 1e-12));
-      nsk_destroy(h);
-      nsp_mesh_destroy(mesh);
-      return 0;
+      std::printf("[nsk] %d assemblies, %ld outer iterations of solve_system(), %.3f s in %s -> %.4g DoF*iters/s\n",
+                  drv.assemblies, drv.total_its, dt, NSK_UNSTEADY ? "the time loop" : "solve_newton",
+                  n * drv.total_its / (dt > 0 ? dt : 1e-12));
     }
-#endif
-    const int variant = NSK_UNSTEADY ? NSK_VARIANT_UNSTEADY : NSK_VARIANT_STATIONARY;
-    const int max_iter = NSK_UNSTEADY ? 100000 : 20000;
-    long total_its = 0;
-    int n_solves = 0;
-    double t_solve = 0.0;
-    bool first = true;
-    for (double current_Re = NSK_UNSTEADY ? 1.0 : 10.0; current_Re <= Re; current_Re += NSK_UNSTEADY ? 10.0 : 20.0) {
-      const double nu = 1.0 / current_Re;
-      std::cout << "===============================================\nSolving for nu = " << nu << std::endl;
-      nsp_params prm;
-      std::memset(&prm, 0, sizeof(prm));
-      prm.mode = first ? 0 : 1;
-      prm.state = first ? 0 : 1;
-      prm.inlet_bc = first ? 1 : 0;
-      prm.nu = nu;
-      prm.inv_dt = NSK_UNSTEADY ? 1.0 / time_step : 0.0;
-      prm.U = NSK_UNSTEADY ? 0.3 : 0.1;
-      prm.p_out = 1.0;
-      if (nsp_assemble(mesh, &prm) != 0) throw std::runtime_error("nsp_assemble failed");
-      std::cout << (first ? "Solving Stokes adding BCs" : "Solving NS") << std::endl;
-      const int n_u = (int)nsp_block_rows(mesh, NSP_BLK_F), n_p = (int)nsp_block_rows(mesh, NSP_BLK_B);
-      if (first) {
-        check(h, nsk_set_partition(h, NSK_SPACE_U, 0, n_u, 0, nullptr), "nsk_set_partition");
-        check(h, nsk_set_partition(h, NSK_SPACE_P, 0, n_p, 0, nullptr), "nsk_set_partition");
-        const int blks[4] = {NSP_BLK_F, NSP_BLK_BT, NSP_BLK_B, NSP_BLK_MP};
-        for (int b : blks)
-          check(h, nsk_set_block_csr(h, b, (int)nsp_block_rows(mesh, b), (int)nsp_block_cols(mesh, b),
-                                     nsp_block_rowptr(mesh, b), nsp_block_col(mesh, b), nsp_block_val(mesh, b)),
-                "nsk_set_block_csr");
-      } else {
-        const int blks[4] = {NSP_BLK_F, NSP_BLK_BT, NSP_BLK_B, NSP_BLK_MP};
-        for (int b : blks) check(h, nsk_update_values(h, b, nsp_block_val(mesh, b)), "nsk_update_values");
-      }
-      double r2 = 0.0;
-      for (int i = 0; i < n_u; ++i) r2 += nsp_rhs_u(mesh)[i] * nsp_rhs_u(mesh)[i];
-      for (int i = 0; i < n_p; ++i) r2 += nsp_rhs_p(mesh)[i] * nsp_rhs_p(mesh)[i];
-      std::printf("Newton iteration 0/%d - ||r|| = %.6e", NSK_UNSTEADY ? 10 : 15, std::sqrt(r2));
-      std::fflush(stdout);
-      if (NSK_UNSTEADY) std::cout << "\nSolver tolerance: " << tolerance << std::endl;
-      std::vector<double> du(nsp_x0_u(mesh), nsp_x0_u(mesh) + n_u), dp(nsp_x0_p(mesh), nsp_x0_p(mesh) + n_p);
-      const auto t0 = std::chrono::steady_clock::now();
-      // int solve_system(): fresh preconditioner, outer solve, last_step()
-      check(h, nsk_setup_preconditioner(h, preconditioner, variant, 0.5), "nsk_setup_preconditioner");
-      int iters = 0;
-      double res = 0.0;
-      const int rc = nsk_solve(h, solver_type, tolerance, max_iter, nsp_rhs_u(mesh), nsp_rhs_p(mesh), du.data(),
-                               dp.data(), &iters, &res);
-      check(h, rc, "nsk_solve");
-      t_solve += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (rc > 0) {  // the reference dies on deal.II's uncaught SolverControl::NoConvergence here
-        std::cerr << "\nIterative method reported convergence failure in step " << iters << ". The residual in the last step was "
-                  << res << ".\n";
-        nsk_destroy(h);
-        nsp_mesh_destroy(mesh);
-        return 3;
-      }
-      std::cout << "   " << iters << (NSK_UNSTEADY ? " iterations" : " solver iterations") << std::endl;
-      total_its += iters;
-      ++n_solves;
-      first = false;
-    }
-    const double n = (double)(info.n_u_global + info.n_p_global);
-    std::printf("===============================================\n[nsk] %d solve_system() calls, %ld outer iterations, "
-                "%.3f s in solve_system (setup + solve) -> %.4g DoF*iters/s\n",
-                n_solves, total_its, t_solve, n * total_its / (t_solve > 0 ? t_solve : 1e-12));
   } catch (const std::exception &e) {
     std::cerr << e.what() << std::endl;
     if (h) nsk_destroy(h);

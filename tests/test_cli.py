@@ -130,3 +130,6 @@ def test_cpp_unsteady_driver_runs():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "Time step: 0.01" in out.stdout and out.stdout.count(" iterations") >= 2
+    # two time steps, continuation 1 and 11 inside each, device assemblies
+    assert "n =   1" in out.stdout and "n =   2" in out.stdout and "Solving for Re = 0.22" in out.stdout
+    assert "[nsk]" in out.stdout and "the time loop" in out.stdout
