@@ -89,6 +89,32 @@ def echo(cfg, unsteady: bool):
     p("-----------------------------------------------\n")
 
 
+def _levels(first, step, target):
+    out, re = [], first
+    while re <= target:
+        out.append(re)
+        re += step
+    return out or [first]
+
+
+def _report(backend, nx, ny, nu, inlet_u, name, counter, n_digits):
+    """What the reference's main() / time loop does with the solution (testStationary.cpp:133-136,
+    NSSolver.cpp:830-833): VTU record, lift and drag forces over boundary id 10, their coefficients."""
+    import os
+
+    from . import postprocess as PP
+    u, p = backend.solution()
+    print("===============================================")
+    PP.write_vtu(os.environ.get("NSK_OUTPUT_DIR", "./"), name, counter, nx, ny, u, p, n_digits=n_digits)
+    print("Output written to output-stokes")          # the reference prints this name in both drivers
+    print("===============================================")
+    print("===============================================\nComputing lift and drag forces")
+    drag, lift = PP.lift_drag(nx, ny, u, p, nu)
+    cd, cl = PP.coefficients(drag, lift, inlet_u)
+    print(f"===============================================\nLift coefficient: {cl:g}")
+    print(f"===============================================\nDrag coefficient: {cd:g}")
+
+
 def run(cfg, unsteady: bool) -> int:
     import numpy as np
 
@@ -118,6 +144,7 @@ def run(cfg, unsteady: bool) -> int:
         t0 = time.time()
         try:
             N.solve_newton(backend, cfg["Re"])
+            _report(backend, nx, ny, 1.0 / max(l for l in _levels(10.0, 20.0, cfg["Re"])), 1.0, "output-stokes", 0, None)
         finally:
             dt = time.time() - t0
             n = info["n_u_global"] + info["n_p_global"]
@@ -135,7 +162,9 @@ def run(cfg, unsteady: bool) -> int:
                               inv_dt=1.0 / cfg["dt"])
     t0 = time.time()
     try:
-        N.time_loop(backend, cfg["T"], cfg["dt"], cfg["Re"])
+        nu_last = 1.0 / max(_levels(1.0, 10.0, cfg["Re"]))
+        N.time_loop(backend, cfg["T"], cfg["dt"], cfg["Re"],
+                    after_step=lambda step: _report(backend, nx, ny, nu_last, 0.3, "output", step, 3))
     finally:
         dt = time.time() - t0
         n = info["n_u_global"] + info["n_p_global"]

@@ -159,7 +159,7 @@ def solve_newton_unsteady(backend, Re, apply_first, log=print):
     return history
 
 
-def time_loop(backend, T, dt, Re, log=print, max_steps=None):
+def time_loop(backend, T, dt, Re, log=print, max_steps=None, after_step=None):
     """`NSSolver::solve()` (NSSolver.cpp:799-837) without output / lift-drag: solution_old = solution, one Newton
     solve per time step."""
     history = []
@@ -171,6 +171,8 @@ def time_loop(backend, T, dt, Re, log=print, max_steps=None):
         log(f"n = {step:3d}, t = {time:5.6f}")
         history.append(solve_newton_unsteady(backend, Re, apply_first, log))
         apply_first = False
+        if after_step is not None:                          # output(time_step); compute_lift_drag(); print coefficients
+            after_step(step)
         log("")
     return history
 

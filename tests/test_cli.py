@@ -51,8 +51,9 @@ def test_echo_block():
 
 
 @pytest.mark.gpu
-def test_stationary_driver_runs_reference_cpu_config():
+def test_stationary_driver_runs_reference_cpu_config(tmp_path, monkeypatch):
     """BASELINE configs[0]: StationaryNSSolver -m 60,20 -r 20 -s 1 -p 0 (one Stokes level, nu = 1/10)."""
+    monkeypatch.setenv("NSK_OUTPUT_DIR", str(tmp_path))
     out = io.StringIO()
     with redirect_stdout(out):
         rc = cli.main(["StationaryNSSolver", "-m", "60,20", "-r", "20", "-s", "1", "-p", "0", "-t", "1e-8"])
@@ -62,6 +63,23 @@ def test_stationary_driver_runs_reference_cpu_config():
     # the whole solve_newton() ran: inlet ramp passes of the Stokes phase, backtracking, device assemblies
     assert "Solving Stokes without adding BCs" in text and "Solving for inlet velocity: 1" in text
     assert "Evaluating alpha=1," in text and "[nsk]" in text and "Solving NS" not in text   # -r 20: level 10 only
+    # main() of the reference then writes the VTU record and prints the coefficients (testStationary.cpp:133-136)
+    assert (tmp_path / "output-stokes_0.0.vtu").exists() and (tmp_path / "output-stokes_0.pvtu").exists()
+    assert "Lift coefficient:" in text and "Drag coefficient:" in text
+
+
+@pytest.mark.gpu
+def test_unsteady_driver_runs_the_time_loop(tmp_path, monkeypatch):
+    """NSSolver -T 0.02,0.01: two time steps, each with its Newton solve, VTU record and coefficients
+    (NSSolver.cpp:799-837)."""
+    monkeypatch.setenv("NSK_OUTPUT_DIR", str(tmp_path))
+    out = io.StringIO()
+    with redirect_stdout(out):
+        rc = cli.main(["NSSolver", "-T", "0.02,0.01", "-m", "16,10", "-r", "11", "-s", "1", "-p", "2", "-t", "1e-9"])
+    text = out.getvalue()
+    assert rc == 0 and "n =   1" in text and "n =   2" in text and "Solving for Re = 0.22" in text
+    assert (tmp_path / "output_001.0.vtu").exists() and (tmp_path / "output_002.pvtu").exists()
+    assert text.count("Drag coefficient:") == 2 and "the time loop" in text
 
 
 def _bin(name):
@@ -100,11 +118,12 @@ def test_cpp_stationary_driver_runs_reference_cpu_config():
 
 
 @pytest.mark.gpu
-def test_cpp_and_python_newton_drivers_agree():
+def test_cpp_and_python_newton_drivers_agree(tmp_path, monkeypatch):
     """Both drivers run solve_newton() over the same C ABI: same residual history through the Stokes and the
     Newton phase (-r 30: levels 10 and 30), quadratic convergence at the end."""
     import re
     import subprocess
+    monkeypatch.setenv("NSK_OUTPUT_DIR", str(tmp_path))
     args = ["-m", "16,10", "-r", "30", "-s", "1", "-p", "2", "-t", "1e-11"]
     cpp = subprocess.run([_bin("StationaryNSSolver")] + args, capture_output=True, text=True, timeout=300)
     assert cpp.returncode == 0, cpp.stderr

@@ -1,0 +1,82 @@
+"""Consumers of the solution: lift / drag and VTU output, checked on the CPU."""
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import pytest
+
+from navier_stokes_solver_amd import postprocess as PP
+from navier_stokes_solver_amd import problem as P
+
+
+@pytest.mark.parametrize("nx,ny", [(16, 10), (60, 20)])
+def test_lattice_numbering_is_the_generators(nx, ny):
+    L = PP.Lattice(nx, ny)
+    pr = P.generate(nx, ny, nu=0.1)
+    assert (L.n_u, L.n_p) == (pr.n_u, pr.n_p)
+    cells = np.argwhere(L.kept)
+    assert len(cells) == pr.cell_u_nodes.shape[0]
+    for k in (0, len(cells) // 2, len(cells) - 1):       # same cell order (ci, cj) and local node order
+        un, pn = L.cell_nodes(*cells[k])
+        assert np.array_equal(un, pr.cell_u_nodes[k]) and np.array_equal(pn, pr.cell_p_dofs[k])
+
+
+def _field(L, fu, fv, fp):
+    """Nodal interpolant of (fu, fv) on the Q3 lattice and fp on the Q2 lattice."""
+    u, p = np.zeros(L.n_u), np.zeros(L.n_p)
+    for ix in range(3 * L.nx + 1):
+        for iy in range(3 * L.ny + 1):
+            n = L.uid[ix, iy]
+            if n >= 0:
+                x = (ix // 3 + PP._GLL[ix % 3]) * L.hx if ix < 3 * L.nx else PP.LX
+                y = (iy // 3 + PP._GLL[iy % 3]) * L.hy if iy < 3 * L.ny else PP.LY
+                u[2 * n], u[2 * n + 1] = fu(x, y), fv(x, y)
+    for ix in range(2 * L.nx + 1):
+        for iy in range(2 * L.ny + 1):
+            n = L.pid[ix, iy]
+            if n >= 0:
+                p[n] = fp(ix * L.hx / 2, iy * L.hy / 2)
+    return u, p
+
+
+def test_lift_and_drag_of_fields_the_spaces_hold_exactly():
+    """sigma = nu (grad u + grad u^T) - p I integrated over the obstacle boundary with the fluid's outward normal
+    equals -(integral of div sigma over the hole) by the divergence theorem.
+    u = (y, 0), p = x      ->  div sigma = (-1, 0):  force = -sum sigma n = (-|hole|, 0)
+    u = (x y, -y^2 / 2), p = 3 y ->  div sigma = nu (0, -1) + (0, -3) ... checked against the same identity."""
+    nx, ny, nu = 60, 20, 0.37
+    L = PP.Lattice(nx, ny)
+    hole = (~L.kept).sum() * L.hx * L.hy
+    assert hole > 0
+    u, p = _field(L, lambda x, y: y, lambda x, y: 0.0, lambda x, y: x)
+    drag, lift = PP.lift_drag(nx, ny, u, p, nu)
+    assert abs(drag + hole) <= 1e-12 and abs(lift) <= 1e-12
+    # quadratic velocity: grad u = [[y, x], [0, -y]], sym part 2*eps = [[2y, x], [x, -2y]], div(nu 2 eps) = nu (0+1, 0-2)...
+    u, p = _field(L, lambda x, y: x * y, lambda x, y: -0.5 * y * y, lambda x, y: 3.0 * y)
+    drag, lift = PP.lift_drag(nx, ny, u, p, nu)
+    # div sigma = nu * (d/dx(2y) + d/dy(x), d/dx(x) + d/dy(-2y)) - grad p = nu * (0, 1 - 2) - (0, 3)
+    # force = -oint sigma n_fluid = +int_hole div sigma
+    assert abs(drag - 0.0) <= 1e-12 and abs(lift - hole * (-nu - 3.0)) <= 1e-12
+    cd, cl = PP.coefficients(drag, lift, 1.0)
+    assert cl == pytest.approx(2.0 * lift / ((2.0 / 3.0) ** 2 * 0.1))
+
+
+def test_vtu_record(tmp_path):
+    nx, ny = 16, 10
+    L = PP.Lattice(nx, ny)
+    u, p = _field(L, lambda x, y: y, lambda x, y: -x, lambda x, y: x + y)
+    path = PP.write_vtu(str(tmp_path), "output-stokes", 0, nx, ny, u, p)
+    assert os.path.basename(path) == "output-stokes_0.0.vtu" and os.path.exists(tmp_path / "output-stokes_0.pvtu")
+    root = ET.parse(path).getroot()
+    piece = root.find("UnstructuredGrid/Piece")
+    n_cells = int(L.kept.sum())
+    assert int(piece.get("NumberOfCells")) == n_cells == 158 and int(piece.get("NumberOfPoints")) == 4 * n_cells
+    arrays = {a.get("Name"): a for a in piece.find("PointData")}
+    assert set(arrays) == {"velocity", "pressure", "partitioning"}
+    pts = np.array(piece.find("Points/DataArray").text.split(), float).reshape(-1, 3)
+    vel = np.array(arrays["velocity"].text.split(), float).reshape(-1, 3)
+    prs = np.array(arrays["pressure"].text.split(), float)
+    assert np.allclose(vel[:, 0], pts[:, 1]) and np.allclose(vel[:, 1], -pts[:, 0]) and np.allclose(prs, pts[:, 0] + pts[:, 1])
+    pv = ET.parse(tmp_path / "output-stokes_0.pvtu").getroot()
+    assert pv.find("PUnstructuredGrid/Piece").get("Source") == "output-stokes_0.0.vtu"
+    assert os.path.basename(PP.write_vtu(str(tmp_path), "output", 7, nx, ny, u, p, n_digits=3)) == "output_007.0.vtu"
