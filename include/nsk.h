@@ -24,7 +24,13 @@
  * Return codes: 0 success; 1 outer solver not converged (iters/final_res still valid —
  * the reference would throw SolverControl::NoConvergence); 2 BiCGStab breakdown
  * restarts exhausted; 3 an inner (preconditioner) solver did not converge;
- * < 0 usage / HIP / RCCL error, text via nsk_last_error().
+ * < 0 usage / HIP / RCCL error, text via nsk_last_error():
+ *   -10..-11 HIP runtime / out of device scalar slots      -20..-24 RCCL / in-process group transport
+ *   -30..-32 triangular-solve analysis (missing diagonal, row too long)
+ *   -40..-47 missing blocks, bad preconditioner / solver type, call order
+ *   -50..-59 bad arguments of the hand-off calls           -60..-66 device assembly / Newton state
+ *   -70 single-launch triangular solve gave up waiting (see NSK_OPT_TRI_SYNC_FREE)
+ *   -80 AMG level operator too large for 32-bit indices     -1 any other exception
  */
 #ifndef NSK_H
 #define NSK_H
