@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--ordering", type=int, default=1, help="0 natural, 1 multicolour (triangular solves)")
     ap.add_argument("--subdomains", type=int, default=1)
-    ap.add_argument("--sync-free", type=int, default=1, help="0 per-level launches, 1 single-launch S/Mp solves, 2 also F")
+    ap.add_argument("--sync-free", type=int, default=2, help="0 per-level launches, 1 single-launch S/Mp solves, 2 also F")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mesh", type=str, default="300,100")
     ap.add_argument("--cpu-steps", type=int, default=12)

@@ -76,7 +76,7 @@ enum {
   NSK_OPT_TRI_RUN_NNZ = 8,    /* non-zeros per workgroup in the scalar streamed triangular levels: 512, 1024, 2048 (default) */
   NSK_OPT_TRI_SYNC_FREE = 9,  /* multicolour triangular solves with ONE launch per half: rows wait in-kernel for the entries
                                  they depend on (bounded spins on a sentinel-filled vector, see nsk_kernels.h).
-                                 0: off (one launch per level); 1 (default): scalar factors (S, Mp); 2: also the 2x2-blocked
+                                 0: off (one launch per level); 1: scalar factors (S, Mp); 2 (default): also the 2x2-blocked
                                  velocity factor; 3: test hook (wrong order in the upper half).  If a wait ever runs out, nsk_solve falls back to 0 and redoes the solve;
                                  nsk_solve_resident returns -70 */
   NSK_OPT_VELOCITY_AMG = 10,  /* stationary blockTriangular: 1 (default) precondition F with the smoothed-aggregation AMG

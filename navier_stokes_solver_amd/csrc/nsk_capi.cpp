@@ -81,7 +81,7 @@ struct nsk_handle_s {
   bool inner_fused_gs = true, outer_fused_gs = false;
   int use_bsr = 1;
   int sync_free_fallbacks = 0;
-  int sync_free_mode = 1;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
+  int sync_free_mode = 2;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
   DBuf<int> jrow_blk, jblk_blk;  // row runs of the fused (F | Bt) block row: CSR and blocked variants
   int jrow_nblk = 0, jblk_nblk = 0;
   bool jrow_ok = false, jblk_ok = false;
