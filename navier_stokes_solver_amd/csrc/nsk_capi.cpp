@@ -81,6 +81,7 @@ struct nsk_handle_s {
   bool inner_fused_gs = true, outer_fused_gs = false;
   int use_bsr = 1;
   int sync_free_fallbacks = 0;
+  int x_layout_mode = 2;   // NSK_OPT_TRI_X_LAYOUT
   int sync_free_mode = 2;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
   DBuf<int> jrow_blk, jblk_blk;  // row runs of the fused (F | Bt) block row: CSR and blocked variants
   int jrow_nblk = 0, jblk_nblk = 0;
@@ -303,6 +304,12 @@ void H::setup(int type, int variant_, double alpha_) {
   tMp.sync_free = tS.sync_free = sync_free_mode >= 1;
   tF.sync_free = sync_free_mode == 2;
   tMp.sf_fault = tS.sf_fault = sync_free_mode == 3;
+  // working-vector layout of the triangular solves: the blocked velocity factor uses a colour-ordered vector whenever
+  // it runs single-launch (its per-level kernels only know the caller's order); the scalar factors only on request
+  const int f_layout = (x_layout_mode != 0 && sync_free_mode == 2) ? 1 : 0, p_layout = x_layout_mode == 1 ? 1 : 0;
+  if (tF.x_layout != f_layout) { tF.x_layout = f_layout; tF_ok = false; }
+  if (tMp.x_layout != p_layout) { tMp.x_layout = p_layout; tMp_ok = false; }
+  if (tS.x_layout != p_layout) { tS.x_layout = p_layout; tS_ok = false; }
   const double t0 = wall_ms();
   prec_type = type;
   variant = variant_;
@@ -658,7 +665,7 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
     case NSK_OPT_VELOCITY_AMG: h->velocity_amg = v != 0.0; break;
     case NSK_OPT_TRI_X_LAYOUT:
-      h->tF.x_layout = h->tMp.x_layout = h->tS.x_layout = v != 0.0;
+      h->x_layout_mode = v == 1.0 ? 1 : (v == 0.0 ? 0 : 2);
       h->tF_ok = h->tMp_ok = h->tS_ok = false;
       break;
     case NSK_OPT_INNER_FUSED_GS: h->inner_fused_gs = v != 0.0; break;

@@ -174,8 +174,8 @@ void vec_fill_sentinel(hipStream_t s, int n, double *y);
 void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int n_blocks, int lower, int kind, int run_nnz,
                          int wrong_order /* test hook */, const double *dinv, const int *perm, const double *rhs,
                          const double *own, double *w, int *err);
-void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int n_blocks, int lower, int kind, const double *intra,
-                      const int *permn, const double *rhs, const double *own, double *w, int *err);
+void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int n_blocks, int lower, int kind, int permx, const double *intra,
+                      const int *permn, const double *rhs, const double *own, double *w, double *out, int *err);
 
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,

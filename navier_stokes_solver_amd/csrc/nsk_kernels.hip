@@ -538,11 +538,15 @@ __global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, i
   }
 }
 
-template <int LOWER, int KIND>
+// PERMX = 1: the working vectors (ownv, x) are in colour order (node r at 2 r) and M.col holds colour-order node
+// ids: a colour then only touches the segments of the colours it depends on.  The lower half gathers rhs through
+// permn, the upper half also writes its result to out[permn[r]] in the caller's order.
+template <int LOWER, int KIND, int PERMX>
 __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, const double *__restrict__ intra,
                                                          const int *__restrict__ permn,
                                                          const double *__restrict__ rhs,
-                                                         const double *__restrict__ ownv, double *x, int *err) {
+                                                         const double *__restrict__ ownv, double *x,
+                                                         double *__restrict__ out, int *err) {
   __shared__ double p0[kBlkMax];
   __shared__ double p1[kBlkMax];
   const int4 d = M.desc[blockIdx.x];  // dispatch order, see tri_stream_sf_kernel
@@ -556,8 +560,9 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, const
   if (have) {
     jb = M.rowptr[r] - k0;
     je = M.rowptr[r + 1] - k0;
-    i = 2 * (size_t)permn[r];
-    own = *reinterpret_cast<const double2 *>((LOWER ? rhs : ownv) + i);
+    const size_t ic = 2 * (size_t)permn[r];   // caller-order position
+    i = PERMX ? 2 * (size_t)r : ic;
+    own = *reinterpret_cast<const double2 *>(LOWER ? rhs + ic : ownv + i);
     cf = *reinterpret_cast<const double2 *>(intra + 4 * (size_t)r);
     di = *reinterpret_cast<const double2 *>(intra + 4 * (size_t)r + 2);
   }
@@ -606,6 +611,7 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, const
       if (KIND == 0) { v1 = (own.y - s1) * di.y; v0 = (own.x - s0 - cf.y * v1) * di.x; }
       else { v1 = own.y - s1 * di.y; v0 = own.x - (s0 + cf.y * v1) * di.x; }
     }
+    if (PERMX && !LOWER) *reinterpret_cast<double2 *>(out + 2 * (size_t)permn[r]) = make_double2(v0, v1);
     sf_store(x + i, v0);
     sf_store(x + i + 1, v1);
   }
@@ -1069,12 +1075,17 @@ void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int
 #undef NSK_SFN
 #undef NSK_SF
 }
-void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int nb, int lower, int kind, const double *intra,
-                      const int *permn, const double *rhs, const double *own, double *w, int *err) {
+void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int nb, int lower, int kind, int permx, const double *intra,
+                      const int *permn, const double *rhs, const double *own, double *w, double *out, int *err) {
   if (nb <= 0) return;
-#define NSK_SB(L, K) hipLaunchKernelGGL((tri_blk_sf_kernel<L, K>), dim3(nb), dim3(BLK), 0, s, M, nb, intra, permn, rhs, own, w, err)
-  if (lower) { if (kind == 0) NSK_SB(1, 0); else NSK_SB(1, 1); }
-  else { if (kind == 0) NSK_SB(0, 0); else NSK_SB(0, 1); }
+#define NSK_SB(L, K, P) hipLaunchKernelGGL((tri_blk_sf_kernel<L, K, P>), dim3(nb), dim3(BLK), 0, s, M, nb, intra, permn, rhs, own, w, out, err)
+  if (permx) {
+    if (lower) { if (kind == 0) NSK_SB(1, 0, 1); else NSK_SB(1, 1, 1); }
+    else { if (kind == 0) NSK_SB(0, 0, 1); else NSK_SB(0, 1, 1); }
+  } else {
+    if (lower) { if (kind == 0) NSK_SB(1, 0, 0); else NSK_SB(1, 1, 0); }
+    else { if (kind == 0) NSK_SB(0, 0, 0); else NSK_SB(0, 1, 0); }
+  }
 #undef NSK_SB
 }
 void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra) {

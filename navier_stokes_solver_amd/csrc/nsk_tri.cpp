@@ -288,8 +288,9 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
         bu.clear();
         for (int k = 0; k < prp[i0 + 1] - a0; k += 2) {
           const int m = pcol[a0 + k] / 2;
-          if (m < r) bl.emplace_back(perm[pcol[a0 + k]] / 2, k);
-          else if (m > r) bu.emplace_back(perm[pcol[a0 + k]] / 2, k);
+          // block-column id: caller-order node id, or the colour-order one for the colour-ordered working vector
+          if (m < r) bl.emplace_back(x_layout ? m : perm[pcol[a0 + k]] / 2, k);
+          else if (m > r) bu.emplace_back(x_layout ? m : perm[pcol[a0 + k]] / 2, k);
           else {  // the node's own 2x2 diagonal block
             isrc[4 * (size_t)r + 0] = a1 + k;      // l10 = (i1, i0)
             isrc[4 * (size_t)r + 1] = a0 + k + 1;  // u01 = (i0, i1)
@@ -466,9 +467,15 @@ void TriSolve::apply(const double *b, double *x) {
     vec_fill_sentinel(s, n, y.p);
     if (block2_ready) {
       const TriBlk L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
-      tri_blk_syncfree(s, L, n_Lsf, 1, kind, intra.p, permn.p, b, nullptr, y.p, sf_err.p);
-      vec_fill_sentinel(s, n, x);
-      tri_blk_syncfree(s, U, n_Usf, 0, kind, intra.p, permn.p, nullptr, y.p, x, sf_err.p);
+      tri_blk_syncfree(s, L, n_Lsf, 1, kind, x_layout, intra.p, permn.p, b, nullptr, y.p, nullptr, sf_err.p);
+      if (x_layout) {  // colour-ordered working vectors y, xc; the upper half also writes the caller-order result
+        if (xc.n != (size_t)n + 1) xc.alloc((size_t)n + 1);
+        vec_fill_sentinel(s, n, xc.p);
+        tri_blk_syncfree(s, U, n_Usf, 0, kind, 1, intra.p, permn.p, nullptr, y.p, xc.p, x, sf_err.p);
+      } else {
+        vec_fill_sentinel(s, n, x);
+        tri_blk_syncfree(s, U, n_Usf, 0, kind, 0, intra.p, permn.p, nullptr, y.p, x, nullptr, sf_err.p);
+      }
     } else {
       const TriHalf L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
       tri_stream_syncfree(s, L, n_Lsf, 1, kind, run_nnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, sf_err.p);
@@ -479,6 +486,8 @@ void TriSolve::apply(const double *b, double *x) {
     ctx->st.tri_bytes += (double)apply_bytes();
     return;
   }
+  if (block2_ready && x_layout && use_stream && !tiny)
+    throw Error(-33, "the colour-ordered layout of the blocked factor needs the single-launch solves");
   if (block2_ready && use_stream && !tiny) {
     const TriBlk L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
     for (int c = 0; c < n_colors; ++c) tri_blk_level(s, L, LB[c], LB[c + 1], 1, kind, intra.p, permn.p, b, x);

@@ -43,6 +43,7 @@ struct TriSolve {
   bool use_stream = true, stream_ready = false;
   bool sync_free = false;  // one launch per half with in-kernel producer/consumer hand-off (see nsk_kernels.h)
   bool sf_fault = false;   // test hook: wrong workgroup order in the upper half
+  DBuf<double> xc;         // colour-ordered result vector of the upper half (x_layout = 1, blocked factor)
   DBuf<int> sf_err;        // raised by a bounded spin that ran out
   int run_nnz = 2048;  // non-zeros per workgroup of the scalar streamed levels (512 / 1024 / 2048)
   int x_layout = 0;  // 0: solve in the caller's (lattice) order; 1: internal colour-ordered vector
