@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--subdomains", type=int, default=1)
     ap.add_argument("--sync-free", type=int, default=2, help="0 per-level launches, 1 single-launch S/Mp solves, 2 also F")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--x-layout", type=int, default=2, help="NSK_OPT_TRI_X_LAYOUT: 2 colour-ordered vector for the blocked F solve, 0 caller order")
     ap.add_argument("--cpu-mesh", type=str, default="300,100")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
@@ -144,6 +145,7 @@ def main():
     ls.set_option(S.OPT_TRI_ORDERING, args.ordering)
     ls.set_option(S.OPT_SUBDOMAINS, args.subdomains)
     ls.set_option(S.OPT_TRI_SYNC_FREE, args.sync_free)
+    ls.set_option(S.OPT_TRI_X_LAYOUT, args.x_layout)
     t0 = time.time()
     ls.set_problem(pr, plan)
     t_upload = time.time() - t0
