@@ -101,6 +101,31 @@ def test_time_term_of_the_unsteady_residual():
     assert np.abs(no_old.rhs_u - pr.rhs_u).max() > 1e-4 * np.abs(pr.rhs_u).max()   # the old state is really used
 
 
+@pytest.mark.parametrize("nranks", [1, 2, 3])
+def test_cell_connectivity_hand_off(nranks):
+    """The assembly hand-off (nsp_cell_*): local ids in range, every owned DoF reached by 1..4 cells, every pair of
+    DoFs of a cell present in the sparsity pattern of the owned rows, outlet flags on the last cell column."""
+    nx, ny = 16, 10
+    total_cells = 0
+    for rank in range(nranks):
+        pr = P.generate(nx, ny, nu=0.1, nranks=nranks, rank=rank)
+        cu, cp = pr.cell_u_nodes, pr.cell_p_dofs
+        n_nodes_own, n_nodes_all = pr.n_u // 2, pr.F.cols // 2
+        assert cu.min() >= 0 and cu.max() < n_nodes_all and cp.min() >= 0 and cp.max() < pr.Bt.cols
+        cnt_u = np.bincount(cu[cu < n_nodes_own], minlength=n_nodes_own)
+        cnt_p = np.bincount(cp[cp < pr.n_p], minlength=pr.n_p)
+        assert cnt_u.min() >= 1 and cnt_u.max() <= 4 and cnt_p.min() >= 1 and cnt_p.max() <= 4
+        rows = [set(pr.F.col[pr.F.rowptr[2 * r]:pr.F.rowptr[2 * r + 1]]) for r in range(n_nodes_own)]
+        for c in range(0, cu.shape[0], 7):
+            for n in cu[c][cu[c] < n_nodes_own]:
+                assert all(2 * m in rows[n] and 2 * m + 1 in rows[n] for m in cu[c])
+        assert (pr.cell_of_dof0 == 0) == (rank == 0)
+        assert int(pr.cell_flags.sum()) == (ny if rank == nranks - 1 else 0)      # outlet faces: last cell column
+        assert pr.cell_tables.shape == (944,) and abs(pr.cell_tables[912:928].sum() - (2.2 / nx) * (0.41 / ny)) < 1e-15
+        total_cells += cu.shape[0]
+    assert total_cells >= P.mesh_info(nx, ny)["n_cells"]          # interface cell columns are seen by both neighbours
+
+
 def test_block_structure_signs():
     """Appendix C: Stokes mode is symmetric on free rows with both off-diagonal blocks negative;
     Newton mode flips the (1,0) block."""
