@@ -47,6 +47,29 @@ def make(name):
     print(name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in g.items() if "iters" in k})
 
 
+def make_widening():
+    """Fixtures for the rows built after the hot path: the AMG V-cycle on the ns16 velocity
+    block and the Newton system assembled about a seeded state (from the host hand-off producer, itself checked
+    against oracle/fe_numpy.py)."""
+    pr = P.generate(**CASES["ns16"])
+    xu = rng_vec(pr.n_u, 201)
+    amg = O.Amg(O.CsrHolder.from_block(pr.F))
+    g = {"x_u": xu, "amg_F_x": amg.apply(xu), "amg_levels": np.array([lv[:2] for lv in amg.levels()], np.int64),
+         "amg_lambda": np.array([lv[2] for lv in amg.levels()])}
+    nx, ny = CASES["ns16"]["nx"], CASES["ns16"]["ny"]
+    i = P.mesh_info(nx, ny)
+    su, sp = 0.1 * rng_vec(i["n_u_global"], 202), rng_vec(i["n_p_global"], 203)
+    so = su + 0.01 * rng_vec(i["n_u_global"], 204)
+    g["state_u"], g["state_p"], g["state_u_old"] = su, sp, so
+    for tag, inv_dt, old in (("steady", 0.0, None), ("unsteady", 100.0, so)):
+        a = P.generate(nx, ny, nu=0.05, mode=1, state=(su, sp), inv_dt=inv_dt, state_old=old)
+        g[f"asm_{tag}_rhs_u"], g[f"asm_{tag}_rhs_p"] = a.rhs_u, a.rhs_p
+        if old is not None:
+            g[f"asm_{tag}_F_val"] = a.F.val          # one copy of the matrix values is enough (1.1 MB)
+    np.savez_compressed(os.path.join(OUT, "widening16.npz"), **g)
+    print("widening16", g["amg_levels"].tolist())
+
+
 def make_north_star_60x20():
     """FGMRES + aSIMPLE to the north-star tolerance 1e-10 on the 60x20 Newton system (about 3 minutes)."""
     pr = P.generate(**CASES["ns60"])
@@ -63,4 +86,5 @@ def make_north_star_60x20():
 if __name__ == "__main__":
     for name in ("stokes16", "ns16", "unsteady16"):
         make(name)
+    make_widening()
     make_north_star_60x20()

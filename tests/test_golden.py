@@ -31,6 +31,47 @@ def test_oracle_reproduces_golden(name):
     assert info["iters"] == int(g["solve_s1p2v0_iters"]) and np.array_equal(x, g["solve_s1p2v0_x"])
 
 
+def test_widening_fixtures_are_reproduced_on_the_cpu():
+    """AMG V-cycle (oracle) and the assembled Newton system (host producer) still give the committed vectors."""
+    from navier_stokes_solver_amd import problem as P
+    from oracle import oracle as O
+    from tests.util import CASES
+    g, pr = _g("widening16"), problem("ns16")
+    amg = O.Amg(O.CsrHolder.from_block(pr.F))
+    assert np.array_equal(np.array([lv[:2] for lv in amg.levels()]), g["amg_levels"])
+    assert np.array_equal(amg.apply(g["x_u"]), g["amg_F_x"])
+    nx, ny = CASES["ns16"]["nx"], CASES["ns16"]["ny"]
+    a = P.generate(nx, ny, nu=0.05, mode=1, state=(g["state_u"], g["state_p"]), inv_dt=100.0, state_old=g["state_u_old"])
+    assert np.array_equal(a.F.val, g["asm_unsteady_F_val"]) and np.array_equal(a.rhs_u, g["asm_unsteady_rhs_u"])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_widening_fixtures():
+    """a17 and f1 through the C ABI against the committed vectors."""
+    from navier_stokes_solver_amd import solver as S
+    from tests.util import CASES
+    g, pr = _g("widening16"), problem("ns16")
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr)
+        ls.setup_preconditioner(S.BLOCK_TRIANGULAR, S.STATIONARY)
+        assert [lv[:2] for lv in ls.amg_levels()] == [tuple(r) for r in g["amg_levels"].tolist()]
+        assert rel_err(ls.tri_apply(S.TRI_VELOCITY, g["x_u"]), g["amg_F_x"]) <= 1e-11
+        ls.set_assembly(pr)
+        ls.state_set(g["state_u_old"], g["state_p"])
+        ls.state_save_old()
+        ls.state_set(g["state_u"], g["state_p"])
+        for tag, inv_dt in (("unsteady", 100.0),):
+            ls.assemble(0.05, inv_dt, 1.0)
+            ru, rp = ls.download_rhs()
+            scale = np.abs(g[f"asm_{tag}_rhs_u"]).max()
+            assert np.abs(ls.get_block(S.BLK_F)[2] - g[f"asm_{tag}_F_val"]).max() <= 1e-12 * np.abs(g[f"asm_{tag}_F_val"]).max()
+            assert np.abs(ru - g[f"asm_{tag}_rhs_u"]).max() <= 1e-12 * scale
+            assert np.abs(rp - g[f"asm_{tag}_rhs_p"]).max() <= 1e-12 * scale
+    finally:
+        ls.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", NAMES)
 def test_gpu_reproduces_golden(name):
