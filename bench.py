@@ -96,7 +96,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    if "OMP_NUM_THREADS" not in os.environ or (world > 1 and os.environ["OMP_NUM_THREADS"] == "1"):
+    if "OMP_NUM_THREADS" not in os.environ or (os.environ["OMP_NUM_THREADS"] == "1" and
+                                               (world > 1 or "TORCHELASTIC_RUN_ID" in os.environ)):
         # The host-side hand-off generation, the one-off symbolic analysis and the CPU baseline are OpenMP loops:
         # size their teams after the cgroup CPU quota (the boxes show 256 CPUs for a 16-core share), split over
         # the ranks of this node (torch.distributed.run pins OMP_NUM_THREADS=1).  Set before any OpenMP runtime loads.
