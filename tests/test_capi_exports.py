@@ -46,3 +46,10 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
                 src = open(os.path.join(dirpath, f)).read().lower()
                 assert "oracle" not in src and "orc_" not in src, f
+
+
+def test_host_thread_budget_is_sane():
+    """include/nsk_threads.h and its Python twin: between 1 and 64, never above the affinity mask."""
+    from navier_stokes_solver_amd._threads import cpu_budget
+    b = cpu_budget()
+    assert 1 <= b <= 64 and b <= len(os.sched_getaffinity(0))
