@@ -116,8 +116,6 @@ def _report(backend, nx, ny, nu, inlet_u, name, counter, n_digits):
 
 
 def run(cfg, unsteady: bool) -> int:
-    import numpy as np
-
     from . import problem as P
     from . import solver as S
     if cfg["read_mesh"]:

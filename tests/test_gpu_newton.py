@@ -2,7 +2,6 @@
 host hand-off producer, linear solves by a sparse-direct factorisation."""
 import numpy as np
 import pytest
-import scipy.sparse.linalg as spl
 
 from navier_stokes_solver_amd import newton as N
 from navier_stokes_solver_amd import problem as P
