@@ -43,7 +43,6 @@ def parse():
     ap.add_argument("--subdomains", type=int, default=1)
     ap.add_argument("--sync-free", type=int, default=2, help="0 per-level launches, 1 single-launch S/Mp solves, 2 also F")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--x-layout", type=int, default=2, help="NSK_OPT_TRI_X_LAYOUT: 2 colour-ordered vector for the blocked F solve, 0 caller order")
     ap.add_argument("--cpu-mesh", type=str, default="300,100")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
@@ -146,7 +145,6 @@ def main():
     ls.set_option(S.OPT_TRI_ORDERING, args.ordering)
     ls.set_option(S.OPT_SUBDOMAINS, args.subdomains)
     ls.set_option(S.OPT_TRI_SYNC_FREE, args.sync_free)
-    ls.set_option(S.OPT_TRI_X_LAYOUT, args.x_layout)
     t0 = time.time()
     ls.set_problem(pr, plan)
     t_upload = time.time() - t0
@@ -163,17 +161,7 @@ def main():
 
     # warm-up
     ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
-    try:
-        ls.solve_resident(args.solver, 0.0, max(1, args.warmup))
-    except RuntimeError as e:
-        if "-70" not in str(e):
-            raise
-        # single-launch triangular solves gave up on a hand-off on this box: use one launch per level
-        print(f"[bench] rank {rank}: {e}; falling back to per-level launches", file=sys.stderr, flush=True)
-        ls.set_option(S.OPT_TRI_SYNC_FREE, 0)
-        ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
-        ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
-        ls.solve_resident(args.solver, 0.0, max(1, args.warmup))
+    ls.solve_resident(args.solver, 0.0, max(1, args.warmup))   # (falls back to per-colour launches by itself if a hand-off gives up)
     # timed: exactly K outer iterations from the same initial state, fresh preconditioner object
     ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
     ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)

@@ -29,7 +29,7 @@
  *   -30..-32 triangular-solve analysis (missing diagonal, row too long)
  *   -40..-47 missing blocks, bad preconditioner / solver type, call order
  *   -50..-59 bad arguments of the hand-off calls           -60..-66 device assembly / Newton state
- *   -70 single-launch triangular solve gave up waiting (see NSK_OPT_TRI_SYNC_FREE)
+ *   -70 single-launch triangular solve gave up waiting AND the per-colour retry failed too (see NSK_OPT_TRI_SYNC_FREE)
  *   -80 AMG level operator too large for 32-bit indices     -1 any other exception
  */
 #ifndef NSK_H
@@ -73,20 +73,15 @@ enum {
                                  (two sweeps, 8 vectors per pass); 0: deal.II's modified Gram-Schmidt (add_and_dot) */
   NSK_OPT_OUTER_FUSED_GS = 5, /* same for the outer FGMRES; default 0 (modified Gram-Schmidt, as deal.II) */
   NSK_OPT_BSR_VELOCITY = 7,   /* 1 (default): SpMVs with the jacobian blocks use 2x2 / 2x1 / 1x2 node-block copies when the pattern allows */
-  NSK_OPT_TRI_RUN_NNZ = 8,    /* non-zeros per workgroup in the scalar streamed triangular levels: 512, 1024, 2048 (default) */
-  NSK_OPT_TRI_SYNC_FREE = 9,  /* multicolour triangular solves with ONE launch per half: rows wait in-kernel for the entries
-                                 they depend on (bounded spins on a sentinel-filled vector, see nsk_kernels.h).
-                                 0: off (one launch per level); 1: scalar factors (S, Mp); 2 (default): also the 2x2-blocked
-                                 velocity factor; 3: test hook (wrong order in the upper half).  If a wait ever runs out, nsk_solve falls back to 0 and redoes the solve;
-                                 nsk_solve_resident returns -70 */
+  NSK_OPT_TRI_SYNC_FREE = 9,  /* multicolour triangular solves in ONE launch instead of one per colour: rows wait in-kernel for
+                                 the entries they depend on (bounded spins on sentinel-filled working vectors, see
+                                 csrc/nsk_kernels.h).  0: one launch per colour; 1: scalar factors (S, Mp: one persistent launch
+                                 for both halves, all workgroups resident); 2 (default): also the 2x2-blocked velocity factor
+                                 (one launch per half).  If a wait ever runs out, the solve is redone with 0 (status 0,
+                                 nsk_stats.sync_free_fallbacks counts it) */
   NSK_OPT_VELOCITY_AMG = 10,  /* stationary blockTriangular: 1 (default) precondition F with the smoothed-aggregation AMG
                                  V-cycle (the reference configures TrilinosWrappers::PreconditionAMG there,
                                  NSSolverStationary.hpp:225,231); 0: ILU(0), as the unsteady variant does */
-  NSK_OPT_TRI_X_LAYOUT = 6    /* working vector of the multicolour triangular solves.  2 (default): the 2x2-blocked velocity
-                                 factor solves on an internal colour-ordered vector when it runs single-launch (a colour
-                                 then only reads the segments of the colours it depends on: 1.09 -> 1.00 ms per apply at
-                                 1200x400), the scalar factors in the caller's DoF order; 0: caller's order everywhere;
-                                 1: colour-ordered for the scalar factors too (per-level kernels; slower, kept for study) */
 };
 
 typedef struct {
@@ -95,7 +90,9 @@ typedef struct {
   double spmv_bytes, tri_bytes, blas1_bytes; /* algorithmic bytes moved (SURVEY 8d formulas) */
   int32_t n_colors_u, n_levels_u, n_colors_p, n_levels_p;
   int64_t nnz_s;
-  int64_t sync_free_fallbacks; /* times nsk_solve fell back to per-level launches */
+  int64_t sync_free_fallbacks; /* times a solve fell back to per-colour launches (NSK_OPT_TRI_SYNC_FREE) */
+  int64_t cur_outer_iters;     /* progress of the running / last outer solve: iterations done ... */
+  double cur_residual;         /* ... and the residual SolverControl saw last (readable from another thread) */
 } nsk_stats;
 
 /* 128-byte RCCL unique id, produced on rank 0 and distributed by the caller (e.g. MPI_Bcast). */

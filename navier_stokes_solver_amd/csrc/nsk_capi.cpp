@@ -19,6 +19,7 @@
 #include "nsk_amg.hpp"
 #include "nsk_assembly.hpp"
 #include "nsk_tri.hpp"
+#include "nsk_internal.h"
 
 using namespace nsk;
 
@@ -81,8 +82,10 @@ struct nsk_handle_s {
   bool inner_fused_gs = true, outer_fused_gs = false;
   int use_bsr = 1;
   int sync_free_fallbacks = 0;
-  int x_layout_mode = 2;   // NSK_OPT_TRI_X_LAYOUT
+  int x_layout_mode = 2;   // NSK_IOPT_TRI_X_LAYOUT
   int sync_free_mode = 2;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
+  int fault_inject = 0;    // NSK_IOPT_FAULT_INJECT
+  int use_win_spmv = 1;    // NSK_IOPT_WINDOW_SPMV
   DBuf<int> jrow_blk, jblk_blk;  // row runs of the fused (F | Bt) block row: CSR and blocked variants
   int jrow_nblk = 0, jblk_nblk = 0;
   bool jrow_ok = false, jblk_ok = false;
@@ -98,7 +101,9 @@ struct nsk_handle_s {
   TriSolve *tP = nullptr;
   int s_max_row = 0;
   double *D = nullptr, *Dinv = nullptr, *tmp_p = nullptr, *delta_p = nullptr, *tmp_u = nullptr, *tmp_b = nullptr;
-  double *rhs_b = nullptr, *x_b = nullptr;
+  double *rhs_b = nullptr, *x_b = nullptr, *x_keep = nullptr;
+  volatile long progress_step = 0;      // outer iterations / residual of the running solve (nsk_get_stats from another thread)
+  volatile double progress_value = 0.0;
   long inner_u = 0, inner_p = 0, prec_applies = 0, outer_iters = 0;
   double setup_ms = 0, solve_ms = 0;
 
@@ -146,6 +151,9 @@ struct nsk_handle_s {
     if (smp) (void)hipEventRecord(smp->e0[smp->used], s());
     if (A.blk_ok && use_stream && use_bsr && mode == 0)
       nsk::spmv_blk_stream(s(), A.blk_view(), A.blk_R, A.blk_C, A.blk_rowblk.p, A.blk_nblk, x.own, x.ghost, y);
+    else if (A.win_ok && use_stream && use_win_spmv && x.ghost == x.own + A.n_own_cols &&
+             (reinterpret_cast<uintptr_t>(x.own) & 127u) == 0)
+      nsk::spmv_win(s(), A.win_view(), A.win_nruns, x.own, y, mode, z);   // scalar blocks S, Mp: window format
     else if (A.stream_ok && use_stream)
       nsk::spmv_stream(s(), A.view(), A.rowblk.p, A.nblk, A.even_rows, x.own, x.ghost, y, mode, z);
     else
@@ -227,7 +235,10 @@ struct nsk_handle_s {
       if (T->sf_err.p) {
         int ei = 0;
         NSK_HIP(hipMemcpy(&ei, T->sf_err.p, sizeof(int), hipMemcpyDeviceToHost));
-        if (ei) NSK_HIP(hipMemset(T->sf_err.p, 0, sizeof(int)));
+        if (ei) {
+          NSK_HIP(hipMemsetAsync(T->sf_err.p, 0, sizeof(int), s()));
+          T->win_dirty = true;   // the working vectors of the abandoned solve are garbage
+        }
         e |= ei;
       }
     if (ctx.comm.active() && sync_free_mode > 0) {
@@ -244,6 +255,7 @@ struct nsk_handle_s {
   void schur_symbolic();
   void setup(int type, int variant_, double alpha_);
   void prec_vmult(DVec &dst, const DVec &src);
+  int solve_once(int solver, double tol, int max_iter, int *iters, double *final_res);
   int solve_resident(int solver, double tol, int max_iter, int *iters, double *final_res);
 };
 using H = nsk_handle_s;
@@ -294,6 +306,7 @@ void H::schur_symbolic() {
   S.lpr = pick_lpr(S.nnz, S.n_rows);
   S.present = true;
   S.build_stream_plan(s());
+  S.build_win(s());
   ctx.sync();
   s_symbolic = true;
 }
@@ -303,13 +316,12 @@ void H::setup(int type, int variant_, double alpha_) {
   ensure_pools();
   tMp.sync_free = tS.sync_free = sync_free_mode >= 1;
   tF.sync_free = sync_free_mode == 2;
-  tMp.sf_fault = tS.sf_fault = sync_free_mode == 3;
-  // working-vector layout of the triangular solves: the blocked velocity factor uses a colour-ordered vector whenever
-  // it runs single-launch (its per-level kernels only know the caller's order); the scalar factors only on request
-  const int f_layout = (x_layout_mode != 0 && sync_free_mode == 2) ? 1 : 0, p_layout = x_layout_mode == 1 ? 1 : 0;
+  tMp.win_fault = tS.win_fault = (fault_inject & 1) ? 1 : 0;
+  tF.sf_fault = (fault_inject & 2) != 0;
+  // working-vector layout of the blocked velocity factor: colour-ordered whenever it runs single-launch (its
+  // per-level kernels only know the caller's order).  The scalar factors always solve on colour-ordered vectors.
+  const int f_layout = (x_layout_mode != 0 && sync_free_mode == 2) ? 1 : 0;
   if (tF.x_layout != f_layout) { tF.x_layout = f_layout; tF_ok = false; }
-  if (tMp.x_layout != p_layout) { tMp.x_layout = p_layout; tMp_ok = false; }
-  if (tS.x_layout != p_layout) { tS.x_layout = p_layout; tS_ok = false; }
   const double t0 = wall_ms();
   prec_type = type;
   variant = variant_;
@@ -345,6 +357,7 @@ void H::setup(int type, int variant_, double alpha_) {
     Csr &S = blk[NSK_BLK_S], &B = blk[NSK_BLK_B], &Bt = blk[NSK_BLK_BT], &Btg = blk[NSK_BLK_BT_GHOST];
     spgemm_bdbt_numeric(s(), B.view(), Dinv, Dinv + n_u(), Bt.view(), Btg.present ? Btg.view() : Bt.view(), S.rowptr.p,
                         S.col.p, S.val.p, S.n_rows, std::max(1, s_max_row));
+    S.refresh_win(s());
     if (!tS_ok || tS_key != key) {
       tS.analyze(&ctx, S, 0, tri_ordering, sub_offsets(1));
       tS_ok = true;
@@ -464,16 +477,15 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
   vec_sub_then_mul(s(), nu, tmp_u, Dinv, du.own);        // u = (u - B~^T p) .* D^-1
 }
 
-int H::solve_resident(int solver, double tol, int max_iter, int *iters, double *final_res) {
-  if (prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
-  if (solver < 0 || solver > 2) throw Error(-47, "Invalid solver type. Use 0: GMRES, 1: FGMRES, 2: Bicgstab.");
+int H::solve_once(int solver, double tol, int max_iter, int *iters, double *final_res) {
   SolverControl control(max_iter, tol);
+  control.progress_step = &progress_step;
+  control.progress_value = &progress_value;
   MatVec A = [&](const DVec &x, double *y) { jacobian_vmult(x, y); };
   PrecVmult P = [&](DVec &d, const DVec &r) { prec_vmult(d, r); };
   DVec x = bb(x_b);
   const DVec b = bb(rhs_b);
   int rc = 0;
-  const double t0 = wall_ms();
   const int slot_mark = ctx.slot_top;
   try {
     if (solver == 0) { SolverGMRES sv(ctx, pool_b, control); sv.solve(A, x, b, P); }
@@ -485,10 +497,40 @@ int H::solve_resident(int solver, double tol, int max_iter, int *iters, double *
   ctx.slot_top = slot_mark;
   ctx.sync();
   check_sync_free();
-  solve_ms = wall_ms() - t0;
   outer_iters += control.last_step();
   if (iters) *iters = control.last_step();
   if (final_res) *final_res = control.last_value();
+  return rc;
+}
+
+// The single-launch triangular solves wait in-kernel with bounded spins.  If a wait ever gives up (error -70: e.g.
+// another process holds part of the GPU, so not all workgroups of the persistent launch are resident), the solve is
+// redone from the caller's initial guess with one launch per colour and a fresh preconditioner object (stale inner
+// state must not leak).  The error is agreed on by all ranks (check_sync_free), so every rank retries.
+int H::solve_resident(int solver, double tol, int max_iter, int *iters, double *final_res) {
+  if (prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
+  if (solver < 0 || solver > 2) throw Error(-47, "Invalid solver type. Use 0: GMRES, 1: FGMRES, 2: Bicgstab.");
+  const double t0 = wall_ms();
+  const bool guarded = sync_free_mode > 0;
+  if (guarded) {   // keep the initial guess: a failed attempt leaves garbage in x_b
+    if (!x_keep) x_keep = pool_b.get(false);
+    vec_copy(s(), N(), x_b, x_keep);
+  }
+  int rc;
+  try {
+    rc = solve_once(solver, tol, max_iter, iters, final_res);
+  } catch (const Error &e) {
+    if (e.code != -70 || !guarded) throw;
+    const long undo = outer_iters;
+    sync_free_mode = 0;
+    tMp.sync_free = tS.sync_free = tF.sync_free = false;
+    ++sync_free_fallbacks;
+    setup(prec_type, variant, alpha);
+    vec_copy(s(), N(), x_keep, x_b);
+    outer_iters = undo;
+    rc = solve_once(solver, tol, max_iter, iters, final_res);
+  }
+  solve_ms = wall_ms() - t0;
   return rc;
 }
 
@@ -623,6 +665,7 @@ int nsk_set_block_csr(nsk_handle h, int b, int n_rows, int n_cols, const int32_t
   if (b == NSK_BLK_F) A.build_blocked(2, 2, h->s());
   if (b == NSK_BLK_BT) A.build_blocked(2, 1, h->s());
   if (b == NSK_BLK_B) A.build_blocked(1, 2, h->s());
+  if (b == NSK_BLK_MP) A.build_win(h->s());
   h->ctx.sync();
   if (b == NSK_BLK_F || b == NSK_BLK_BT) { h->jrow_ok = h->jblk_ok = false; h->jrow_nblk = h->jblk_nblk = 0; }
   // a new pattern invalidates cached symbolic data
@@ -640,6 +683,7 @@ int nsk_update_values(nsk_handle h, int b, const double *val) {
   Csr &A = h->blk[b];
   NSK_HIP(hipMemcpyAsync(A.val.p, val, sizeof(double) * (size_t)A.nnz, hipMemcpyHostToDevice, h->s()));
   A.refresh_blocked(h->s());
+  A.refresh_win(h->s());
   h->ctx.sync();
   return 0;
   NSK_CATCH(h)
@@ -652,21 +696,24 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
     case NSK_OPT_SUBDOMAINS: h->subdomains = std::max(1, (int)v); break;
     case NSK_OPT_FUSE_BLOCK_ROW: h->fuse_block_row = v != 0.0; break;
     case NSK_OPT_STREAM_KERNELS: h->use_stream = v != 0.0; h->tF.use_stream = h->tMp.use_stream = h->tS.use_stream = h->use_stream; break;
-    case NSK_OPT_TRI_RUN_NNZ:
-      h->tF.run_nnz = h->tMp.run_nnz = h->tS.run_nnz = v <= 512 ? 512 : (v <= 1024 ? 1024 : 2048);
-      h->tF_ok = h->tMp_ok = h->tS_ok = false;
-      break;
     case NSK_OPT_TRI_SYNC_FREE:
+      if (v != 0.0 && v != 1.0 && v != 2.0) throw Error(-61, "NSK_OPT_TRI_SYNC_FREE: 0, 1 or 2");
       h->sync_free_mode = (int)v;
       h->tMp.sync_free = h->tS.sync_free = v >= 1.0;
       h->tF.sync_free = v == 2.0;
-      h->tMp.sf_fault = h->tS.sf_fault = v == 3.0;  // 3: fault injection for the tests (consumers before producers)
       break;
+    case NSK_IOPT_FAULT_INJECT:
+      h->fault_inject = (int)v;
+      h->tMp.win_fault = h->tS.win_fault = (h->fault_inject & 1) ? 1 : 0;
+      h->tF.sf_fault = (h->fault_inject & 2) != 0;
+      break;
+    case NSK_IOPT_WINDOW_SPMV: h->use_win_spmv = v != 0.0; break;
+    case NSK_IOPT_TINY_BYTES: h->tF.tiny_bytes = h->tMp.tiny_bytes = h->tS.tiny_bytes = v; break;
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
     case NSK_OPT_VELOCITY_AMG: h->velocity_amg = v != 0.0; break;
-    case NSK_OPT_TRI_X_LAYOUT:
-      h->x_layout_mode = v == 1.0 ? 1 : (v == 0.0 ? 0 : 2);
-      h->tF_ok = h->tMp_ok = h->tS_ok = false;
+    case NSK_IOPT_TRI_X_LAYOUT:
+      h->x_layout_mode = v == 0.0 ? 0 : 2;
+      h->tF_ok = false;
       break;
     case NSK_OPT_INNER_FUSED_GS: h->inner_fused_gs = v != 0.0; break;
     case NSK_OPT_OUTER_FUSED_GS: h->outer_fused_gs = v != 0.0; break;
@@ -719,18 +766,7 @@ int nsk_solve(nsk_handle h, int solver, double tol, int max_iter, const double *
               double *xp, int *iters, double *final_res) {
   int rc = nsk_upload_system(h, ru, rp, xu, xp);
   if (rc < 0) return rc;
-  int rs = nsk_solve_resident(h, solver, tol, max_iter, iters, final_res);
-  if (rs == -70) {  // the error is agreed on by all ranks (check_sync_free), so every rank retries
-    // the single-launch triangular solves gave up on a hand-off: fall back to one launch per level and redo the
-    // solve from the caller's initial guess (a fresh preconditioner object: stale inner state must not leak)
-    nsk_set_option(h, NSK_OPT_TRI_SYNC_FREE, 0.0);
-    h->sync_free_fallbacks++;
-    rc = nsk_setup_preconditioner(h, h->prec_type, h->variant, h->alpha);
-    if (rc < 0) return rc;
-    rc = nsk_upload_system(h, ru, rp, xu, xp);
-    if (rc < 0) return rc;
-    rs = nsk_solve_resident(h, solver, tol, max_iter, iters, final_res);
-  }
+  const int rs = nsk_solve_resident(h, solver, tol, max_iter, iters, final_res);
   if (rs < 0) return rs;
   rc = nsk_download_solution(h, xu, xp);
   return rc < 0 ? rc : rs;
@@ -1009,6 +1045,7 @@ int nsk_scale_values(nsk_handle h, int blk, double factor) {
   Csr &A = h->blk[blk];
   vec_scale(h->s(), (int)A.nnz, sref(factor), A.val.p);
   A.refresh_blocked(h->s());
+  A.refresh_win(h->s());
   return 0;
   NSK_CATCH(h)
 }
@@ -1172,6 +1209,8 @@ int nsk_get_stats(nsk_handle h, nsk_stats *o) {
   o->n_levels_p = h->tP ? h->tP->n_levels_L : 0;
   o->nnz_s = h->blk[NSK_BLK_S].present ? h->blk[NSK_BLK_S].nnz : 0;
   o->sync_free_fallbacks = h->sync_free_fallbacks;
+  o->cur_outer_iters = h->progress_step;
+  o->cur_residual = h->progress_value;
   return 0;
   NSK_CATCH(h)
 }
@@ -1245,9 +1284,14 @@ int nsk_time_op(nsk_handle h, int op, int reps, double *avg_ms, double *bytes) {
     if (!h->blk[op].present) throw Error(-62, "nsk_time_op: block not set");
     Csr &A = h->blk[op];
     const int cs = (op == NSK_BLK_F || op == NSK_BLK_B) ? 0 : 1;
-    const DVec xv = cs == 0 ? h->ub(xb) : h->pb(xb);
+    // operand from the pool of its own space, as the inner solvers hand it over (owned | ghost contiguous, aligned)
+    VecPool &pc = cs == 0 ? h->pool_u : h->pool_p;
+    double *xs = pc.get(true);
+    vec_set(h->s(), pc.n, xs, 1.0);
+    const DVec xv = pc.view(xs);
     by = (double)A.spmv_bytes();
     f = [=, &A]() { h->halo(cs, xv); h->spmv_nohalo(A, xv, yb, 0); };
+    pc.put(xs);   // stays valid until the pool hands it out again (not during this call)
   } else if (op == 10) {
     Csr &F = h->blk[NSK_BLK_F], &Bt = h->blk[NSK_BLK_BT], &B = h->blk[NSK_BLK_B];
     by = (double)F.spmv_bytes() + (double)Bt.spmv_bytes() + (double)B.spmv_bytes();

@@ -168,6 +168,11 @@ void Comm::halo_exchange(Space &sp, const DVec &x, hipStream_t s) {
 void Ctx::init(int device_id) {
   device = device_id;
   NSK_HIP(hipSetDevice(device));
+  {
+    hipDeviceProp_t prop;
+    NSK_HIP(hipGetDeviceProperties(&prop, device));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
   NSK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   ws_partials.alloc((size_t)kMaxReduceBlocks * kMaxReduceOut);
   ws_ticket.alloc(1);
@@ -347,6 +352,40 @@ void Csr::build_blocked(int R, int C, hipStream_t s) {
   refresh_blocked(s);
 }
 
+// upload helper of the window format: two int4 per run
+std::vector<int4> win_pack_runs(const std::vector<WinRun> &runs) {
+  std::vector<int4> out(2 * runs.size());
+  for (size_t b = 0; b < runs.size(); ++b) {
+    const WinRun &R = runs[b];
+    out[2 * b] = make_int4(R.r0, R.nrows, R.l0, R.nl);
+    out[2 * b + 1] = make_int4(R.p0, R.q2, R.roff0, R.flags);
+  }
+  return out;
+}
+
+void Csr::build_win(hipStream_t s) {
+  win_ok = false;
+  if (n_rows <= 0 || nnz <= 0) return;
+  WinFormat W;
+  if (!build_win_format(n_rows, h_rowptr.data(), h_col.data(), nullptr, nullptr, nullptr, kWinMaxLines, 0, W)) return;
+  win_nruns = (int)W.runs.size();
+  win_slots = W.n_slots;
+  win_bytes = W.bytes_per_apply();
+  win_runs.upload(win_pack_runs(W.runs), s);
+  win_lines.upload(W.lines, s);
+  win_roff.upload(W.roff, s);
+  win_pos.upload(W.pos, s);
+  win_src.upload(W.src, s);
+  win_val.alloc((size_t)W.n_slots);
+  NSK_HIP(hipStreamSynchronize(s));
+  win_ok = true;
+  refresh_win(s);
+}
+
+void Csr::refresh_win(hipStream_t s) {
+  if (win_ok) vec_gather_or_zero(s, (long)win_slots, win_src.p, val.p, win_val.p);
+}
+
 void Csr::refresh_blocked(hipStream_t s) {
   if (blk_ok) vec_gather(s, (int)(blk_count * blk_R * blk_C), blk_src.p, val.p, blk_val.p);
 }
@@ -357,7 +396,8 @@ double *VecPool::get(bool zero) {
     p = free_list.back();
     free_list.pop_back();
   } else {
-    NSK_HIP(hipMalloc((void **)&p, sizeof(double) * ((size_t)n + ng + 2)));
+    // whole 128-byte lines plus one: the window kernels copy the lines a run touches, including the last, partial one
+    NSK_HIP(hipMalloc((void **)&p, sizeof(double) * (((size_t)n + ng + 15) / 16 * 16 + 16)));
     all.push_back(p);
     zero = true;
   }

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "nsk_kernels.h"
+#include "nsk_win.hpp"
 
 struct ncclComm;
 
@@ -110,6 +111,20 @@ struct Csr {  // device CSR block with host copy of the pattern
   void build_blocked(int R, int C, hipStream_t s);  // pattern analysis + upload (host); values via refresh_blocked
   void refresh_blocked(hipStream_t s);              // blk_val[k] = val[blk_src[k]] on the device
   BlkView blk_view() const { return BlkView{blk_rows, n_own_cols / blk_C, blk_rowptr.p, blk_col.p, blk_val.p}; }
+  // window-format copy (nsk_win.hpp; scalar blocks S and Mp): used when x is one contiguous, 128-byte aligned vector
+  bool win_ok = false;
+  int win_nruns = 0;
+  int64_t win_slots = 0;
+  double win_bytes = 0;   // bytes one pass over the window copy reads (values, positions, lines, descriptors)
+  DBuf<int4> win_runs;
+  DBuf<int> win_lines, win_src;
+  DBuf<unsigned short> win_roff, win_pos;
+  DBuf<double> win_val;
+  void build_win(hipStream_t s);     // pattern analysis + upload (host); values via refresh_win
+  void refresh_win(hipStream_t s);   // win_val[k] = val[win_src[k]] (0 in padding slots) on the device
+  WinView win_view() const {
+    return WinView{win_runs.p, win_lines.p, win_roff.p, reinterpret_cast<const unsigned *>(win_pos.p), win_val.p};
+  }
   CsrView view() const { return CsrView{n_rows, n_own_cols, rowptr.p, col.p, val.p}; }
   size_t spmv_bytes() const {  // 12 nnz + 4 (rows+1) + 8 rows + 8 cols
     return (size_t)12 * nnz + 4 * ((size_t)n_rows + 1) + 8 * (size_t)n_rows + 8 * (size_t)n_cols;
@@ -121,6 +136,9 @@ struct Csr {  // device CSR block with host copy of the pattern
 // single row exceeds max_nnz.
 bool build_rowblocks(const int *rowptr_a, const int *rowptr_b, int n_rows, int max_nnz, const std::vector<int> *cuts,
                      std::vector<int> &rowblk);
+
+// device layout of the window format's run list: two int4 per run
+std::vector<int4> win_pack_runs(const std::vector<WinRun> &runs);
 
 inline int pick_lpr(int64_t nnz, int n_rows) {
   const double mean = n_rows > 0 ? (double)nnz / n_rows : 0.0;
@@ -165,6 +183,7 @@ struct Stats {
 struct Ctx {
   hipStream_t stream = nullptr;
   int device = 0;
+  int n_cu = 256;   // compute units of the device
   Comm comm;
   ReduceWs ws{};
   DBuf<double> ws_partials;

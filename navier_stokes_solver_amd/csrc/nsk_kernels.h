@@ -130,25 +130,7 @@ void tri_lower_serial(hipStream_t s, const TriView &T, int kind, const int *lvl_
                       const double *rhs, double *y);
 void tri_upper_serial(hipStream_t s, const TriView &T, int kind, const int *lvl_ptr, const int *rows, int l0, int l1,
                       double *y, double *out);
-// Streamed level of a triangular solve on split factors: M = strict-lower or strict-upper CSR whose
-// ROWS are in the permuted (colour) order, one level = one contiguous run of rows covered by
-// workgroups [b0, b1) of rowblk, while COLUMN ids and the vector x stay in the caller's numbering
-// (i = perm[r]):
-//   lower: x[i] = (rhs[i] - sum) * (kind ? dinv[r] : 1)
-//   upper: x[i] = kind ? x[i] - sum*dinv[r] : (x[i] - sum)*dinv[r]
-struct TriHalf {
-  const int *rowptr;
-  const int *col;
-  const double *val;
-  const int4 *desc;  // per workgroup: {first row, end row, first nnz, end nnz} — one load instead of a chain
-};
-// permx = 1: w is an internal colour-ordered vector and M.col holds colour-order ids; the lower solve gathers
-// rhs through perm, the upper solve also scatters its result to out[perm[r]].
-// run_nnz: the non-zero cap the row runs in M.desc were built with (512, 1024 or 2048)
-void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx, int run_nnz,
-                      const double *dinv, const int *perm, const double *rhs, double *w, double *out);
-
-// 2x2 node-block variant of the streamed level: node rows (two adjacent DoF rows) in node-colour order,
+// 2x2 node-block streamed level of a triangular solve (velocity block): node rows (two adjacent DoF rows) in node-colour order,
 // 2x2 blocks towards other nodes, and per node row intra = {l10, u01, 1/d0, 1/d1} for its own diagonal block.
 //   lower ILU: y0 = b0 - s0 ; y1 = b1 - s1 - l10 y0            lower SGS: y0 = (b0 - s0)/d0 ; y1 = (b1 - s1 - l10 y0)/d1
 //   upper ILU: x1 = (y1 - s1)/d1 ; x0 = (y0 - s0 - u01 x1)/d0  upper SGS: x1 = y1 - s1/d1 ; x0 = y0 - (s0 + u01 x1)/d0
@@ -171,11 +153,41 @@ void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra);
 // needs no separate flag or fence).  Producers are always in lower-indexed workgroups, which the dispatcher
 // starts first; every spin is bounded and raises *err instead of hanging.
 void vec_fill_sentinel(hipStream_t s, int n, double *y);
-void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int n_blocks, int lower, int kind, int run_nnz,
-                         int wrong_order /* test hook */, const double *dinv, const int *perm, const double *rhs,
-                         const double *own, double *w, int *err);
-void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int n_blocks, int lower, int kind, int permx, const double *intra,
-                      const int *permn, const double *rhs, const double *own, double *w, double *out, int *err);
+void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int n_blocks, int lower, int kind, int permx,
+                      int wrong_order /* test hook */, const double *intra, const int *permn, const double *rhs,
+                      const double *own, double *w, double *out, int *err);
+
+// ---- window format (nsk_win.hpp): LDS-staged column tiles, 16-bit window positions, transposed value stream ----
+struct WinView {
+  const int4 *runs;            // two int4 per run: {r0, nrows, l0, nl}, {p0, q2, roff0, flags}
+  const int *lines;            // window line ids (16 doubles per line)
+  const unsigned short *roff;  // per run nrows + 1 entry offsets
+  const unsigned *pos;         // one dword per pair: two 16-bit window positions
+  const double *val;           // two doubles per pair
+};
+// y = A x (mode 0) | y += A x (1) | y = z - A x (2); x = [owned | ghost] as ONE contiguous, 128-byte aligned vector
+void spmv_win(hipStream_t s, const WinView &A, int n_runs, const double *x, double *y, int mode, const double *z);
+// y[i] = idx[i] >= 0 ? x[idx[i]] : 0   (values of the padded window slots)
+void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, double *y);
+
+// Triangular solve on the window format, both halves in ONE run list in dispatch order (lower colours ascending,
+// then upper colours descending).  Working vectors are in COLOUR order and 128-byte aligned:
+//   Y   lower result; every entry holds the sentinel on entry, and again on exit (the upper run of a row resets it)
+//   X   upper result of this call (sentinel on entry);  Xnext: the buffer of the NEXT call, reset here
+// rhs / out are in the caller's order (gathered / scattered through perm).  Runs [i0, i1) of the list are solved by
+// `grid` workgroups, workgroup g taking runs i0 + g, i0 + g + grid, ...: with grid <= the number of co-resident
+// workgroups this needs no assumption on the dispatch order (every wait is on a run a resident workgroup owns);
+// with grid = i1 - i0 and launches cut at colour boundaries it is the plain level-by-level schedule.
+struct WinTriArgs {
+  const double *dinv;   // per row (colour order): 1 / diagonal
+  const int *perm;      // colour order -> caller's order
+  const double *rhs;    // caller's order
+  double *Y, *X, *Xnext, *out;
+  int *err;
+};
+void tri_win_solve(hipStream_t s, const WinView &M, int i0, int i1, int grid, int kind, int reverse /* test hook */,
+                   const WinTriArgs &a);
+int tri_win_max_resident_per_cu();   // occupancy of the kernel above (workgroups per CU)
 
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,

@@ -9,6 +9,8 @@
 //     next kernel without a host round trip.
 #include "nsk_kernels.h"
 
+#include <algorithm>
+
 namespace nsk {
 
 namespace {
@@ -219,10 +221,6 @@ __global__ __launch_bounds__(BLK) void spmv2_stream_kernel(CsrView A, const doub
   if (have && lane == 0) y[r] = sum;
 }
 
-// Streamed level of a triangular solve.  Rows r of the level are contiguous in the permuted
-// (colour) order, but the solution vector x and the column ids stay in the CALLER's (lattice)
-// numbering: the gathers x[col] of one row then fall into a few runs of neighbouring entries, like
-// the x-gathers of the SpMV, instead of one cache line per entry.
 // ------------------------------------------------------------------ blocked SpMV (R x C dense blocks)
 template <int R, int C>
 __device__ __forceinline__ void blk_products(const BlkView &A, int k0, int k1, const double *__restrict__ xo,
@@ -317,69 +315,6 @@ __global__ __launch_bounds__(BLK) void spmv_blk_fused_kernel(BlkView A, const do
   s0 = subwave_sum<RG>(s0);
   s1 = subwave_sum<RG>(s1);
   if (have && lane == 0) *reinterpret_cast<double2 *>(y + 2 * (size_t)r) = make_double2(s0, s1);
-}
-
-// PERMX = 0: w is the caller-order vector x (i = perm[r]), column ids are caller-order ids.
-// PERMX = 1: w is an internal colour-ordered vector (i = r), column ids are colour-order ids; the lower
-//            solve gathers rhs through perm and the upper solve scatters the result to `out`.  A level
-//            then only touches the segments of the colours it depends on (fewer bytes per level), at
-//            the price of one cache line per gathered entry.
-template <int LOWER, int KIND, int PERMX, int NNZ>
-__global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int nb, const double *__restrict__ dinv,
-                                                         const int *__restrict__ perm,
-                                                         const double *__restrict__ rhs, double *__restrict__ w,
-                                                         double *__restrict__ out) {
-  __shared__ double prod[NNZ];
-  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the k-th
-  // contiguous eighth of the level's row runs.  Neighbouring rows then share one L2, and the same
-  // slice of x is touched by the same XCD level after level (speed only, never correctness).
-  const int per = (int)gridDim.x >> 3;  // the grid is padded to a multiple of 8
-  const int mapped = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  if (mapped >= nb) return;
-  const int4 d = M.desc[b0 + mapped];
-  const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
-  const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
-  const bool have = r < r1;
-  int jb = 0, je = 0, i = 0, ip = 0;
-  double own = 0.0, dv = 1.0;
-  if (have) {
-    jb = M.rowptr[r] - k0;
-    je = M.rowptr[r + 1] - k0;
-    ip = perm[r];
-    i = PERMX ? r : ip;
-    own = LOWER ? rhs[ip] : w[i];  // w[i] of this level's own rows is not written by anyone else
-    if (KIND == 1 || !LOWER) dv = dinv[r];
-  }
-  // the factor is streamed once per apply: non-temporal loads keep it from evicting the lines the
-  // gathers want to find in L2 again
-  {
-    constexpr int U = NNZ / BLK;  // staged: see stream_products
-    int c[U];
-    double v[U], g[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = k0 + (int)threadIdx.x + u * BLK;
-      const bool ok = k < k1;
-      c[u] = ok ? __builtin_nontemporal_load(M.col + k) : 0;
-      v[u] = ok ? __builtin_nontemporal_load(M.val + k) : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) g[u] = w[c[u]];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = k0 + (int)threadIdx.x + u * BLK;
-      if (k < k1) prod[k - k0] = v[u] * g[u];
-    }
-  }
-  __syncthreads();
-  const double sum = row_sum_lds(prod, jb, je, lane);
-  if (have && lane == 0) {
-    double v;
-    if (LOWER) v = KIND == 0 ? (own - sum) : (own - sum) * dv;
-    else v = KIND == 0 ? (own - sum) * dv : own - sum * dv;
-    w[i] = v;
-    if (PERMX && !LOWER) out[ip] = v;
-  }
 }
 
 template <int LOWER, int KIND>
@@ -482,74 +417,23 @@ __device__ __forceinline__ double sf_wait(const double *p, unsigned long long fi
   return __longlong_as_double((long long)v);
 }
 
-template <int LOWER, int KIND, int NNZ>
-__global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, int wrong_order,
-                                                            const double *__restrict__ dinv,
-                                                            const int *__restrict__ perm,
-                                                            const double *__restrict__ rhs,
-                                                            const double *__restrict__ ownv, double *w, int *err) {
-  __shared__ double prod[NNZ];
-  // M.desc is in DISPATCH order (TriSolve::sf_dispatch_order): colours in dependency order, so producers
-  // always sit in workgroups the dispatcher has started earlier; inside a colour (padded to a multiple of 8
-  // with empty runs) the runs are dealt so that XCD k works on the k-th eighth of every colour.
-  // wrong_order (test hook): walk the list backwards, i.e. consumers before their producers, to exercise
-  // the bounded-spin / fallback path
-  const int4 d = M.desc[wrong_order ? nb - 1 - (int)blockIdx.x : (int)blockIdx.x];
-  const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
-  if (r0 == r1) return;  // padding run
-  const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
-  const bool have = r < r1;
-  int jb = 0, je = 0, i = 0;
-  double own = 0.0, dv = 1.0;
-  if (have) {
-    jb = M.rowptr[r] - k0;
-    je = M.rowptr[r + 1] - k0;
-    i = perm[r];
-    own = LOWER ? rhs[i] : ownv[i];
-    if (KIND == 1 || !LOWER) dv = dinv[r];
-  }
-  {
-    constexpr int U = NNZ / BLK;
-    int c[U];
-    double v[U];
-    unsigned long long g[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = k0 + (int)threadIdx.x + u * BLK;
-      const bool ok = k < k1;
-      c[u] = ok ? __builtin_nontemporal_load(M.col + k) : -1;
-      v[u] = ok ? __builtin_nontemporal_load(M.val + k) : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) g[u] = c[u] >= 0 ? sf_peek(w + c[u]) : 0ull;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = k0 + (int)threadIdx.x + u * BLK;
-      if (k < k1) prod[k - k0] = v[u] * sf_wait(w + c[u], g[u], err);
-    }
-  }
-  __syncthreads();
-  const double sum = row_sum_lds(prod, jb, je, lane);
-  if (have && lane == 0) {
-    double x;
-    if (LOWER) x = KIND == 0 ? (own - sum) : (own - sum) * dv;
-    else x = KIND == 0 ? (own - sum) * dv : own - sum * dv;
-    sf_store(w + i, x);
-  }
-}
-
 // PERMX = 1: the working vectors (ownv, x) are in colour order (node r at 2 r) and M.col holds colour-order node
 // ids: a colour then only touches the segments of the colours it depends on.  The lower half gathers rhs through
 // permn, the upper half also writes its result to out[permn[r]] in the caller's order.
 template <int LOWER, int KIND, int PERMX>
-__global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, const double *__restrict__ intra,
+__global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int wrong_order,
+                                                         const double *__restrict__ intra,
                                                          const int *__restrict__ permn,
                                                          const double *__restrict__ rhs,
                                                          const double *__restrict__ ownv, double *x,
                                                          double *__restrict__ out, int *err) {
   __shared__ double p0[kBlkMax];
   __shared__ double p1[kBlkMax];
-  const int4 d = M.desc[blockIdx.x];  // dispatch order, see tri_stream_sf_kernel
+  // M.desc is in DISPATCH order (TriSolve::sf_dispatch_order): colours in dependency order, so producers sit in
+  // workgroups the dispatcher has started earlier; inside a colour (padded to a multiple of 8 with empty runs) the
+  // runs are dealt so that XCD k works on the k-th eighth of every colour.  wrong_order (test hook): walk the list
+  // backwards, i.e. consumers before their producers, to exercise the bounded-spin / fallback path.
+  const int4 d = M.desc[wrong_order ? nb - 1 - (int)blockIdx.x : (int)blockIdx.x];
   const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
   if (r0 == r1) return;  // padding run
   const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
@@ -617,7 +501,205 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, const
   }
 }
 
+// ------------------------------------------------------------------ window format (nsk_win.hpp)
+// One workgroup per run: (1) stream the run's values and 16-bit window positions with 16-byte / 4-byte loads per
+// lane (transposed storage: every wave instruction reads contiguous memory), (2) copy the run's window lines of the
+// gathered vector into LDS with 16-byte loads, (3) products from LDS, (4) per-row sums with RG lanes.
+// Address-unit work per non-zero drops from {4 B load, 8 B load, 64-address gather} to ~1/3 of a wide load.
+constexpr int WQ = 4;       // pairs per thread (kWinMaxQ2)
+constexpr int WL = 160;     // window lines (kWinMaxLines)
+constexpr int WLD = (WL * 8 + BLK - 1) / BLK;  // 16-byte window chunks per thread
+
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+struct WinRegs {            // the matrix stream of one run in flight
+  dvec2 v[WQ];
+  unsigned c[WQ];
+};
+__device__ __forceinline__ void win_issue(const WinView &M, int p0, int q2, WinRegs &R) {
+#pragma unroll
+  for (int j = 0; j < WQ; ++j) {
+    const bool ok = j < q2;   // uniform in the workgroup
+    const size_t pi = (size_t)p0 + (size_t)(ok ? j : 0) * BLK + threadIdx.x;
+    R.v[j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const dvec2 *>(M.val) + pi) : dvec2{0.0, 0.0};
+    R.c[j] = ok ? __builtin_nontemporal_load(M.pos + pi) : 0u;
+  }
+}
+// window lines -> LDS (and the line ids, which the sentinel polls need)
+__device__ __forceinline__ void win_stage(const int *__restrict__ lines, int l0, int nl, const double *w, double *win,
+                                          int *s_lines) {
+  int ln[WLD];
+  double2 ch[WLD];
+#pragma unroll
+  for (int u = 0; u < WLD; ++u) {
+    const int k = (int)threadIdx.x + u * BLK;
+    ln[u] = k < nl * 8 ? lines[l0 + (k >> 3)] : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < WLD; ++u) {
+    const int k = (int)threadIdx.x + u * BLK;
+    ch[u] = ln[u] >= 0 ? *reinterpret_cast<const double2 *>(w + (size_t)ln[u] * 16 + (size_t)(k & 7) * 2)
+                       : make_double2(0.0, 0.0);
+  }
+#pragma unroll
+  for (int u = 0; u < WLD; ++u) {
+    const int k = (int)threadIdx.x + u * BLK;
+    if (ln[u] >= 0) {
+      *reinterpret_cast<double2 *>(win + 2 * k) = ch[u];
+      if ((k & 7) == 0) s_lines[k >> 3] = ln[u];
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BLK) void spmv_win_kernel(WinView M, const double *__restrict__ x, double *__restrict__ y,
+                                                       const double *__restrict__ z) {
+  __shared__ double win[WL * 16];
+  __shared__ double prod[2 * WQ * BLK];
+  __shared__ int s_lines[WL];
+  const int4 d0 = M.runs[2 * blockIdx.x], d1 = M.runs[2 * blockIdx.x + 1];
+  const int r0 = d0.x, nrows = d0.y, l0 = d0.z, nl = d0.w, p0 = d1.x, q2 = d1.y, roff0 = d1.z;
+  WinRegs R;
+  win_issue(M, p0, q2, R);
+  win_stage(M.lines, l0, nl, x, win, s_lines);
+  __syncthreads();
+  const int e0 = (int)threadIdx.x * 2 * q2;
+#pragma unroll
+  for (int j = 0; j < WQ; ++j)
+    if (j < q2) {
+      prod[e0 + 2 * j] = R.v[j].x * win[R.c[j] & 0xffffu];
+      prod[e0 + 2 * j + 1] = R.v[j].y * win[R.c[j] >> 16];
+    }
+  __syncthreads();
+  constexpr int RGW = 8;  // lanes per row in the reduce phase
+  for (int rho = (int)threadIdx.x / RGW; rho < nrows; rho += BLK / RGW) {
+    const int lane = threadIdx.x % RGW;
+    const int jb = M.roff[roff0 + rho], je = M.roff[roff0 + rho + 1];
+    double sum = 0.0;
+    for (int k = jb + lane; k < je; k += RGW) sum += prod[k];
+    sum = subwave_sum<RGW>(sum);
+    if (lane == 0) {
+      const int r = r0 + rho;
+      if (MODE == 0) y[r] = sum;
+      else if (MODE == 1) y[r] += sum;
+      else y[r] = z[r] - sum;
+    }
+  }
+}
+
+// Triangular solve, both halves in one run list (see nsk_kernels.h: tri_win_solve).  The matrix stream of the NEXT
+// run of this workgroup is issued before the row sums of the current one, so only the window copy (L2 hits) and
+// the LDS phases sit between two dependent runs.
+template <int KIND>
+__global__ __launch_bounds__(BLK) void tri_win_kernel(WinView M, int i0, int i1, int reverse, const double *__restrict__ dinv,
+                                                      const int *__restrict__ perm, const double *__restrict__ rhs,
+                                                      double *Y, double *X, double *__restrict__ Xnext,
+                                                      double *__restrict__ out, int *err) {
+  __shared__ double win[WL * 16];
+  __shared__ double prod[2 * WQ * BLK];
+  __shared__ int s_lines[WL];
+  constexpr int RGW = 4;
+  // reverse (test hook): walk the list backwards, i.e. consumers before their producers, to exercise the bounded
+  // spins and the fallback
+  auto at = [&](int k) { return reverse ? i1 - 1 - (k - i0) : k; };
+  int i = i0 + (int)blockIdx.x;
+  if (i >= i1) return;
+  int4 d0 = M.runs[2 * at(i)], d1 = M.runs[2 * at(i) + 1];
+  WinRegs R;
+  win_issue(M, d1.x, d1.y, R);
+  for (;;) {
+    const int r0 = d0.x, nrows = d0.y, l0 = d0.z, nl = d0.w, q2 = d1.y, roff0 = d1.z;
+    const bool upper = d1.w & 1;
+    double *W = upper ? X : Y;
+    if (nrows > 0) {   // (padding runs of the dispatch order are empty)
+      win_stage(M.lines, l0, nl, W, win, s_lines);
+      // row data of the first reduce pass: loaded here so that its latency hides behind the window copy
+      const int rho0 = (int)threadIdx.x / RGW;
+      int jb = 0, je = 0, ip = 0;
+      double dv = 1.0;
+      unsigned long long ownb = 0ull;
+      if (rho0 < nrows) {
+        const int r = r0 + rho0;
+        jb = M.roff[roff0 + rho0];
+        je = M.roff[roff0 + rho0 + 1];
+        ip = perm[r];
+        if (upper) ownb = sf_peek(Y + r); else ownb = (unsigned long long)__double_as_longlong(rhs[ip]);
+        if (KIND == 1 || upper) dv = dinv[r];
+      }
+      __syncthreads();
+      const int e0 = (int)threadIdx.x * 2 * q2, N = M.roff[roff0 + nrows];
+#pragma unroll
+      for (int j = 0; j < WQ; ++j)
+        if (j < q2) {
+          const unsigned pa = R.c[j] & 0xffffu, pb = R.c[j] >> 16;
+          double xa = win[pa], xb = win[pb];
+          if (e0 + 2 * j < N && (unsigned long long)__double_as_longlong(xa) == kSentinel)
+            xa = sf_wait(W + (size_t)s_lines[pa >> 4] * 16 + (pa & 15u), kSentinel, err);
+          if (e0 + 2 * j + 1 < N && (unsigned long long)__double_as_longlong(xb) == kSentinel)
+            xb = sf_wait(W + (size_t)s_lines[pb >> 4] * 16 + (pb & 15u), kSentinel, err);
+          prod[e0 + 2 * j] = R.v[j].x * xa;
+          prod[e0 + 2 * j + 1] = R.v[j].y * xb;
+        }
+      // prefetch: descriptor and matrix stream of this workgroup's next run
+      const int inext = i + (int)gridDim.x;
+      int4 n0 = make_int4(0, 0, 0, 0), n1 = n0;
+      if (inext < i1) {
+        n0 = M.runs[2 * at(inext)];
+        n1 = M.runs[2 * at(inext) + 1];
+        win_issue(M, n1.x, n1.y, R);
+      }
+      __syncthreads();
+      for (int rho = rho0; rho < nrows; rho += BLK / RGW) {
+        const int lane = threadIdx.x % RGW, r = r0 + rho;
+        if (rho != rho0) {   // later passes (runs of short rows): load the row data now
+          jb = M.roff[roff0 + rho];
+          je = M.roff[roff0 + rho + 1];
+          ip = perm[r];
+          if (upper) ownb = sf_peek(Y + r); else ownb = (unsigned long long)__double_as_longlong(rhs[ip]);
+          if (KIND == 1 || upper) dv = dinv[r];
+        }
+        double sum = 0.0;
+        for (int k = jb + lane; k < je; k += RGW) sum += prod[k];
+        sum = subwave_sum<RGW>(sum);
+        if (lane == 0) {
+          if (!upper) {
+            const double own = __longlong_as_double((long long)ownb);
+            sf_store(Y + r, KIND == 0 ? (own - sum) : (own - sum) * dv);
+          } else {
+            const double own = sf_wait(Y + r, ownb, err);
+            const double v = KIND == 0 ? (own - sum) * dv : own - sum * dv;
+            sf_store(X + r, v);
+            out[ip] = v;
+            // every reader of Y[r] (lower runs of later colours next to r) has finished: their results fed the
+            // X entries this row just consumed.  Leave the sentinel for the next call; same for its X buffer.
+            reinterpret_cast<unsigned long long *>(Y)[r] = kSentinel;
+            reinterpret_cast<unsigned long long *>(Xnext)[r] = kSentinel;
+          }
+        }
+      }
+      i = inext;
+      d0 = n0;
+      d1 = n1;
+    } else {
+      i += (int)gridDim.x;
+      if (i < i1) {   // the matrix stream issued for the empty run is void: issue the next one
+        d0 = M.runs[2 * at(i)];
+        d1 = M.runs[2 * at(i) + 1];
+        win_issue(M, d1.x, d1.y, R);
+      }
+    }
+    if (i >= i1) break;
+  }
+}
+
 // ------------------------------------------------------------------ element-wise
+__global__ __launch_bounds__(BLK) void gather_or_zero_kernel(long n, const int *__restrict__ idx,
+                                                            const double *__restrict__ x, double *__restrict__ y) {
+  for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+    const int k = idx[i];
+    y[i] = k >= 0 ? x[k] : 0.0;
+  }
+}
+
 template <class F>
 __global__ __launch_bounds__(BLK) void ew_kernel(int n, F f) {
   for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) f((int)i);
@@ -972,29 +1054,6 @@ void spmv_blk_fused22_21(hipStream_t s, const BlkView &A, const double *xao, con
     hipLaunchKernelGGL(spmv_blk_fused_kernel, dim3(nblk), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, rowblk, y);
 }
 
-void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx, int run_nnz,
-                      const double *dinv, const int *perm, const double *rhs, double *w, double *out) {
-  const int nb = b1 - b0;
-  if (nb <= 0) return;
-  const int grid = ((nb + 7) / 8) * 8;
-#define NSK_TS(L, K, P, N) hipLaunchKernelGGL((tri_stream_kernel<L, K, P, N>), dim3(grid), dim3(BLK), 0, s, M, b0, nb, dinv, perm, rhs, w, out)
-#define NSK_TSN(L, K, P)                                            \
-  do {                                                              \
-    if (run_nnz <= 512) NSK_TS(L, K, P, 512);                       \
-    else if (run_nnz <= 1024) NSK_TS(L, K, P, 1024);                \
-    else NSK_TS(L, K, P, 2048);                                     \
-  } while (0)
-  if (permx) {
-    if (lower) { if (kind == 0) NSK_TSN(1, 0, 1); else NSK_TSN(1, 1, 1); }
-    else { if (kind == 0) NSK_TSN(0, 0, 1); else NSK_TSN(0, 1, 1); }
-  } else {
-    if (lower) { if (kind == 0) NSK_TSN(1, 0, 0); else NSK_TSN(1, 1, 0); }
-    else { if (kind == 0) NSK_TSN(0, 0, 0); else NSK_TSN(0, 1, 0); }
-  }
-#undef NSK_TSN
-#undef NSK_TS
-}
-
 #define NSK_EW(n, ...)                                                                       \
   do {                                                                                       \
     if ((n) > 0) {                                                                           \
@@ -1059,26 +1118,11 @@ void vec_fill_sentinel(hipStream_t s, int n, double *y) {
   unsigned long long *p = reinterpret_cast<unsigned long long *>(y);
   NSK_EW(n, [=] __device__(int i) { p[i] = kSentinel; });
 }
-void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int kind, int run_nnz, int wrong_order,
-                         const double *dinv, const int *perm, const double *rhs, const double *own, double *w,
-                         int *err) {
+void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int nb, int lower, int kind, int permx, int wrong_order,
+                      const double *intra, const int *permn, const double *rhs, const double *own, double *w, double *out,
+                      int *err) {
   if (nb <= 0) return;
-#define NSK_SF(L, K, N) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, dinv, perm, rhs, own, w, err)
-#define NSK_SFN(L, K)                                      \
-  do {                                                     \
-    if (run_nnz <= 512) NSK_SF(L, K, 512);                 \
-    else if (run_nnz <= 1024) NSK_SF(L, K, 1024);          \
-    else NSK_SF(L, K, 2048);                               \
-  } while (0)
-  if (lower) { if (kind == 0) NSK_SFN(1, 0); else NSK_SFN(1, 1); }
-  else { if (kind == 0) NSK_SFN(0, 0); else NSK_SFN(0, 1); }
-#undef NSK_SFN
-#undef NSK_SF
-}
-void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int nb, int lower, int kind, int permx, const double *intra,
-                      const int *permn, const double *rhs, const double *own, double *w, double *out, int *err) {
-  if (nb <= 0) return;
-#define NSK_SB(L, K, P) hipLaunchKernelGGL((tri_blk_sf_kernel<L, K, P>), dim3(nb), dim3(BLK), 0, s, M, nb, intra, permn, rhs, own, w, out, err)
+#define NSK_SB(L, K, P) hipLaunchKernelGGL((tri_blk_sf_kernel<L, K, P>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, intra, permn, rhs, own, w, out, err)
   if (permx) {
     if (lower) { if (kind == 0) NSK_SB(1, 0, 1); else NSK_SB(1, 1, 1); }
     else { if (kind == 0) NSK_SB(0, 0, 1); else NSK_SB(0, 1, 1); }
@@ -1087,6 +1131,32 @@ void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int nb, int lower, int kin
     else { if (kind == 0) NSK_SB(0, 0, 0); else NSK_SB(0, 1, 0); }
   }
 #undef NSK_SB
+}
+void spmv_win(hipStream_t s, const WinView &A, int n_runs, const double *x, double *y, int mode, const double *z) {
+  if (n_runs <= 0) return;
+  if (mode == 0) hipLaunchKernelGGL((spmv_win_kernel<0>), dim3(n_runs), dim3(BLK), 0, s, A, x, y, z);
+  else if (mode == 1) hipLaunchKernelGGL((spmv_win_kernel<1>), dim3(n_runs), dim3(BLK), 0, s, A, x, y, z);
+  else hipLaunchKernelGGL((spmv_win_kernel<2>), dim3(n_runs), dim3(BLK), 0, s, A, x, y, z);
+}
+void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, double *y) {
+  if (n <= 0) return;
+  const int grid = (int)std::min<long>(65535 * 8, (n + BLK * 4 - 1) / (BLK * 4));
+  hipLaunchKernelGGL(gather_or_zero_kernel, dim3(grid), dim3(BLK), 0, s, n, idx, x, y);
+}
+void tri_win_solve(hipStream_t s, const WinView &M, int i0, int i1, int grid, int kind, int reverse, const WinTriArgs &a) {
+  if (i1 <= i0 || grid <= 0) return;
+  if (kind == 0)
+    hipLaunchKernelGGL((tri_win_kernel<0>), dim3(grid), dim3(BLK), 0, s, M, i0, i1, reverse, a.dinv, a.perm, a.rhs, a.Y, a.X, a.Xnext,
+                       a.out, a.err);
+  else
+    hipLaunchKernelGGL((tri_win_kernel<1>), dim3(grid), dim3(BLK), 0, s, M, i0, i1, reverse, a.dinv, a.perm, a.rhs, a.Y, a.X, a.Xnext,
+                       a.out, a.err);
+}
+int tri_win_max_resident_per_cu() {
+  int a = 0, b = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, tri_win_kernel<0>, BLK, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, tri_win_kernel<1>, BLK, 0) != hipSuccess) return 0;
+  return std::min(a, b);
 }
 void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra) {
   const int n = n_nodes;

@@ -30,10 +30,13 @@ struct SolverControl {
   double tol;
   int lstep = 0;
   double lvalue = 0.0;
+  volatile long *progress_step = nullptr;     // optional: where a watcher (bench heartbeat) reads the progress
+  volatile double *progress_value = nullptr;
   SolverControl(int n, double t) : max_steps(n), tol(t) {}
   State check(int step, double value) {
     lstep = step;
     lvalue = value;
+    if (progress_step) { *progress_step = step; *progress_value = value; }
     if (value <= tol) return success;
     if (step >= max_steps || std::isnan(value)) return failure;
     return iterate;

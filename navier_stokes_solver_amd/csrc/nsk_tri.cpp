@@ -36,6 +36,8 @@ void level_lists(const std::vector<int> &level, int n_levels, std::vector<int> &
   std::vector<int> cur(lvl_ptr.begin(), lvl_ptr.end() - 1);
   for (int i = 0; i < n; ++i) rows[cur[level[i]]++] = i;  // ascending row id inside a level
 }
+}  // namespace
+
 // greedy distance-1 colouring on the graph of G + G^T, vertices visited in natural order
 int greedy_color(int nv, const std::vector<int> &grp, const std::vector<int> &gcol, std::vector<int> &color) {
   const int64_t ne = grp[nv];
@@ -65,7 +67,6 @@ int greedy_color(int nv, const std::vector<int> &grp, const std::vector<int> &gc
   }
   return ncol;
 }
-}  // namespace
 
 // Dispatch order for the single-launch (sync-free) kernels.  Workgroup b of a grid lands on XCD b % 8 and
 // workgroups start in index order.  Colours follow each other in dependency order (ascending for the lower
@@ -258,7 +259,6 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   lpr = mean_half <= 6 ? 4 : (mean_half <= 14 ? 8 : (mean_half <= 48 ? 16 : 32));
 
   hipStream_t s = ctx->stream;
-  stream_ready = false;
   block2_ready = false;
   if (!perm.empty() && block2) {
     // node rows in colour order; 2x2 blocks towards earlier (L) / later (U) colours, column ids = caller-order node ids
@@ -355,66 +355,11 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       block2_ready = true;
     }
   }
+  win_ready = false;
   if (!perm.empty() && !block2) {
-    // strict-lower / strict-upper CSR halves with every colour a contiguous run of rows
-    std::vector<int> lrp(n + 1, 0), urp(n + 1, 0);
-    for (int i = 0; i < n; ++i) {
-      lrp[i + 1] = lrp[i] + (pdiag[i] - prp[i]);
-      urp[i + 1] = urp[i] + (prp[i + 1] - pdiag[i] - 1);
-    }
-    nnzL = lrp[n];
-    nnzU = urp[n];
-    std::vector<int> lcol((size_t)nnzL), lsrc((size_t)nnzL), ucol((size_t)nnzU), usrc((size_t)nnzU);
-    // column ids go back to the caller's numbering, sorted, so that a row's gathers are runs of neighbours
-#pragma omp parallel
-    {
-      std::vector<std::pair<int, int>> buf;
-#pragma omp for schedule(static)
-      for (int i = 0; i < n; ++i) {
-        buf.clear();
-        for (int k = prp[i]; k < pdiag[i]; ++k) buf.emplace_back(x_layout ? pcol[k] : perm[pcol[k]], k);
-        std::sort(buf.begin(), buf.end());
-        int w = lrp[i];
-        for (auto &e : buf) { lcol[w] = e.first; lsrc[w] = e.second; ++w; }
-        buf.clear();
-        for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k) buf.emplace_back(x_layout ? pcol[k] : perm[pcol[k]], k);
-        std::sort(buf.begin(), buf.end());
-        w = urp[i];
-        for (auto &e : buf) { ucol[w] = e.first; usrc[w] = e.second; ++w; }
-      }
-    }
-    std::vector<int> cuts(hLp.begin() + 1, hLp.end());  // colour boundaries (levL = colour, rows ascending)
-    std::vector<int> lb, ub;
-    if (build_rowblocks(lrp.data(), nullptr, n, run_nnz, &cuts, lb) &&
-        build_rowblocks(urp.data(), nullptr, n, run_nnz, &cuts, ub)) {
-      auto first_block_of = [&](const std::vector<int> &blk, std::vector<int> &out) {
-        out.assign(n_colors + 1, 0);
-        size_t b = 0;
-        for (int c = 0; c <= n_colors; ++c) {
-          const int row = c < n_colors ? hLp[c] : n;
-          while (b + 1 < blk.size() && blk[b] < row) ++b;
-          out[c] = (int)b;
-        }
-      };
-      first_block_of(lb, LB);
-      first_block_of(ub, UB);
-      auto make_desc = [](const std::vector<int> &blk, const std::vector<int> &rp_) {
-        std::vector<int4> d(blk.size() - 1);
-        for (size_t b = 0; b + 1 < blk.size(); ++b) d[b] = make_int4(blk[b], blk[b + 1], rp_[blk[b]], rp_[blk[b + 1]]);
-        return d;
-      };
-      const std::vector<int4> ld = make_desc(lb, lrp), ud = make_desc(ub, urp);
-      const std::vector<int4> lsf = sf_dispatch_order(ld, LB, true), usf = sf_dispatch_order(ud, UB, false);
-      n_Lsf = (int)lsf.size();
-      n_Usf = (int)usf.size();
-      Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Ldesc.upload(ld, s); Lsf.upload(lsf, s);
-      Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Udesc.upload(ud, s); Usf.upload(usf, s);
-      Lval.alloc((size_t)nnzL);
-      Uval.alloc((size_t)nnzU);
-      dinv.alloc((size_t)n);
-      ctx->sync();
-      stream_ready = true;
-    }
+    // strict-lower / strict-upper CSR halves in colour order (rows AND columns: the solves work on colour-ordered
+    // vectors, so a colour only reads the segments of the colours it depends on), then the window format of both
+    build_window_factor(prp, pcol, pdiag, hLp, pcolor);
   }
   rowptr.upload(prp, s);
   col.upload(pcol, s);
@@ -428,6 +373,94 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   val.alloc((size_t)nnz);
   y.alloc((size_t)n + 1);
   ctx->sync();  // host staging vectors die at scope exit
+}
+
+void TriSolve::build_window_factor(const std::vector<int> &prp, const std::vector<int> &pcol,
+                                   const std::vector<int> &pdiag, const std::vector<int> &color_ptr,
+                                   const std::vector<int> &pcolor) {
+  hipStream_t s = ctx->stream;
+  std::vector<int> lrp(n + 1, 0), urp(n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    lrp[i + 1] = lrp[i] + (pdiag[i] - prp[i]);
+    urp[i + 1] = urp[i] + (prp[i + 1] - pdiag[i] - 1);
+  }
+  nnzL = lrp[n];
+  nnzU = urp[n];
+  std::vector<int> lcol((size_t)nnzL), lsrc((size_t)nnzL), ucol((size_t)nnzU), usrc((size_t)nnzU);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {   // pcol is sorted inside a row
+    int w = lrp[i];
+    for (int k = prp[i]; k < pdiag[i]; ++k) { lcol[w] = pcol[k]; lsrc[w] = k; ++w; }
+    w = urp[i];
+    for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k) { ucol[w] = pcol[k]; usrc[w] = k; ++w; }
+  }
+  std::vector<int> cuts(color_ptr.begin() + 1, color_ptr.end());   // colour boundaries
+  WinFormat WLo, WUp;
+  if (!build_win_format(n, lrp.data(), lcol.data(), lsrc.data(), &cuts, pcolor.data(), kWinMaxLines, 0, WLo) ||
+      !build_win_format(n, urp.data(), ucol.data(), usrc.data(), &cuts, pcolor.data(), kWinMaxLines, 1, WUp))
+    return;   // a row exceeds the window: the level-scheduled CSR kernels serve this factor
+  // one run list in dispatch order; lower and upper runs index the same value / position arrays (upper shifted)
+  const int64_t pair_shift = WLo.n_slots / 2;
+  const int line_shift = (int)WLo.lines.size(), roff_shift = (int)WLo.roff.size();
+  std::vector<WinRun> list;
+  win_level.assign(1, 0);
+  auto deal = [&](const WinFormat &W, int c, bool upper) {
+    // runs of colour c are contiguous in W.runs (built in row order with cuts at the colour boundaries)
+    size_t b0 = 0, b1 = 0;
+    {
+      auto lo = std::lower_bound(W.runs.begin(), W.runs.end(), color_ptr[c], [](const WinRun &R, int r) { return R.r0 < r; });
+      auto hi = std::lower_bound(W.runs.begin(), W.runs.end(), color_ptr[c + 1], [](const WinRun &R, int r) { return R.r0 < r; });
+      b0 = (size_t)(lo - W.runs.begin());
+      b1 = (size_t)(hi - W.runs.begin());
+    }
+    const int nb = (int)(b1 - b0), per = (nb + 7) / 8;
+    for (int p = 0; p < 8 * per; ++p) {
+      const int logical = (p & 7) * per + (p >> 3);
+      WinRun R{};
+      if (logical < nb) {
+        R = W.runs[b0 + (size_t)logical];
+        if (upper) { R.p0 += (int)pair_shift; R.l0 += line_shift; R.roff0 += roff_shift; }
+      }
+      R.flags = (R.flags & ~1) | (upper ? 1 : 0);
+      list.push_back(R);
+    }
+    win_level.push_back((int)list.size());
+  };
+  for (int c = 0; c < n_colors; ++c) deal(WLo, c, false);
+  for (int c = n_colors - 1; c >= 0; --c) deal(WUp, c, true);
+  win_nruns = (int)list.size();
+  win_slots = WLo.n_slots + WUp.n_slots;
+  win_bytes = WLo.bytes_per_apply() + WUp.bytes_per_apply();
+  WLo.lines.insert(WLo.lines.end(), WUp.lines.begin(), WUp.lines.end());
+  WLo.roff.insert(WLo.roff.end(), WUp.roff.begin(), WUp.roff.end());
+  WLo.pos.insert(WLo.pos.end(), WUp.pos.begin(), WUp.pos.end());
+  WLo.src.insert(WLo.src.end(), WUp.src.begin(), WUp.src.end());
+  win_runs.upload(win_pack_runs(list), s);
+  win_lines.upload(WLo.lines, s);
+  win_roff.upload(WLo.roff, s);
+  win_pos.upload(WLo.pos, s);
+  win_src.upload(WLo.src, s);
+  win_val.alloc((size_t)win_slots);
+  const size_t nw = ((size_t)n + kWinLine - 1) / kWinLine * kWinLine + kWinLine;   // whole lines
+  win_y.alloc(nw);
+  win_x0.alloc(nw);
+  win_x1.alloc(nw);
+  dinv.alloc((size_t)n);
+  // workgroups of the persistent launch: all of them must be resident together
+  const int per_cu = std::min(tri_win_max_resident_per_cu(), 4);
+  win_grid = std::max(8, per_cu * ctx->n_cu / 8 * 8);
+  win_dirty = true;
+  win_parity = 0;
+  ctx->sync();
+  win_ready = per_cu > 0;
+}
+
+double TriSolve::format_bytes() const {
+  if (win_ready)   // window stream + per row: perm, rhs, dinv, Y (store, load, reset), X (store), Xnext (reset), result
+    return win_bytes + 68.0 * (double)n;
+  if (block2_ready)   // 2x2 blocks with one int32 block column + per node row: descriptor share, intra, rhs, y, x
+    return 36.0 * (double)(nnzL + nnzU) / 4.0 + 8.0 * (double)(n / 2) + (32.0 + 4.0 + 48.0) * (double)(n / 2);
+  return (double)apply_bytes();
 }
 
 void TriSolve::numeric(const double *a_val_dev) {
@@ -445,9 +478,8 @@ void TriSolve::numeric(const double *a_val_dev) {
     vec_gather(s, 2 * n, intra_src.p, val.p, intra.p);   // per node: l10, u01, d0, d1
     invert_node_diagonals(s, n / 2, intra.p);            // d0, d1 -> 1/d0, 1/d1
   }
-  if (stream_ready) {
-    vec_gather(s, (int)nnzL, Lsrc.p, val.p, Lval.p);
-    vec_gather(s, (int)nnzU, Usrc.p, val.p, Uval.p);
+  if (win_ready) {
+    vec_gather_or_zero(s, (long)win_slots, win_src.p, val.p, win_val.p);
     vec_gather(s, n, diag.p, val.p, dinv.p);
     vec_recip(s, n, dinv.p, dinv.p);
   }
@@ -457,30 +489,51 @@ void TriSolve::apply(const double *b, double *x) {
   hipStream_t s = ctx->stream;
   // Tiny factors (a few MB: they sit in one XCD's L2) are latency-bound on the ~5 us per level launch:
   // one 1024-thread workgroup walking all levels with __syncthreads in between is faster there.
-  const bool tiny = (double)nnz * 12.0 < 4.0e6 && !schedL.empty();
-  if (sync_free && use_stream && !tiny && (block2_ready || (stream_ready && x_layout == 0))) {
+  const bool tiny = (double)nnz * 12.0 < tiny_bytes && !schedL.empty();
+  if (win_ready && use_stream && !tiny) {
+    // scalar multicolour factor in the window format, colour-ordered working vectors (see nsk_kernels.h: tri_win_solve)
+    if (!sf_err.p) {
+      sf_err.alloc(1);
+      NSK_HIP(hipMemsetAsync(sf_err.p, 0, sizeof(int), s));
+    }
+    if (win_dirty) {   // first call, or a call after a solve that gave up: every entry waits for its producer again
+      vec_fill_sentinel(s, (int)win_y.n, win_y.p);
+      vec_fill_sentinel(s, (int)win_x0.n, win_x0.p);
+      vec_fill_sentinel(s, (int)win_x1.n, win_x1.p);
+      win_dirty = false;
+    }
+    const WinView M{win_runs.p, win_lines.p, win_roff.p, reinterpret_cast<const unsigned *>(win_pos.p), win_val.p};
+    const WinTriArgs a{dinv.p, d_perm.p, b, win_y.p, win_parity ? win_x1.p : win_x0.p, win_parity ? win_x0.p : win_x1.p,
+                       x, sf_err.p};
+    if (sync_free) {
+      // ONE persistent launch for both halves; all its workgroups are resident together, so a wait never depends
+      // on a workgroup that has not started
+      tri_win_solve(s, M, 0, win_nruns, std::min(win_grid, win_nruns), kind, win_fault, a);
+    } else {
+      for (size_t l = 0; l + 1 < win_level.size(); ++l)   // one launch per colour, a workgroup per run
+        tri_win_solve(s, M, win_level[l], win_level[l + 1], win_level[l + 1] - win_level[l], kind, 0, a);
+    }
+    win_parity ^= 1;
+    ++ctx->st.tri_applies;
+    ctx->st.tri_bytes += (double)apply_bytes();
+    return;
+  }
+  if (sync_free && use_stream && !tiny && block2_ready) {
     if (!sf_err.p) {
       sf_err.alloc(1);
       NSK_HIP(hipMemsetAsync(sf_err.p, 0, sizeof(int), s));
     }
     // lower half into y (pre-filled with the sentinel), upper half into x; each half is ONE launch
     vec_fill_sentinel(s, n, y.p);
-    if (block2_ready) {
-      const TriBlk L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
-      tri_blk_syncfree(s, L, n_Lsf, 1, kind, x_layout, intra.p, permn.p, b, nullptr, y.p, nullptr, sf_err.p);
-      if (x_layout) {  // colour-ordered working vectors y, xc; the upper half also writes the caller-order result
-        if (xc.n != (size_t)n + 1) xc.alloc((size_t)n + 1);
-        vec_fill_sentinel(s, n, xc.p);
-        tri_blk_syncfree(s, U, n_Usf, 0, kind, 1, intra.p, permn.p, nullptr, y.p, xc.p, x, sf_err.p);
-      } else {
-        vec_fill_sentinel(s, n, x);
-        tri_blk_syncfree(s, U, n_Usf, 0, kind, 0, intra.p, permn.p, nullptr, y.p, x, nullptr, sf_err.p);
-      }
+    const TriBlk L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
+    tri_blk_syncfree(s, L, n_Lsf, 1, kind, x_layout, 0, intra.p, permn.p, b, nullptr, y.p, nullptr, sf_err.p);
+    if (x_layout) {  // colour-ordered working vectors y, xc; the upper half also writes the caller-order result
+      if (xc.n != (size_t)n + 1) xc.alloc((size_t)n + 1);
+      vec_fill_sentinel(s, n, xc.p);
+      tri_blk_syncfree(s, U, n_Usf, 0, kind, 1, sf_fault ? 1 : 0, intra.p, permn.p, nullptr, y.p, xc.p, x, sf_err.p);
     } else {
-      const TriHalf L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
-      tri_stream_syncfree(s, L, n_Lsf, 1, kind, run_nnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, sf_err.p);
       vec_fill_sentinel(s, n, x);
-      tri_stream_syncfree(s, U, n_Usf, 0, kind, run_nnz, sf_fault ? 1 : 0, dinv.p, d_perm.p, nullptr, y.p, x, sf_err.p);
+      tri_blk_syncfree(s, U, n_Usf, 0, kind, 0, sf_fault ? 1 : 0, intra.p, permn.p, nullptr, y.p, x, nullptr, sf_err.p);
     }
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
@@ -492,20 +545,6 @@ void TriSolve::apply(const double *b, double *x) {
     const TriBlk L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
     for (int c = 0; c < n_colors; ++c) tri_blk_level(s, L, LB[c], LB[c + 1], 1, kind, intra.p, permn.p, b, x);
     for (int c = n_colors - 1; c >= 0; --c) tri_blk_level(s, U, UB[c], UB[c + 1], 0, kind, intra.p, permn.p, nullptr, x);
-    ++ctx->st.tri_applies;
-    ctx->st.tri_bytes += (double)apply_bytes();
-    return;
-  }
-  if (stream_ready && use_stream && !tiny) {
-    const TriHalf L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
-    if (x_layout == 0) {
-      // x doubles as the intermediate vector: rows not yet solved hold L^-1 b, solved rows hold the result
-      for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, 0, run_nnz, dinv.p, d_perm.p, b, x, nullptr);
-      for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, 0, run_nnz, dinv.p, d_perm.p, nullptr, x, nullptr);
-    } else {
-      for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, 1, run_nnz, dinv.p, d_perm.p, b, y.p, nullptr);
-      for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, 1, run_nnz, dinv.p, d_perm.p, nullptr, y.p, x);
-    }
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
     return;

@@ -19,6 +19,10 @@ namespace nsk {
 
 enum { ORDER_NATURAL = 0, ORDER_MULTICOLOR = 1 };
 
+// greedy distance-1 colouring of the graph of G + G^T (CSR grp/gcol, nv vertices, visited in natural order);
+// returns the number of colours
+int greedy_color(int nv, const std::vector<int> &grp, const std::vector<int> &gcol, std::vector<int> &color);
+
 struct TriSolve {
   Ctx *ctx = nullptr;
   int n = 0;
@@ -40,13 +44,13 @@ struct TriSolve {
   std::vector<Step> schedL, schedU;
 
   // split factors for the streamed kernels (multicolour ordering: one colour = one contiguous level)
-  bool use_stream = true, stream_ready = false;
+  bool use_stream = true;
+  double tiny_bytes = 4.0e6;  // factors below this size take the single-workgroup path (NSK_IOPT_TINY_BYTES)
   bool sync_free = false;  // one launch per half with in-kernel producer/consumer hand-off (see nsk_kernels.h)
-  bool sf_fault = false;   // test hook: wrong workgroup order in the upper half
+  bool sf_fault = false;   // test hook (blocked factor): wrong workgroup order in the upper half
   DBuf<double> xc;         // colour-ordered result vector of the upper half (x_layout = 1, blocked factor)
   DBuf<int> sf_err;        // raised by a bounded spin that ran out
-  int run_nnz = 2048;  // non-zeros per workgroup of the scalar streamed levels (512 / 1024 / 2048)
-  int x_layout = 0;  // 0: solve in the caller's (lattice) order; 1: internal colour-ordered vector
+  int x_layout = 0;  // blocked factor: 0 solve in the caller's (lattice) order; 1: internal colour-ordered vector
   DBuf<int> Lrp, Lcol, Lsrc, Urp, Ucol, Usrc;
   DBuf<int4> Ldesc, Udesc;
   DBuf<int4> Lsf, Usf;     // the same runs in the dispatch order of the single-launch kernels
@@ -54,6 +58,18 @@ struct TriSolve {
   DBuf<double> Lval, Uval, dinv;
   std::vector<int> LB, UB;  // per colour: first workgroup of that colour in Lblk / Ublk (n_colors + 1)
   int64_t nnzL = 0, nnzU = 0;
+  // window format of the scalar multicolour factors (nsk_win.hpp): both halves in ONE run list in dispatch order
+  // (lower colours ascending, then upper colours descending; inside a colour XCD k owns the k-th eighth), solved on
+  // colour-ordered working vectors by a persistent single launch (sync_free) or level by level
+  bool win_ready = false, win_dirty = true;   // dirty: the working vectors must be re-filled with the sentinel
+  int win_nruns = 0, win_grid = 0, win_parity = 0, win_fault = 0;
+  int64_t win_slots = 0;
+  double win_bytes = 0;
+  std::vector<int> win_level;                 // run-list offsets of the 2 * n_colors levels (+ end)
+  DBuf<int4> win_runs;
+  DBuf<int> win_lines, win_src;
+  DBuf<unsigned short> win_roff, win_pos;
+  DBuf<double> win_val, win_y, win_x0, win_x1;
   // 2x2 node-block variant (velocity block): node rows in node-colour order, blocks in L*/U* above,
   // per node row {l10, u01, 1/d0, 1/d1} in `intra`
   bool block2_ready = false;
@@ -64,10 +80,15 @@ struct TriSolve {
   // sub_off: optional n_sub+1 offsets of emulated MPI ranks inside this GPU (block Jacobi)
   void analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off,
                bool want_block2 = false);
+  void build_window_factor(const std::vector<int> &prp, const std::vector<int> &pcol, const std::vector<int> &pdiag,
+                           const std::vector<int> &color_ptr, const std::vector<int> &pcolor);
   void numeric(const double *a_val_dev);           // refresh values (+ factorise for ILU)
   void apply(const double *b, double *x);          // x = M^{-1} b, caller's ordering
   TriView view() const { return TriView{n, rowptr.p, diag.p, col.p, val.p, perm.empty() ? nullptr : d_perm.p}; }
-  size_t apply_bytes() const { return (size_t)12 * nnz + 8 * ((size_t)n + 1) * 2 + 16 * (size_t)n; }
+  // 12 nnz_factor + 4 (rows + 1) * 2 + 16 rows
+  size_t apply_bytes() const { return (size_t)12 * nnz + 8 * ((size_t)n + 1) + 16 * (size_t)n; }
+  // bytes the storage format in use really streams per apply (values, indices, descriptors, vectors)
+  double format_bytes() const;
 };
 
 }  // namespace nsk

@@ -24,9 +24,11 @@ BLOCK_DIAGONAL, BLOCK_TRIANGULAR, ASIMPLE = 0, 1, 2
 STATIONARY, UNSTEADY = 0, 1
 TRI_VELOCITY, TRI_PRESSURE = 0, 1
 OPT_TRI_ORDERING, OPT_SUBDOMAINS, OPT_FUSE_BLOCK_ROW, OPT_STREAM_KERNELS = 0, 1, 2, 3
-OPT_INNER_FUSED_GS, OPT_OUTER_FUSED_GS, OPT_TRI_X_LAYOUT, OPT_BSR_VELOCITY, OPT_TRI_RUN_NNZ = 4, 5, 6, 7, 8
+OPT_INNER_FUSED_GS, OPT_OUTER_FUSED_GS, OPT_BSR_VELOCITY = 4, 5, 7
 OPT_TRI_SYNC_FREE = 9
 OPT_VELOCITY_AMG = 10
+# not part of the public ABI (csrc/nsk_internal.h): study switches and the fault-injection hook of the tests
+IOPT_TRI_X_LAYOUT, IOPT_FAULT_INJECT, IOPT_WINDOW_SPMV, IOPT_TINY_BYTES = 6, 100, 101, 102
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
 
 EXPORTS = [
@@ -46,7 +48,8 @@ class Stats(C.Structure):
                 ("reductions", C.c_int64), ("host_syncs", C.c_int64),
                 ("spmv_bytes", C.c_double), ("tri_bytes", C.c_double), ("blas1_bytes", C.c_double),
                 ("n_colors_u", C.c_int32), ("n_levels_u", C.c_int32), ("n_colors_p", C.c_int32),
-                ("n_levels_p", C.c_int32), ("nnz_s", C.c_int64), ("sync_free_fallbacks", C.c_int64)]
+                ("n_levels_p", C.c_int32), ("nnz_s", C.c_int64), ("sync_free_fallbacks", C.c_int64),
+                ("cur_outer_iters", C.c_int64), ("cur_residual", C.c_double)]
 
 
 class NoConvergence(RuntimeError):

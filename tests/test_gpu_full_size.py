@@ -71,35 +71,43 @@ def test_single_launch_and_per_level_pressure_solves_agree(big):
         ls.set_option(S.OPT_TRI_SYNC_FREE, mode)
         ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
         out.append((ls.tri_apply(S.TRI_PRESSURE, b), ls.tri_apply(S.TRI_VELOCITY, np.resize(b, pr.n_u))))
-    ls.set_option(S.OPT_TRI_SYNC_FREE, 1)
+    ls.set_option(S.OPT_TRI_SYNC_FREE, 2)
     for k in (1, 2):
         assert np.abs(out[k][0] - out[0][0]).max() <= 1e-12 * np.abs(out[0][0]).max()
         assert np.abs(out[k][1] - out[0][1]).max() <= 1e-12 * np.abs(out[0][1]).max()
 
 
-def test_sync_free_timeout_falls_back(big):
-    """Fault injection: the upper half of the single-launch ILU(S) solve runs its workgroups in the wrong
-    order, so consumers wait for producers that are not scheduled yet.  The bounded spins must give up (no
-    hang), nsk_solve_resident must report -70, and nsk_solve must fall back to per-level launches by itself."""
+@pytest.mark.parametrize("which", [1, 2])
+def test_sync_free_timeout_falls_back(big, which):
+    """Fault injection on the DEFAULT kernels (1: the persistent window solve of ILU(S) walks its run list backwards,
+    2: the upper half of the blocked ILU(F) solve does): consumers wait for producers that cannot run yet.  The bounded
+    spins must give up (no hang) and nsk_solve_resident — the path of bench.py and of both CLI drivers — must redo the
+    solve with one launch per colour by itself and return the same result as an undisturbed solve."""
     import time
     pr, ls, S = big
-    ls.set_option(S.OPT_TRI_SYNC_FREE, 1)
-    ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
-    good = ls.solve(S.FGMRES, 0.0, 1, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
-    ls.set_option(S.OPT_TRI_SYNC_FREE, 3)
+    ls.set_option(S.IOPT_FAULT_INJECT, 0)
+    ls.set_option(S.OPT_TRI_SYNC_FREE, 2)
     ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
     ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
-    t0 = time.time()
-    with pytest.raises(RuntimeError, match="-70"):
-        ls.solve_resident(S.FGMRES, 0.0, 1)
-    assert time.time() - t0 < 120.0
-    ls.set_option(S.OPT_TRI_SYNC_FREE, 3)
+    good_its, good_res, good_rc = ls.solve_resident(S.FGMRES, 0.0, 1)
+    good = ls.download_solution()
+    ls.set_option(S.IOPT_FAULT_INJECT, which)
     ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+    ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
     before = ls.stats()["sync_free_fallbacks"]
-    xu, xp, its, res, rc = ls.solve(S.FGMRES, 0.0, 1, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
-    assert ls.stats()["sync_free_fallbacks"] == before + 1 and (its, rc) == (good[2], good[4])
-    assert np.abs(xu - good[0]).max() <= 1e-9 * np.abs(good[0]).max() and abs(res - good[3]) <= 1e-9 * good[3]
-    ls.set_option(S.OPT_TRI_SYNC_FREE, 1)
+    t0 = time.time()
+    its, res, rc = ls.solve_resident(S.FGMRES, 0.0, 1)
+    assert time.time() - t0 < 120.0
+    assert ls.stats()["sync_free_fallbacks"] == before + 1 and (its, rc) == (good_its, good_rc)
+    xu, xp = ls.download_solution()
+    assert np.abs(xu - good[0]).max() <= 1e-9 * np.abs(good[0]).max() and abs(res - good_res) <= 1e-9 * good_res
+    # the handle now runs per-colour launches; switching the single-launch solves on again works
+    ls.set_option(S.IOPT_FAULT_INJECT, 0)
+    ls.set_option(S.OPT_TRI_SYNC_FREE, 2)
+    ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+    ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    its2, res2, rc2 = ls.solve_resident(S.FGMRES, 0.0, 1)
+    assert ls.stats()["sync_free_fallbacks"] == before + 1 and abs(res2 - good_res) <= 1e-9 * good_res
 
 
 def test_ilu_apply_inverts_its_own_factors(big):

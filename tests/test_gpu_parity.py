@@ -335,27 +335,65 @@ def test_north_star_tolerance_on_60x20(handles):
 
 
 def test_tri_x_layouts_agree():
-    """Triangular solves on the caller-order vector and on the internal colour-ordered vector are the
+    """The blocked velocity factor solved on the caller-order vector and on the internal colour-ordered vector is the
     same arithmetic (only the summation order inside a row differs)."""
     S, O = _S(), _O()
     pr = problem("ns60")
     out = []
-    for layout in (0, 1):
+    for layout in (0, 2):
         ls = S.LinearSolver()
         try:
             ls.set_problem(pr)
             ls.set_option(S.OPT_TRI_ORDERING, 1)
-            ls.set_option(S.OPT_TRI_X_LAYOUT, layout)
+            ls.set_option(S.IOPT_TRI_X_LAYOUT, layout)
             ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
             b = rng_vec(pr.n_u, 70)
             x = ls.tri_apply(S.TRI_VELOCITY, b)
             ref = O.Tri(O.CsrHolder.from_block(pr.F), kind=0, perm=ls.tri_perm(S.TRI_VELOCITY)).apply(b)
             assert rel_err(x, ref) <= 1e-11
-            bp = rng_vec(pr.n_p, 71)
-            out.append((x, ls.tri_apply(S.TRI_PRESSURE, bp)))
+            out.append(x)
         finally:
             ls.close()
-    assert rel_err(out[0][0], out[1][0]) <= 1e-12 and rel_err(out[0][1], out[1][1]) <= 1e-12
+    assert rel_err(out[0], out[1]) <= 1e-12
+
+
+@pytest.mark.parametrize("name", ["ns60", "stokes60"])
+@pytest.mark.parametrize("sync_free", [0, 1])
+def test_window_kernels_on_the_pressure_block(name, sync_free):
+    """ILU(S) / SGS(Mp) applies and the S / Mp SpMVs on the window format (LDS-staged column tiles, 16-bit
+    positions): against the oracle with the library's permutation; persistent single launch and per-colour launches;
+    repeated applies (the sentinel state of the working vectors is restored by every call)."""
+    S, O = _S(), _O()
+    import scipy.sparse as sp
+    pr = problem(name)
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr)
+        ls.set_option(S.OPT_TRI_ORDERING, 1)
+        ls.set_option(S.OPT_TRI_SYNC_FREE, sync_free)
+        ls.set_option(S.IOPT_TINY_BYTES, 0)     # these factors are small: force them through the streamed kernels
+        ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+        rp, col, val = ls.get_block(S.BLK_S)
+        Sm = sp.csr_matrix((val, col, rp), shape=(pr.n_p, pr.n_p))
+        tri = O.Tri(O.CsrHolder.from_scipy(Sm), kind=0, perm=ls.tri_perm(S.TRI_PRESSURE))
+        for k in range(4):
+            b = rng_vec(pr.n_p, 100 + k)
+            assert rel_err(ls.tri_apply(S.TRI_PRESSURE, b), tri.apply(b)) <= 1e-11, (name, sync_free, k)
+        x = rng_vec(pr.n_p, 9)
+        for opt in (1, 0):
+            ls.set_option(S.IOPT_WINDOW_SPMV, opt)
+            assert rel_err(ls.spmv(S.BLK_S, x), Sm @ x) <= 1e-13
+            assert rel_err(ls.spmv(S.BLK_MP, x), pr.Mp.to_scipy() @ x) <= 1e-13
+            y0 = rng_vec(pr.n_p, 10)
+            assert rel_err(ls.spmv(S.BLK_MP, x, y0, add=True), y0 + pr.Mp.to_scipy() @ x) <= 1e-13
+        ls.set_option(S.IOPT_WINDOW_SPMV, 1)
+        ls.setup_preconditioner(S.BLOCK_DIAGONAL, S.STATIONARY)      # SGS on the pressure mass matrix
+        tri = O.Tri(O.CsrHolder.from_block(pr.Mp), kind=1, perm=ls.tri_perm(S.TRI_PRESSURE))
+        for k in range(3):
+            b = rng_vec(pr.n_p, 200 + k)
+            assert rel_err(ls.tri_apply(S.TRI_PRESSURE, b), tri.apply(b)) <= 1e-11
+    finally:
+        ls.close()
 
 
 @pytest.mark.parametrize("bsr", [0, 1])
