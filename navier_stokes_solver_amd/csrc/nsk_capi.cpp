@@ -86,6 +86,7 @@ struct nsk_handle_s {
   int sync_free_mode = 2;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
   int fault_inject = 0;    // NSK_IOPT_FAULT_INJECT
   int use_win_spmv = 1;    // NSK_IOPT_WINDOW_SPMV
+  int tri_window = 0;      // NSK_IOPT_TRI_WINDOW
   DBuf<int> jrow_blk, jblk_blk;  // row runs of the fused (F | Bt) block row: CSR and blocked variants
   int jrow_nblk = 0, jblk_nblk = 0;
   bool jrow_ok = false, jblk_ok = false;
@@ -317,7 +318,10 @@ void H::setup(int type, int variant_, double alpha_) {
   tMp.sync_free = tS.sync_free = sync_free_mode >= 1;
   tF.sync_free = sync_free_mode == 2;
   tMp.win_fault = tS.win_fault = (fault_inject & 1) ? 1 : 0;
+  tMp.sf_fault = tS.sf_fault = (fault_inject & 1) != 0;
   tF.sf_fault = (fault_inject & 2) != 0;
+  if (tMp.use_window != (tri_window != 0)) { tMp.use_window = tri_window != 0; tMp_ok = false; }
+  if (tS.use_window != (tri_window != 0)) { tS.use_window = tri_window != 0; tS_ok = false; }
   // working-vector layout of the blocked velocity factor: colour-ordered whenever it runs single-launch (its
   // per-level kernels only know the caller's order).  The scalar factors always solve on colour-ordered vectors.
   const int f_layout = (x_layout_mode != 0 && sync_free_mode == 2) ? 1 : 0;
@@ -705,9 +709,11 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
     case NSK_IOPT_FAULT_INJECT:
       h->fault_inject = (int)v;
       h->tMp.win_fault = h->tS.win_fault = (h->fault_inject & 1) ? 1 : 0;
+      h->tMp.sf_fault = h->tS.sf_fault = (h->fault_inject & 1) != 0;
       h->tF.sf_fault = (h->fault_inject & 2) != 0;
       break;
     case NSK_IOPT_WINDOW_SPMV: h->use_win_spmv = v != 0.0; break;
+    case NSK_IOPT_TRI_WINDOW: h->tri_window = v != 0.0; break;
     case NSK_IOPT_TINY_BYTES: h->tF.tiny_bytes = h->tMp.tiny_bytes = h->tS.tiny_bytes = v; break;
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
     case NSK_OPT_VELOCITY_AMG: h->velocity_amg = v != 0.0; break;
@@ -1112,6 +1118,34 @@ int nsk_tri_apply(nsk_handle h, int which, const double *b, double *x) {
   p.put(xv);
   h->check_sync_free();
   return 0;
+  NSK_CATCH(h)
+}
+
+// diagnostics (nsk_internal.h): one apply of a scalar triangular preconditioner with in-kernel time stamps
+int nsk_debug_tri_trace(nsk_handle h, int which, int64_t *out16, int max_runs, int *grid) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  if (h->prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
+  TriSolve *T = which == NSK_TRI_VELOCITY ? &h->tF : h->tP;
+  if (!T->win_ready) return 0;
+  VecPool &p = which == NSK_TRI_VELOCITY ? h->pool_u : h->pool_p;
+  double *bv = p.get(true), *xv = p.get(true);
+  vec_set(h->s(), p.n, bv, 1.0);
+  T->apply(bv, xv);   // warm
+  DBuf<long long> dbg;
+  dbg.alloc((size_t)T->win_nruns * 16);
+  NSK_HIP(hipMemsetAsync(dbg.p, 0, sizeof(long long) * dbg.n, h->s()));
+  T->win_dbg = dbg.p;
+  T->apply(bv, xv);
+  T->win_dbg = nullptr;
+  const int n = std::min(max_runs, T->win_nruns);
+  NSK_HIP(hipMemcpyAsync(out16, dbg.p, sizeof(long long) * (size_t)n * 16, hipMemcpyDeviceToHost, h->s()));
+  h->ctx.sync();
+  p.put(bv);
+  p.put(xv);
+  if (grid) *grid = T->sync_free ? std::min(T->win_grid, T->win_nruns) : 0;
+  h->check_sync_free();
+  return T->win_nruns;
   NSK_CATCH(h)
 }
 

@@ -367,7 +367,7 @@ void Csr::build_win(hipStream_t s) {
   win_ok = false;
   if (n_rows <= 0 || nnz <= 0) return;
   WinFormat W;
-  if (!build_win_format(n_rows, h_rowptr.data(), h_col.data(), nullptr, nullptr, nullptr, kWinMaxLines, 0, W)) return;
+  if (!build_win_format(n_rows, h_rowptr.data(), h_col.data(), nullptr, nullptr, nullptr, kWinMaxLines, 0, 0, W)) return;
   win_nruns = (int)W.runs.size();
   win_slots = W.n_slots;
   win_bytes = W.bytes_per_apply();

@@ -130,6 +130,24 @@ void tri_lower_serial(hipStream_t s, const TriView &T, int kind, const int *lvl_
                       const double *rhs, double *y);
 void tri_upper_serial(hipStream_t s, const TriView &T, int kind, const int *lvl_ptr, const int *rows, int l0, int l1,
                       double *y, double *out);
+// Streamed level of a triangular solve on split factors: M = strict-lower or strict-upper CSR whose
+// ROWS are in the permuted (colour) order, one level = one contiguous run of rows covered by
+// workgroups [b0, b1) of rowblk, while COLUMN ids and the vector x stay in the caller's numbering
+// (i = perm[r]):
+//   lower: x[i] = (rhs[i] - sum) * (kind ? dinv[r] : 1)
+//   upper: x[i] = kind ? x[i] - sum*dinv[r] : (x[i] - sum)*dinv[r]
+struct TriHalf {
+  const int *rowptr;
+  const int *col;
+  const double *val;
+  const int4 *desc;  // per workgroup: {first row, end row, first nnz, end nnz} — one load instead of a chain
+};
+// permx = 1: w is an internal colour-ordered vector and M.col holds colour-order ids; the lower solve gathers
+// rhs through perm, the upper solve also scatters its result to out[perm[r]].
+// run_nnz: the non-zero cap the row runs in M.desc were built with (512, 1024 or 2048)
+void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx, int run_nnz,
+                      const double *dinv, const int *perm, const double *rhs, double *w, double *out);
+
 // 2x2 node-block streamed level of a triangular solve (velocity block): node rows (two adjacent DoF rows) in node-colour order,
 // 2x2 blocks towards other nodes, and per node row intra = {l10, u01, 1/d0, 1/d1} for its own diagonal block.
 //   lower ILU: y0 = b0 - s0 ; y1 = b1 - s1 - l10 y0            lower SGS: y0 = (b0 - s0)/d0 ; y1 = (b1 - s1 - l10 y0)/d1
@@ -153,6 +171,9 @@ void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra);
 // needs no separate flag or fence).  Producers are always in lower-indexed workgroups, which the dispatcher
 // starts first; every spin is bounded and raises *err instead of hanging.
 void vec_fill_sentinel(hipStream_t s, int n, double *y);
+void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int n_blocks, int lower, int kind, int run_nnz,
+                         int wrong_order /* test hook */, const double *dinv, const int *perm, const double *rhs,
+                         const double *own, double *w, int *err);
 void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int n_blocks, int lower, int kind, int permx,
                       int wrong_order /* test hook */, const double *intra, const int *permn, const double *rhs,
                       const double *own, double *w, double *out, int *err);
@@ -184,10 +205,14 @@ struct WinTriArgs {
   const double *rhs;    // caller's order
   double *Y, *X, *Xnext, *out;
   int *err;
+  long long *dbg = nullptr;   // diagnostics: 16 int64 per run of the list (nsk_internal.h: nsk_debug_tri_trace)
 };
 void tri_win_solve(hipStream_t s, const WinView &M, int i0, int i1, int grid, int kind, int reverse /* test hook */,
                    const WinTriArgs &a);
-int tri_win_max_resident_per_cu();   // occupancy of the kernel above (workgroups per CU)
+int tri_win_max_resident_per_cu();   // occupancy API's answer for the kernel above (workgroups per CU)
+// census launch of `grid` workgroups of that kernel: afterwards two_ints[1] == 0 iff they were all resident together
+// (two_ints must be zeroed before the launch)
+void tri_win_census(hipStream_t s, int grid, int kind, int *two_ints);
 
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,

@@ -317,6 +317,71 @@ __global__ __launch_bounds__(BLK) void spmv_blk_fused_kernel(BlkView A, const do
   if (have && lane == 0) *reinterpret_cast<double2 *>(y + 2 * (size_t)r) = make_double2(s0, s1);
 }
 
+// Streamed level of a triangular solve on split CSR halves (scalar factors): rows of the level are contiguous in the
+// permuted (colour) order, the solution vector and the column ids stay in the caller's numbering.
+// PERMX = 0: w is the caller-order vector x (i = perm[r]), column ids are caller-order ids.
+// PERMX = 1: w is an internal colour-ordered vector (i = r), column ids are colour-order ids; the lower
+//            solve gathers rhs through perm and the upper solve scatters the result to `out`.  A level
+//            then only touches the segments of the colours it depends on (fewer bytes per level), at
+//            the price of one cache line per gathered entry.
+template <int LOWER, int KIND, int PERMX, int NNZ>
+__global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int nb, const double *__restrict__ dinv,
+                                                         const int *__restrict__ perm,
+                                                         const double *__restrict__ rhs, double *__restrict__ w,
+                                                         double *__restrict__ out) {
+  __shared__ double prod[NNZ];
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the k-th
+  // contiguous eighth of the level's row runs.  Neighbouring rows then share one L2, and the same
+  // slice of x is touched by the same XCD level after level (speed only, never correctness).
+  const int per = (int)gridDim.x >> 3;  // the grid is padded to a multiple of 8
+  const int mapped = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (mapped >= nb) return;
+  const int4 d = M.desc[b0 + mapped];
+  const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
+  const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
+  const bool have = r < r1;
+  int jb = 0, je = 0, i = 0, ip = 0;
+  double own = 0.0, dv = 1.0;
+  if (have) {
+    jb = M.rowptr[r] - k0;
+    je = M.rowptr[r + 1] - k0;
+    ip = perm[r];
+    i = PERMX ? r : ip;
+    own = LOWER ? rhs[ip] : w[i];  // w[i] of this level's own rows is not written by anyone else
+    if (KIND == 1 || !LOWER) dv = dinv[r];
+  }
+  // the factor is streamed once per apply: non-temporal loads keep it from evicting the lines the
+  // gathers want to find in L2 again
+  {
+    constexpr int U = NNZ / BLK;  // staged: see stream_products
+    int c[U];
+    double v[U], g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      const bool ok = k < k1;
+      c[u] = ok ? __builtin_nontemporal_load(M.col + k) : 0;
+      v[u] = ok ? __builtin_nontemporal_load(M.val + k) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) g[u] = w[c[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      if (k < k1) prod[k - k0] = v[u] * g[u];
+    }
+  }
+  __syncthreads();
+  const double sum = row_sum_lds(prod, jb, je, lane);
+  if (have && lane == 0) {
+    double v;
+    if (LOWER) v = KIND == 0 ? (own - sum) : (own - sum) * dv;
+    else v = KIND == 0 ? (own - sum) * dv : own - sum * dv;
+    w[i] = v;
+    if (PERMX && !LOWER) out[ip] = v;
+  }
+}
+
 template <int LOWER, int KIND>
 __global__ __launch_bounds__(BLK) void tri_blk_kernel(TriBlk M, int b0, int nb, const double *__restrict__ intra,
                                                       const int *__restrict__ permn, const double *__restrict__ rhs,
@@ -415,6 +480,62 @@ __device__ __forceinline__ double sf_wait(const double *p, unsigned long long fi
     v = sf_load(p);
   }
   return __longlong_as_double((long long)v);
+}
+
+template <int LOWER, int KIND, int NNZ>
+__global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, int wrong_order,
+                                                            const double *__restrict__ dinv,
+                                                            const int *__restrict__ perm,
+                                                            const double *__restrict__ rhs,
+                                                            const double *__restrict__ ownv, double *w, int *err) {
+  __shared__ double prod[NNZ];
+  // M.desc is in DISPATCH order (TriSolve::sf_dispatch_order): colours in dependency order, so producers
+  // always sit in workgroups the dispatcher has started earlier; inside a colour (padded to a multiple of 8
+  // with empty runs) the runs are dealt so that XCD k works on the k-th eighth of every colour.
+  // wrong_order (test hook): walk the list backwards, i.e. consumers before their producers, to exercise
+  // the bounded-spin / fallback path
+  const int4 d = M.desc[wrong_order ? nb - 1 - (int)blockIdx.x : (int)blockIdx.x];
+  const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
+  if (r0 == r1) return;  // padding run
+  const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
+  const bool have = r < r1;
+  int jb = 0, je = 0, i = 0;
+  double own = 0.0, dv = 1.0;
+  if (have) {
+    jb = M.rowptr[r] - k0;
+    je = M.rowptr[r + 1] - k0;
+    i = perm[r];
+    own = LOWER ? rhs[i] : ownv[i];
+    if (KIND == 1 || !LOWER) dv = dinv[r];
+  }
+  {
+    constexpr int U = NNZ / BLK;
+    int c[U];
+    double v[U];
+    unsigned long long g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      const bool ok = k < k1;
+      c[u] = ok ? __builtin_nontemporal_load(M.col + k) : -1;
+      v[u] = ok ? __builtin_nontemporal_load(M.val + k) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) g[u] = c[u] >= 0 ? sf_peek(w + c[u]) : 0ull;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + (int)threadIdx.x + u * BLK;
+      if (k < k1) prod[k - k0] = v[u] * sf_wait(w + c[u], g[u], err);
+    }
+  }
+  __syncthreads();
+  const double sum = row_sum_lds(prod, jb, je, lane);
+  if (have && lane == 0) {
+    double x;
+    if (LOWER) x = KIND == 0 ? (own - sum) : (own - sum) * dv;
+    else x = KIND == 0 ? (own - sum) * dv : own - sum * dv;
+    sf_store(w + i, x);
+  }
 }
 
 // PERMX = 1: the working vectors (ownv, x) are in colour order (node r at 2 r) and M.col holds colour-order node
@@ -586,112 +707,234 @@ __global__ __launch_bounds__(BLK) void spmv_win_kernel(WinView M, const double *
   }
 }
 
-// Triangular solve, both halves in one run list (see nsk_kernels.h: tri_win_solve).  The matrix stream of the NEXT
-// run of this workgroup is issued before the row sums of the current one, so only the window copy (L2 hits) and
-// the LDS phases sit between two dependent runs.
-template <int KIND>
-__global__ __launch_bounds__(BLK) void tri_win_kernel(WinView M, int i0, int i1, int reverse, const double *__restrict__ dinv,
-                                                      const int *__restrict__ perm, const double *__restrict__ rhs,
-                                                      double *Y, double *X, double *__restrict__ Xnext,
-                                                      double *__restrict__ out, int *err) {
-  __shared__ double win[WL * 16];
-  __shared__ double prod[2 * WQ * BLK];
-  __shared__ int s_lines[WL];
-  constexpr int RGW = 4;
-  // reverse (test hook): walk the list backwards, i.e. consumers before their producers, to exercise the bounded
-  // spins and the fallback
-  auto at = [&](int k) { return reverse ? i1 - 1 - (k - i0) : k; };
-  int i = i0 + (int)blockIdx.x;
-  if (i >= i1) return;
-  int4 d0 = M.runs[2 * at(i)], d1 = M.runs[2 * at(i) + 1];
+constexpr int TWB = 2 * BLK;
+constexpr int RGW = 4;   // lanes per row in the row sums
+
+struct WinTriK {   // kernel arguments of the triangular window solve
+  WinView M;
+  int i0, i1, reverse;
+  const double *dinv;
+  const int *perm;
+  const double *rhs;
+  double *Y, *X, *Xnext, *out;
+  int *err;
+  long long *dbg;   // diagnostics (null in production): 16 time stamps / counters per run, see nsk_internal.h
+};
+__device__ __forceinline__ void win_stamp(const WinTriK &a, int run, int k) {
+  if (a.dbg) a.dbg[(size_t)run * 16 + k] = (long long)__builtin_amdgcn_s_memrealtime();
+}
+// reverse (test hook): walk the list backwards, i.e. consumers before their producers, to exercise the bounded
+// spins and the fallback
+__device__ __forceinline__ int win_at(const WinTriK &a, int k) { return a.reverse ? a.i1 - 1 - (k - a.i0) : k; }
+
+// stream role (waves 0-3): values and window positions of the NEXT run in registers, products into LDS
+__device__ __forceinline__ void tri_win_stream_role(const WinTriK &a, int t, const double *win, double *prod,
+                                                    const int *s_lines) {
+  const WinView &M = a.M;
+  int i = a.i0 + (int)blockIdx.x;
+  int4 d0 = M.runs[2 * win_at(a, i)], d1 = M.runs[2 * win_at(a, i) + 1];
   WinRegs R;
-  win_issue(M, d1.x, d1.y, R);
-  for (;;) {
-    const int r0 = d0.x, nrows = d0.y, l0 = d0.z, nl = d0.w, q2 = d1.y, roff0 = d1.z;
-    const bool upper = d1.w & 1;
-    double *W = upper ? X : Y;
-    if (nrows > 0) {   // (padding runs of the dispatch order are empty)
-      win_stage(M.lines, l0, nl, W, win, s_lines);
-      // row data of the first reduce pass: loaded here so that its latency hides behind the window copy
-      const int rho0 = (int)threadIdx.x / RGW;
-      int jb = 0, je = 0, ip = 0;
-      double dv = 1.0;
-      unsigned long long ownb = 0ull;
-      if (rho0 < nrows) {
-        const int r = r0 + rho0;
-        jb = M.roff[roff0 + rho0];
-        je = M.roff[roff0 + rho0 + 1];
-        ip = perm[r];
-        if (upper) ownb = sf_peek(Y + r); else ownb = (unsigned long long)__double_as_longlong(rhs[ip]);
-        if (KIND == 1 || upper) dv = dinv[r];
-      }
-      __syncthreads();
-      const int e0 = (int)threadIdx.x * 2 * q2, N = M.roff[roff0 + nrows];
+  for (bool first = true;; first = false) {
+    int4 n0 = d0, n1 = d1;
+    int inext = i;
+    if (!first) {
+      const int nrows = d0.y, q2 = d1.y;
+      double *W = (d1.w & 1) ? a.X : a.Y;
+      if (nrows > 0) {   // (padding runs of the dispatch order are empty)
+        if (t == 0) win_stamp(a, win_at(a, i), 0);
+        __syncthreads();   // A: the window of this run is in LDS
+        if (t == 0) win_stamp(a, win_at(a, i), 1);
+        const int e0 = t * 2 * q2, N = (d1.w >> 1) & 0xfff;   // entries of the run
+        bool missing = false;   // a window entry this thread needs still holds the sentinel
 #pragma unroll
-      for (int j = 0; j < WQ; ++j)
-        if (j < q2) {
-          const unsigned pa = R.c[j] & 0xffffu, pb = R.c[j] >> 16;
-          double xa = win[pa], xb = win[pb];
-          if (e0 + 2 * j < N && (unsigned long long)__double_as_longlong(xa) == kSentinel)
-            xa = sf_wait(W + (size_t)s_lines[pa >> 4] * 16 + (pa & 15u), kSentinel, err);
-          if (e0 + 2 * j + 1 < N && (unsigned long long)__double_as_longlong(xb) == kSentinel)
-            xb = sf_wait(W + (size_t)s_lines[pb >> 4] * 16 + (pb & 15u), kSentinel, err);
-          prod[e0 + 2 * j] = R.v[j].x * xa;
-          prod[e0 + 2 * j + 1] = R.v[j].y * xb;
+        for (int j = 0; j < WQ; ++j)
+          if (j < q2) {
+            const double xa = win[R.c[j] & 0xffffu], xb = win[R.c[j] >> 16];
+            missing |= (e0 + 2 * j < N && (unsigned long long)__double_as_longlong(xa) == kSentinel) ||
+                       (e0 + 2 * j + 1 < N && (unsigned long long)__double_as_longlong(xb) == kSentinel);
+            prod[e0 + 2 * j] = R.v[j].x * xa;
+            prod[e0 + 2 * j + 1] = R.v[j].y * xb;
+          }
+        if (a.dbg && missing) atomicAdd(reinterpret_cast<unsigned long long *>(a.dbg) + (size_t)win_at(a, i) * 16 + 8, 1ull);
+        if (missing) {   // rare: a producer's store had not landed when the window was copied — poll those entries
+          // (re-reads its slots from memory instead of keeping the register copy alive through the loop)
+          const unsigned short *pos16 = reinterpret_cast<const unsigned short *>(M.pos);
+#pragma unroll 1
+          for (int e = e0; e < min(N, e0 + 2 * q2); ++e) {
+            const size_t slot = 2 * ((size_t)d1.x + (size_t)((e - e0) >> 1) * BLK + (size_t)t) + (size_t)((e - e0) & 1);
+            const unsigned p = pos16[slot];
+            if ((unsigned long long)__double_as_longlong(win[p]) == kSentinel)
+              prod[e] = M.val[slot] * sf_wait(W + (size_t)s_lines[p >> 4] * 16 + (p & 15u), kSentinel, a.err);
+          }
         }
-      // prefetch: descriptor and matrix stream of this workgroup's next run
-      const int inext = i + (int)gridDim.x;
-      int4 n0 = make_int4(0, 0, 0, 0), n1 = n0;
-      if (inext < i1) {
-        n0 = M.runs[2 * at(inext)];
-        n1 = M.runs[2 * at(inext) + 1];
-        win_issue(M, n1.x, n1.y, R);
       }
-      __syncthreads();
-      for (int rho = rho0; rho < nrows; rho += BLK / RGW) {
-        const int lane = threadIdx.x % RGW, r = r0 + rho;
-        if (rho != rho0) {   // later passes (runs of short rows): load the row data now
-          jb = M.roff[roff0 + rho];
-          je = M.roff[roff0 + rho + 1];
-          ip = perm[r];
-          if (upper) ownb = sf_peek(Y + r); else ownb = (unsigned long long)__double_as_longlong(rhs[ip]);
-          if (KIND == 1 || upper) dv = dinv[r];
+      if (t == 0 && nrows > 0) win_stamp(a, win_at(a, i), 2);
+    }
+    if (!first && d0.y > 0) {
+      __syncthreads();   // B: the products of this run are in LDS
+      if (t == 0) win_stamp(a, win_at(a, i), 3);
+    }
+    if (!first) {
+      inext = i + (int)gridDim.x;
+      n0 = n1 = make_int4(0, 0, 0, 0);   // no next run: an empty one (its loads are all masked off)
+      if (inext < a.i1) { n0 = M.runs[2 * win_at(a, inext)]; n1 = M.runs[2 * win_at(a, inext) + 1]; }
+    }
+    // the (next) run's matrix stream: in flight during the whole step before it is used (issued behind barrier B so
+    // that the window role starts the row sums as early as possible)
+#pragma unroll
+    for (int j = 0; j < WQ; ++j) {
+      const bool ok = j < n1.y;   // uniform in the workgroup
+      const size_t pi = (size_t)n1.x + (size_t)(ok ? j : 0) * BLK + (size_t)t;
+      R.v[j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const dvec2 *>(M.val) + pi) : dvec2{0.0, 0.0};
+      R.c[j] = ok ? __builtin_nontemporal_load(M.pos + pi) : 0u;
+    }
+    i = inext;
+    d0 = n0;
+    d1 = n1;
+    if (i >= a.i1) break;
+  }
+}
+
+// window role (waves 4-7): window lines into LDS, then the row sums and the results
+template <int KIND>
+__device__ __forceinline__ void tri_win_window_role(const WinTriK &a, int t, double *win, const double *prod,
+                                                    int *s_lines) {
+  const WinView &M = a.M;
+  int i = a.i0 + (int)blockIdx.x;
+  int4 d0 = M.runs[2 * win_at(a, i)], d1 = M.runs[2 * win_at(a, i) + 1];
+  int ln[WLD];                   // line ids of this thread's 16-byte window chunks
+  int jb = 0, je = 0, ip = 0;    // row data of the first reduce pass (row t / RGW of the run)
+  double dv = 1.0;
+  for (bool first = true;; first = false) {
+    int4 n0 = d0, n1 = d1;
+    int inext = i;
+    const int cjb = jb, cje = je, cip = ip;
+    const double cdv = dv;
+    unsigned long long ownb = 0ull;
+    const int r0 = d0.x, nrows = d0.y, roff0 = d1.z;
+    const bool upper = d1.w & 1, work = !first && nrows > 0;
+    double *W = upper ? a.X : a.Y;
+    if (!first) {
+      if (work) {
+        if (t == 0) win_stamp(a, win_at(a, i), 4);
+        // window lines -> LDS by LDS-DMA (16 B per lane, a wave writes 1 KB of contiguous LDS per instruction: no
+        // staging registers); the row's own value rides along (lower: rhs through perm, upper: the lower result)
+        const int wbase = __builtin_amdgcn_readfirstlane(t & ~63);
+#pragma unroll
+        for (int u = 0; u < WLD; ++u)
+          if (ln[u] >= 0)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(W + (size_t)ln[u] * 16 + (size_t)((t + u * BLK) & 7) * 2),
+                (__attribute__((address_space(3))) void *)(win + 2 * (u * BLK + wbase)), 16, 0, 0);
+        if (t / RGW < nrows)
+          ownb = upper ? sf_peek(a.Y + r0 + t / RGW) : (unsigned long long)__double_as_longlong(a.rhs[cip]);
+#pragma unroll
+        for (int u = 0; u < WLD; ++u) {
+          const int k = t + u * BLK;
+          if (ln[u] >= 0 && (k & 7) == 0) s_lines[k >> 3] = ln[u];
+        }
+      }
+    }
+    if (work) {
+      if (t == 0) win_stamp(a, win_at(a, i), 5);
+      __syncthreads();   // A: the window is in LDS
+      if (t == 0) win_stamp(a, win_at(a, i), 6);
+    }
+    if (!first) {
+      inext = i + (int)gridDim.x;
+      n0 = n1 = make_int4(0, 0, 0, 0);
+      if (inext < a.i1) { n0 = M.runs[2 * win_at(a, inext)]; n1 = M.runs[2 * win_at(a, inext) + 1]; }
+    }
+    // line ids and row data of the (next) run, a step ahead — issued while the stream role multiplies
+#pragma unroll
+    for (int u = 0; u < WLD; ++u) {
+      const int k = t + u * BLK;
+      ln[u] = k < n0.w * 8 ? M.lines[n0.z + (k >> 3)] : -1;
+    }
+    jb = je = 0;
+    if (t / RGW < n0.y) {
+      jb = M.roff[n1.z + t / RGW];
+      je = M.roff[n1.z + t / RGW + 1];
+      ip = a.perm[n0.x + t / RGW];
+      if (KIND == 1 || (n1.w & 1)) dv = a.dinv[n0.x + t / RGW];
+    }
+    if (work) {
+      __syncthreads();   // B: the products are in LDS
+      for (int rho = t / RGW; rho < nrows; rho += BLK / RGW) {
+        const int lane = t % RGW, r = r0 + rho;
+        int qb = cjb, qe = cje, qi = cip;
+        double qd = cdv;
+        if (rho != t / RGW) {   // later passes (runs of short rows): load the row data now
+          qb = M.roff[roff0 + rho];
+          qe = M.roff[roff0 + rho + 1];
+          qi = a.perm[r];
+          ownb = upper ? sf_peek(a.Y + r) : (unsigned long long)__double_as_longlong(a.rhs[qi]);
+          if (KIND == 1 || upper) qd = a.dinv[r];
         }
         double sum = 0.0;
-        for (int k = jb + lane; k < je; k += RGW) sum += prod[k];
+#pragma unroll 4
+        for (int k = qb + lane; k < qe; k += RGW) sum += prod[k];
         sum = subwave_sum<RGW>(sum);
         if (lane == 0) {
           if (!upper) {
             const double own = __longlong_as_double((long long)ownb);
-            sf_store(Y + r, KIND == 0 ? (own - sum) : (own - sum) * dv);
+            sf_store(a.Y + r, KIND == 0 ? (own - sum) : (own - sum) * qd);
           } else {
-            const double own = sf_wait(Y + r, ownb, err);
-            const double v = KIND == 0 ? (own - sum) * dv : own - sum * dv;
-            sf_store(X + r, v);
-            out[ip] = v;
+            const double own = sf_wait(a.Y + r, ownb, a.err);
+            const double v = KIND == 0 ? (own - sum) * qd : own - sum * qd;
+            sf_store(a.X + r, v);
+            a.out[qi] = v;
             // every reader of Y[r] (lower runs of later colours next to r) has finished: their results fed the
             // X entries this row just consumed.  Leave the sentinel for the next call; same for its X buffer.
-            reinterpret_cast<unsigned long long *>(Y)[r] = kSentinel;
-            reinterpret_cast<unsigned long long *>(Xnext)[r] = kSentinel;
+            reinterpret_cast<unsigned long long *>(a.Y)[r] = kSentinel;
+            reinterpret_cast<unsigned long long *>(a.Xnext)[r] = kSentinel;
           }
         }
       }
-      i = inext;
-      d0 = n0;
-      d1 = n1;
-    } else {
-      i += (int)gridDim.x;
-      if (i < i1) {   // the matrix stream issued for the empty run is void: issue the next one
-        d0 = M.runs[2 * at(i)];
-        d1 = M.runs[2 * at(i) + 1];
-        win_issue(M, d1.x, d1.y, R);
-      }
+      if (t == 0) win_stamp(a, win_at(a, i), 7);
     }
-    if (i >= i1) break;
+    i = inext;
+    d0 = n0;
+    d1 = n1;
+    if (i >= a.i1) break;
   }
 }
 
-// ------------------------------------------------------------------ element-wise
+// Triangular solve, both halves in one run list (see nsk_kernels.h: tri_win_solve).
+// 512-thread workgroups with two roles, because a wavefront can only wait for its memory operations IN ORDER:
+//   waves 0-3 (stream role)  hold the matrix stream of the workgroup's NEXT run in registers — issued a whole step
+//                            ahead, one colour's worth of the factor is in flight chip-wide — multiply it with the
+//                            window and park the products in LDS;
+//   waves 4-7 (window role)  copy the run's window lines (the only loads that depend on other workgroups' results)
+//                            into LDS, then sum the rows and store the results.
+// Nothing the dependency chain waits for queues behind the bandwidth stream.  Two barriers per run; both roles walk
+// the same run sequence and execute the same number of barriers.
+// reverse == 2: CENSUS instead of a solve — every workgroup announces itself on err[0] and waits (bounded) until the
+// whole grid has: true iff all gridDim.x workgroups of THIS kernel (same registers, same LDS) are resident together,
+// which the occupancy API over-estimates at some SGPR counts (MI355X_MICROARCH.md, Residency).  err[1] = 1 on failure.
+template <int KIND>
+__global__ __launch_bounds__(TWB, 8) void tri_win_kernel(WinTriK a) {
+  __shared__ double win[WL * 16];
+  __shared__ double prod[2 * WQ * BLK];
+  __shared__ int s_lines[WL];
+  if (a.reverse == 2) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
+        if (++spins > (1 << 15)) { __hip_atomic_store(a.err + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    return;
+  }
+  if (a.i0 + (int)blockIdx.x >= a.i1) return;
+  const int t = (int)threadIdx.x & (BLK - 1);
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < BLK) tri_win_stream_role(a, t, win, prod, s_lines);
+  else tri_win_window_role<KIND>(a, t, win, prod, s_lines);
+}
+
+
 __global__ __launch_bounds__(BLK) void gather_or_zero_kernel(long n, const int *__restrict__ idx,
                                                             const double *__restrict__ x, double *__restrict__ y) {
   for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
@@ -1054,6 +1297,29 @@ void spmv_blk_fused22_21(hipStream_t s, const BlkView &A, const double *xao, con
     hipLaunchKernelGGL(spmv_blk_fused_kernel, dim3(nblk), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, rowblk, y);
 }
 
+void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx, int run_nnz,
+                      const double *dinv, const int *perm, const double *rhs, double *w, double *out) {
+  const int nb = b1 - b0;
+  if (nb <= 0) return;
+  const int grid = ((nb + 7) / 8) * 8;
+#define NSK_TS(L, K, P, N) hipLaunchKernelGGL((tri_stream_kernel<L, K, P, N>), dim3(grid), dim3(BLK), 0, s, M, b0, nb, dinv, perm, rhs, w, out)
+#define NSK_TSN(L, K, P)                                            \
+  do {                                                              \
+    if (run_nnz <= 512) NSK_TS(L, K, P, 512);                       \
+    else if (run_nnz <= 1024) NSK_TS(L, K, P, 1024);                \
+    else NSK_TS(L, K, P, 2048);                                     \
+  } while (0)
+  if (permx) {
+    if (lower) { if (kind == 0) NSK_TSN(1, 0, 1); else NSK_TSN(1, 1, 1); }
+    else { if (kind == 0) NSK_TSN(0, 0, 1); else NSK_TSN(0, 1, 1); }
+  } else {
+    if (lower) { if (kind == 0) NSK_TSN(1, 0, 0); else NSK_TSN(1, 1, 0); }
+    else { if (kind == 0) NSK_TSN(0, 0, 0); else NSK_TSN(0, 1, 0); }
+  }
+#undef NSK_TSN
+#undef NSK_TS
+}
+
 #define NSK_EW(n, ...)                                                                       \
   do {                                                                                       \
     if ((n) > 0) {                                                                           \
@@ -1118,6 +1384,22 @@ void vec_fill_sentinel(hipStream_t s, int n, double *y) {
   unsigned long long *p = reinterpret_cast<unsigned long long *>(y);
   NSK_EW(n, [=] __device__(int i) { p[i] = kSentinel; });
 }
+void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int kind, int run_nnz, int wrong_order,
+                         const double *dinv, const int *perm, const double *rhs, const double *own, double *w,
+                         int *err) {
+  if (nb <= 0) return;
+#define NSK_SF(L, K, N) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, dinv, perm, rhs, own, w, err)
+#define NSK_SFN(L, K)                                      \
+  do {                                                     \
+    if (run_nnz <= 512) NSK_SF(L, K, 512);                 \
+    else if (run_nnz <= 1024) NSK_SF(L, K, 1024);          \
+    else NSK_SF(L, K, 2048);                               \
+  } while (0)
+  if (lower) { if (kind == 0) NSK_SFN(1, 0); else NSK_SFN(1, 1); }
+  else { if (kind == 0) NSK_SFN(0, 0); else NSK_SFN(0, 1); }
+#undef NSK_SFN
+#undef NSK_SF
+}
 void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int nb, int lower, int kind, int permx, int wrong_order,
                       const double *intra, const int *permn, const double *rhs, const double *own, double *w, double *out,
                       int *err) {
@@ -1145,18 +1427,22 @@ void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, 
 }
 void tri_win_solve(hipStream_t s, const WinView &M, int i0, int i1, int grid, int kind, int reverse, const WinTriArgs &a) {
   if (i1 <= i0 || grid <= 0) return;
-  if (kind == 0)
-    hipLaunchKernelGGL((tri_win_kernel<0>), dim3(grid), dim3(BLK), 0, s, M, i0, i1, reverse, a.dinv, a.perm, a.rhs, a.Y, a.X, a.Xnext,
-                       a.out, a.err);
-  else
-    hipLaunchKernelGGL((tri_win_kernel<1>), dim3(grid), dim3(BLK), 0, s, M, i0, i1, reverse, a.dinv, a.perm, a.rhs, a.Y, a.X, a.Xnext,
-                       a.out, a.err);
+  const WinTriK k{M, i0, i1, reverse, a.dinv, a.perm, a.rhs, a.Y, a.X, a.Xnext, a.out, a.err, a.dbg};
+  if (kind == 0) hipLaunchKernelGGL((tri_win_kernel<0>), dim3(grid), dim3(TWB), 0, s, k);
+  else hipLaunchKernelGGL((tri_win_kernel<1>), dim3(grid), dim3(TWB), 0, s, k);
 }
 int tri_win_max_resident_per_cu() {
   int a = 0, b = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, tri_win_kernel<0>, BLK, 0) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, tri_win_kernel<1>, BLK, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, tri_win_kernel<0>, TWB, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, tri_win_kernel<1>, TWB, 0) != hipSuccess) return 0;
   return std::min(a, b);
+}
+void tri_win_census(hipStream_t s, int grid, int kind, int *two_ints) {
+  WinTriK k{};
+  k.reverse = 2;
+  k.err = two_ints;
+  if (kind == 0) hipLaunchKernelGGL((tri_win_kernel<0>), dim3(grid), dim3(TWB), 0, s, k);
+  else hipLaunchKernelGGL((tri_win_kernel<1>), dim3(grid), dim3(TWB), 0, s, k);
 }
 void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra) {
   const int n = n_nodes;

@@ -2,6 +2,7 @@
 #include "nsk_tri.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 namespace nsk {
@@ -260,6 +261,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
 
   hipStream_t s = ctx->stream;
   block2_ready = false;
+  stream_ready = false;
   if (!perm.empty() && block2) {
     // node rows in colour order; 2x2 blocks towards earlier (L) / later (U) colours, column ids = caller-order node ids
     const int nn = n / 2;
@@ -355,10 +357,71 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       block2_ready = true;
     }
   }
-  win_ready = false;
   if (!perm.empty() && !block2) {
-    // strict-lower / strict-upper CSR halves in colour order (rows AND columns: the solves work on colour-ordered
-    // vectors, so a colour only reads the segments of the colours it depends on), then the window format of both
+    // strict-lower / strict-upper CSR halves with every colour a contiguous run of rows
+    std::vector<int> lrp(n + 1, 0), urp(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+      lrp[i + 1] = lrp[i] + (pdiag[i] - prp[i]);
+      urp[i + 1] = urp[i] + (prp[i + 1] - pdiag[i] - 1);
+    }
+    nnzL = lrp[n];
+    nnzU = urp[n];
+    std::vector<int> lcol((size_t)nnzL), lsrc((size_t)nnzL), ucol((size_t)nnzU), usrc((size_t)nnzU);
+    // column ids go back to the caller's numbering, sorted, so that a row's gathers are runs of neighbours
+#pragma omp parallel
+    {
+      std::vector<std::pair<int, int>> buf;
+#pragma omp for schedule(static)
+      for (int i = 0; i < n; ++i) {
+        buf.clear();
+        for (int k = prp[i]; k < pdiag[i]; ++k) buf.emplace_back(perm[pcol[k]], k);
+        std::sort(buf.begin(), buf.end());
+        int w = lrp[i];
+        for (auto &e : buf) { lcol[w] = e.first; lsrc[w] = e.second; ++w; }
+        buf.clear();
+        for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k) buf.emplace_back(perm[pcol[k]], k);
+        std::sort(buf.begin(), buf.end());
+        w = urp[i];
+        for (auto &e : buf) { ucol[w] = e.first; usrc[w] = e.second; ++w; }
+      }
+    }
+    std::vector<int> cuts(hLp.begin() + 1, hLp.end());  // colour boundaries (levL = colour, rows ascending)
+    std::vector<int> lb, ub;
+    if (build_rowblocks(lrp.data(), nullptr, n, kStreamNnz, &cuts, lb) &&
+        build_rowblocks(urp.data(), nullptr, n, kStreamNnz, &cuts, ub)) {
+      auto first_block_of = [&](const std::vector<int> &blk, std::vector<int> &out) {
+        out.assign(n_colors + 1, 0);
+        size_t b = 0;
+        for (int c = 0; c <= n_colors; ++c) {
+          const int row = c < n_colors ? hLp[c] : n;
+          while (b + 1 < blk.size() && blk[b] < row) ++b;
+          out[c] = (int)b;
+        }
+      };
+      first_block_of(lb, LB);
+      first_block_of(ub, UB);
+      auto make_desc = [](const std::vector<int> &blk, const std::vector<int> &rp_) {
+        std::vector<int4> d(blk.size() - 1);
+        for (size_t b = 0; b + 1 < blk.size(); ++b) d[b] = make_int4(blk[b], blk[b + 1], rp_[blk[b]], rp_[blk[b + 1]]);
+        return d;
+      };
+      const std::vector<int4> ld = make_desc(lb, lrp), ud = make_desc(ub, urp);
+      const std::vector<int4> lsf = sf_dispatch_order(ld, LB, true), usf = sf_dispatch_order(ud, UB, false);
+      n_Lsf = (int)lsf.size();
+      n_Usf = (int)usf.size();
+      Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Ldesc.upload(ld, s); Lsf.upload(lsf, s);
+      Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Udesc.upload(ud, s); Usf.upload(usf, s);
+      Lval.alloc((size_t)nnzL);
+      Uval.alloc((size_t)nnzU);
+      dinv.alloc((size_t)n);
+      ctx->sync();
+      stream_ready = true;
+    }
+  }
+  win_ready = false;
+  if (!perm.empty() && !block2 && use_window) {
+    // study variant (NSK_IOPT_TRI_WINDOW): the same factor in the window format, colour-ordered working vectors,
+    // one persistent launch for both halves
     build_window_factor(prp, pcol, pdiag, hLp, pcolor);
   }
   rowptr.upload(prp, s);
@@ -379,6 +442,29 @@ void TriSolve::build_window_factor(const std::vector<int> &prp, const std::vecto
                                    const std::vector<int> &pdiag, const std::vector<int> &color_ptr,
                                    const std::vector<int> &pcolor) {
   hipStream_t s = ctx->stream;
+  // workgroups of the persistent launch: all of them must be resident together.  Start from the occupancy API's
+  // answer (at most 4 per CU: more do not help a stream that is one colour deep) and VERIFY it with a census launch
+  // of the same kernel, going down until a grid of that size has been seen resident as a whole.
+  int per_cu = std::min(tri_win_max_resident_per_cu(), 4);
+  {
+    DBuf<int> census;
+    census.alloc(2);
+    for (; per_cu > 0; --per_cu) {
+      int flags[2] = {0, 0};
+      bool ok = true;
+      for (int k = 0; k < 2 && ok; ++k) {
+        NSK_HIP(hipMemsetAsync(census.p, 0, 2 * sizeof(int), s));
+        tri_win_census(s, per_cu * ctx->n_cu, k, census.p);
+        NSK_HIP(hipMemcpyAsync(flags, census.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        ctx->sync();
+        ok = flags[1] == 0 && flags[0] == per_cu * ctx->n_cu;
+      }
+      if (ok) break;
+    }
+  }
+  if (per_cu <= 0) return;
+  win_grid = std::max(8, per_cu * ctx->n_cu / 8 * 8);
+
   std::vector<int> lrp(n + 1, 0), urp(n + 1, 0);
   for (int i = 0; i < n; ++i) {
     lrp[i + 1] = lrp[i] + (pdiag[i] - prp[i]);
@@ -394,10 +480,17 @@ void TriSolve::build_window_factor(const std::vector<int> &prp, const std::vecto
     w = urp[i];
     for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k) { ucol[w] = pcol[k]; usrc[w] = k; ++w; }
   }
+  // POSITION-PROPORTIONAL schedule.  The rows of a colour are in lattice order, and so are its runs (each as full
+  // as the caps allow).  Run j of the n_c runs of colour c goes to workgroup floor(j G / n_c) of the persistent
+  // launch: workgroup p then works on about the same patch of the mesh colour after colour, what it waits for was
+  // produced by itself and by the workgroups of the neighbouring patches one colour earlier, and patches far apart
+  // never wait for each other.  The list holds, per colour, ceil(n_c / G) rounds of G slots (empty where a
+  // workgroup has fewer runs than the round count).
+  const int G = win_grid;
   std::vector<int> cuts(color_ptr.begin() + 1, color_ptr.end());   // colour boundaries
   WinFormat WLo, WUp;
-  if (!build_win_format(n, lrp.data(), lcol.data(), lsrc.data(), &cuts, pcolor.data(), kWinMaxLines, 0, WLo) ||
-      !build_win_format(n, urp.data(), ucol.data(), usrc.data(), &cuts, pcolor.data(), kWinMaxLines, 1, WUp))
+  if (!build_win_format(n, lrp.data(), lcol.data(), lsrc.data(), &cuts, pcolor.data(), kWinMaxLines, 0, 0, WLo) ||
+      !build_win_format(n, urp.data(), ucol.data(), usrc.data(), &cuts, pcolor.data(), kWinMaxLines, 1, 0, WUp))
     return;   // a row exceeds the window: the level-scheduled CSR kernels serve this factor
   // one run list in dispatch order; lower and upper runs index the same value / position arrays (upper shifted)
   const int64_t pair_shift = WLo.n_slots / 2;
@@ -405,26 +498,32 @@ void TriSolve::build_window_factor(const std::vector<int> &prp, const std::vecto
   std::vector<WinRun> list;
   win_level.assign(1, 0);
   auto deal = [&](const WinFormat &W, int c, bool upper) {
-    // runs of colour c are contiguous in W.runs (built in row order with cuts at the colour boundaries)
-    size_t b0 = 0, b1 = 0;
-    {
-      auto lo = std::lower_bound(W.runs.begin(), W.runs.end(), color_ptr[c], [](const WinRun &R, int r) { return R.r0 < r; });
-      auto hi = std::lower_bound(W.runs.begin(), W.runs.end(), color_ptr[c + 1], [](const WinRun &R, int r) { return R.r0 < r; });
-      b0 = (size_t)(lo - W.runs.begin());
-      b1 = (size_t)(hi - W.runs.begin());
+    // runs of colour c are contiguous in W.runs (built in row order, never crossing a colour boundary)
+    const int b = color_ptr[c], e = color_ptr[c + 1];
+    auto lo = std::lower_bound(W.runs.begin(), W.runs.end(), b, [](const WinRun &R, int r) { return R.r0 < r; });
+    auto hi = std::lower_bound(W.runs.begin(), W.runs.end(), e, [](const WinRun &R, int r) { return R.r0 < r; });
+    const int64_t nc = hi - lo;
+    std::vector<std::vector<const WinRun *>> chunk((size_t)G);
+    int depth = 0;
+    for (int64_t j = 0; j < nc; ++j) {
+      const int p = (int)(j * G / nc);
+      chunk[(size_t)p].push_back(&*(lo + j));
+      depth = std::max(depth, (int)chunk[(size_t)p].size());
     }
-    const int nb = (int)(b1 - b0), per = (nb + 7) / 8;
-    for (int p = 0; p < 8 * per; ++p) {
-      const int logical = (p & 7) * per + (p >> 3);
-      WinRun R{};
-      if (logical < nb) {
-        R = W.runs[b0 + (size_t)logical];
-        if (upper) { R.p0 += (int)pair_shift; R.l0 += line_shift; R.roff0 += roff_shift; }
+    const int per = G / 8;
+    for (int d = 0; d < depth; ++d)
+      for (int slot = 0; slot < G; ++slot) {
+        const int p = (slot & 7) * per + (slot >> 3);   // XCD k (= slot % 8) owns the k-th eighth of the chunks
+        WinRun R{};
+        if (d < (int)chunk[(size_t)p].size()) {
+          R = *chunk[(size_t)p][(size_t)d];
+          if (upper) { R.p0 += (int)pair_shift; R.l0 += line_shift; R.roff0 += roff_shift; }
+        }
+        R.flags = (R.flags & ~1) | (upper ? 1 : 0);   // (an empty slot has no entries: bits 1-12 are 0)
+        list.push_back(R);
       }
-      R.flags = (R.flags & ~1) | (upper ? 1 : 0);
-      list.push_back(R);
-    }
     win_level.push_back((int)list.size());
+    if (getenv("NSK_TRACE_ANALYZE")) fprintf(stderr, "[nsk] %s colour %d: %d runs, depth %d\n", upper ? "U" : "L", c, (int)(hi - lo), depth);
   };
   for (int c = 0; c < n_colors; ++c) deal(WLo, c, false);
   for (int c = n_colors - 1; c >= 0; --c) deal(WUp, c, true);
@@ -445,19 +544,18 @@ void TriSolve::build_window_factor(const std::vector<int> &prp, const std::vecto
   win_y.alloc(nw);
   win_x0.alloc(nw);
   win_x1.alloc(nw);
-  dinv.alloc((size_t)n);
-  // workgroups of the persistent launch: all of them must be resident together
-  const int per_cu = std::min(tri_win_max_resident_per_cu(), 4);
-  win_grid = std::max(8, per_cu * ctx->n_cu / 8 * 8);
+  if (dinv.n != (size_t)n) dinv.alloc((size_t)n);
   win_dirty = true;
   win_parity = 0;
   ctx->sync();
-  win_ready = per_cu > 0;
+  win_ready = true;
 }
 
 double TriSolve::format_bytes() const {
   if (win_ready)   // window stream + per row: perm, rhs, dinv, Y (store, load, reset), X (store), Xnext (reset), result
     return win_bytes + 68.0 * (double)n;
+  if (stream_ready)   // CSR halves + per run: descriptor; per row: rowptr x2, perm x2, rhs, dinv, y (store + load), x (fill + store)
+    return 12.0 * (double)(nnzL + nnzU) + 16.0 * (double)(n_Lsf + n_Usf) + (8.0 + 8.0 + 8.0 + 8.0 + 16.0 + 16.0 + 16.0) * (double)n;
   if (block2_ready)   // 2x2 blocks with one int32 block column + per node row: descriptor share, intra, rhs, y, x
     return 36.0 * (double)(nnzL + nnzU) / 4.0 + 8.0 * (double)(n / 2) + (32.0 + 4.0 + 48.0) * (double)(n / 2);
   return (double)apply_bytes();
@@ -478,11 +576,13 @@ void TriSolve::numeric(const double *a_val_dev) {
     vec_gather(s, 2 * n, intra_src.p, val.p, intra.p);   // per node: l10, u01, d0, d1
     invert_node_diagonals(s, n / 2, intra.p);            // d0, d1 -> 1/d0, 1/d1
   }
-  if (win_ready) {
-    vec_gather_or_zero(s, (long)win_slots, win_src.p, val.p, win_val.p);
+  if (stream_ready) {
+    vec_gather(s, (int)nnzL, Lsrc.p, val.p, Lval.p);
+    vec_gather(s, (int)nnzU, Usrc.p, val.p, Uval.p);
     vec_gather(s, n, diag.p, val.p, dinv.p);
     vec_recip(s, n, dinv.p, dinv.p);
   }
+  if (win_ready) vec_gather_or_zero(s, (long)win_slots, win_src.p, val.p, win_val.p);
 }
 
 void TriSolve::apply(const double *b, double *x) {
@@ -504,7 +604,7 @@ void TriSolve::apply(const double *b, double *x) {
     }
     const WinView M{win_runs.p, win_lines.p, win_roff.p, reinterpret_cast<const unsigned *>(win_pos.p), win_val.p};
     const WinTriArgs a{dinv.p, d_perm.p, b, win_y.p, win_parity ? win_x1.p : win_x0.p, win_parity ? win_x0.p : win_x1.p,
-                       x, sf_err.p};
+                       x, sf_err.p, win_dbg};
     if (sync_free) {
       // ONE persistent launch for both halves; all its workgroups are resident together, so a wait never depends
       // on a workgroup that has not started
@@ -514,6 +614,30 @@ void TriSolve::apply(const double *b, double *x) {
         tri_win_solve(s, M, win_level[l], win_level[l + 1], win_level[l + 1] - win_level[l], kind, 0, a);
     }
     win_parity ^= 1;
+    ++ctx->st.tri_applies;
+    ctx->st.tri_bytes += (double)apply_bytes();
+    return;
+  }
+  if (sync_free && use_stream && !tiny && stream_ready) {
+    // scalar factor: lower half into y (pre-filled with the sentinel), upper half into x; each half is ONE launch
+    if (!sf_err.p) {
+      sf_err.alloc(1);
+      NSK_HIP(hipMemsetAsync(sf_err.p, 0, sizeof(int), s));
+    }
+    const TriHalf L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
+    vec_fill_sentinel(s, n, y.p);
+    tri_stream_syncfree(s, L, n_Lsf, 1, kind, kStreamNnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, sf_err.p);
+    vec_fill_sentinel(s, n, x);
+    tri_stream_syncfree(s, U, n_Usf, 0, kind, kStreamNnz, sf_fault ? 1 : 0, dinv.p, d_perm.p, nullptr, y.p, x, sf_err.p);
+    ++ctx->st.tri_applies;
+    ctx->st.tri_bytes += (double)apply_bytes();
+    return;
+  }
+  if (stream_ready && use_stream && !tiny) {
+    // x doubles as the intermediate vector: rows not yet solved hold L^-1 b, solved rows hold the result
+    const TriHalf L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
+    for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, 0, kStreamNnz, dinv.p, d_perm.p, b, x, nullptr);
+    for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, 0, kStreamNnz, dinv.p, d_perm.p, nullptr, x, nullptr);
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
     return;

@@ -44,10 +44,11 @@ struct TriSolve {
   std::vector<Step> schedL, schedU;
 
   // split factors for the streamed kernels (multicolour ordering: one colour = one contiguous level)
-  bool use_stream = true;
+  bool use_stream = true, stream_ready = false;
+  bool use_window = false;    // NSK_IOPT_TRI_WINDOW: scalar factors on the window format (study variant)
   double tiny_bytes = 4.0e6;  // factors below this size take the single-workgroup path (NSK_IOPT_TINY_BYTES)
   bool sync_free = false;  // one launch per half with in-kernel producer/consumer hand-off (see nsk_kernels.h)
-  bool sf_fault = false;   // test hook (blocked factor): wrong workgroup order in the upper half
+  bool sf_fault = false;   // test hook: wrong workgroup order in the upper half of the single-launch solves
   DBuf<double> xc;         // colour-ordered result vector of the upper half (x_layout = 1, blocked factor)
   DBuf<int> sf_err;        // raised by a bounded spin that ran out
   int x_layout = 0;  // blocked factor: 0 solve in the caller's (lattice) order; 1: internal colour-ordered vector
@@ -70,6 +71,7 @@ struct TriSolve {
   DBuf<int> win_lines, win_src;
   DBuf<unsigned short> win_roff, win_pos;
   DBuf<double> win_val, win_y, win_x0, win_x1;
+  long long *win_dbg = nullptr;   // diagnostics buffer of the next apply (16 int64 per run), see nsk_debug_tri_trace
   // 2x2 node-block variant (velocity block): node rows in node-colour order, blocks in L*/U* above,
   // per node row {l10, u01, 1/d0, 1/d1} in `intra`
   bool block2_ready = false;

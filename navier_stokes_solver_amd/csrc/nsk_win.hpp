@@ -33,7 +33,7 @@ struct WinRun {      // 8 ints per run, read by the kernels as two int4
   int p0, q2;        // first pair and pairs per thread: entry e of the run lives in thread t = e / (2 q2) as its
                      // i = e % (2 q2)-th entry, in slot 2 * (p0 + (i / 2) * 256 + t) + i % 2
   int roff0;         // roff[roff0 + k], k = 0..nrows: entry offsets of the run's rows inside the run
-  int flags;         // bit 0: upper half (triangular solves); bits 8..: colour / level of the rows
+  int flags;         // bit 0: upper half (triangular solves); bits 1-12: entries of the run; bits 16..: colour / level
 };
 
 struct WinFormat {
@@ -52,10 +52,13 @@ struct WinFormat {
 
 // Build the format for rows [0, n) given as CSR (rp, col; srcpos may be null = identity).
 //   cuts          ascending row ids no run may cross (may be null)
+//   balanced      1: the rows between two cuts (a CHUNK) become as few runs as the caps allow, of about equal size (a
+//                 workgroup that owns a chunk solves its runs back to back, so the longest chunk sets the pace);
+//                 0: greedy, every run as long as the caps allow
 //   level_of_row  stored in the runs' flags (may be null)
 // Returns false when a single row touches more than max_lines lines or holds more than kWinRunNnz entries.
 bool build_win_format(int n, const int *rp, const int *col, const int *srcpos, const std::vector<int> *cuts,
-                      const int *level_of_row, int max_lines, int flags, WinFormat &out);
+                      const int *level_of_row, int max_lines, int flags, int balanced, WinFormat &out);
 
 // Append `b` to `a`: used to put the lower and the upper half of a triangular factor into one run list.
 void win_append(WinFormat &a, const WinFormat &b);

@@ -26,7 +26,7 @@ void *nsk_host_win_create(int n, const int32_t *rp, const int32_t *col, int orde
   if (max_lines <= 0) max_lines = kWinMaxLines;
   bool ok;
   if (part == 0) {
-    ok = build_win_format(n, rp, col, nullptr, nullptr, nullptr, max_lines, 0, H->W);
+    ok = build_win_format(n, rp, col, nullptr, nullptr, nullptr, max_lines, 0, 0, H->W);
   } else {
     std::vector<int> color((size_t)n, 0), cuts;
     if (ordering == ORDER_MULTICOLOR) {
@@ -55,7 +55,7 @@ void *nsk_host_win_create(int n, const int32_t *rp, const int32_t *col, int orde
       hrp[(size_t)i + 1] = (int)hcol.size();
     }
     ok = build_win_format(n, hrp.data(), hcol.data(), hsrc.data(), cuts.empty() ? nullptr : &cuts,
-                          ordering == ORDER_MULTICOLOR ? pcolor.data() : nullptr, max_lines, part == 2 ? 1 : 0, H->W);
+                          ordering == ORDER_MULTICOLOR ? pcolor.data() : nullptr, max_lines, part == 2 ? 1 : 0, 0, H->W);
   }
   if (!ok) { delete H; return nullptr; }
   return H;

@@ -79,8 +79,8 @@ def test_single_launch_and_per_level_pressure_solves_agree(big):
 
 @pytest.mark.parametrize("which", [1, 2])
 def test_sync_free_timeout_falls_back(big, which):
-    """Fault injection on the DEFAULT kernels (1: the persistent window solve of ILU(S) walks its run list backwards,
-    2: the upper half of the blocked ILU(F) solve does): consumers wait for producers that cannot run yet.  The bounded
+    """Fault injection on the DEFAULT kernels (1: the upper half of the single-launch ILU(S) solve walks its run list
+    backwards, 2: the upper half of the blocked ILU(F) solve does): consumers wait for producers that cannot run yet.  The bounded
     spins must give up (no hang) and nsk_solve_resident — the path of bench.py and of both CLI drivers — must redo the
     solve with one launch per colour by itself and return the same result as an undisturbed solve."""
     import time

@@ -45,6 +45,7 @@ def test_window_format_decodes_to_the_csr_it_was_built_from(name):
         assert np.array_equal(src, np.arange(A.nnz))                                    # every entry once, in CSR order
         assert np.array_equal(cols, A.indices) and np.array_equal(rows, np.repeat(np.arange(A.shape[0]), np.diff(A.indptr)))
         assert (w.runs[:, 3] <= 160).all() and (w.runs[:, 5] <= 4).all() and (w.runs[:, 1] <= 256).all()
+        assert np.array_equal((w.runs[:, 7] >> 1) & 0xfff, [w.roff[r[6] + r[1]] for r in w.runs])   # entries per run
         x = rng_vec(A.shape[1], 3)
         ref = A @ x
         assert np.abs(_emulate_pass(w, A.data, x) - ref).max() <= 1e-13 * np.abs(ref).max()
@@ -70,7 +71,7 @@ def test_window_format_of_triangular_halves(part, ordering):
     assert np.abs(got.data - T.data).max() == 0.0
     if ordering:
         assert 20 <= w.n_colors <= 40
-        level = w.runs[:, 7] >> 8
+        level = w.runs[:, 7] >> 16
         first_row_of_level = {}
         for (r0, nrows, *_), lv in zip(w.runs, level):
             first_row_of_level.setdefault(lv, r0)
