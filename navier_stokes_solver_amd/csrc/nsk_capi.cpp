@@ -85,7 +85,7 @@ struct nsk_handle_s {
   int x_layout_mode = 2;   // NSK_IOPT_TRI_X_LAYOUT
   int sync_free_mode = 2;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
   int fault_inject = 0;    // NSK_IOPT_FAULT_INJECT
-  int use_win_spmv = 1;    // NSK_IOPT_WINDOW_SPMV
+  int use_win_spmv = 0;    // NSK_IOPT_WINDOW_SPMV
   int tri_window = 0;      // NSK_IOPT_TRI_WINDOW
   DBuf<int> jrow_blk, jblk_blk;  // row runs of the fused (F | Bt) block row: CSR and blocked variants
   int jrow_nblk = 0, jblk_nblk = 0;
@@ -239,6 +239,7 @@ struct nsk_handle_s {
         if (ei) {
           NSK_HIP(hipMemsetAsync(T->sf_err.p, 0, sizeof(int), s()));
           T->win_dirty = true;   // the working vectors of the abandoned solve are garbage
+          T->sf_armed = false;
         }
         e |= ei;
       }
@@ -307,7 +308,7 @@ void H::schur_symbolic() {
   S.lpr = pick_lpr(S.nnz, S.n_rows);
   S.present = true;
   S.build_stream_plan(s());
-  S.build_win(s());
+  if (use_win_spmv) S.build_win(s());
   ctx.sync();
   s_symbolic = true;
 }
@@ -669,7 +670,7 @@ int nsk_set_block_csr(nsk_handle h, int b, int n_rows, int n_cols, const int32_t
   if (b == NSK_BLK_F) A.build_blocked(2, 2, h->s());
   if (b == NSK_BLK_BT) A.build_blocked(2, 1, h->s());
   if (b == NSK_BLK_B) A.build_blocked(1, 2, h->s());
-  if (b == NSK_BLK_MP) A.build_win(h->s());
+  if (b == NSK_BLK_MP && h->use_win_spmv) A.build_win(h->s());
   h->ctx.sync();
   if (b == NSK_BLK_F || b == NSK_BLK_BT) { h->jrow_ok = h->jblk_ok = false; h->jrow_nblk = h->jblk_nblk = 0; }
   // a new pattern invalidates cached symbolic data
@@ -712,7 +713,13 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
       h->tMp.sf_fault = h->tS.sf_fault = (h->fault_inject & 1) != 0;
       h->tF.sf_fault = (h->fault_inject & 2) != 0;
       break;
-    case NSK_IOPT_WINDOW_SPMV: h->use_win_spmv = v != 0.0; break;
+    case NSK_IOPT_WINDOW_SPMV:   // set before the blocks are handed over (the window copy is built with the block)
+      h->use_win_spmv = v != 0.0;
+      if (h->use_win_spmv) {
+        if (h->blk[NSK_BLK_MP].present && !h->blk[NSK_BLK_MP].win_ok) { h->blk[NSK_BLK_MP].build_win(h->s()); h->ctx.sync(); }
+        if (h->blk[NSK_BLK_S].present && !h->blk[NSK_BLK_S].win_ok) { h->blk[NSK_BLK_S].build_win(h->s()); h->ctx.sync(); }
+      }
+      break;
     case NSK_IOPT_TRI_WINDOW: h->tri_window = v != 0.0; break;
     case NSK_IOPT_TINY_BYTES: h->tF.tiny_bytes = h->tMp.tiny_bytes = h->tS.tiny_bytes = v; break;
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;

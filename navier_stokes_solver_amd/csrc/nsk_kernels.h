@@ -173,10 +173,11 @@ void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra);
 void vec_fill_sentinel(hipStream_t s, int n, double *y);
 void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int n_blocks, int lower, int kind, int run_nnz,
                          int wrong_order /* test hook */, const double *dinv, const int *perm, const double *rhs,
-                         const double *own, double *w, int *err);
+                         const double *own, double *w, double *reset /* gets the sentinel at the rows' positions */,
+                         int *err);
 void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int n_blocks, int lower, int kind, int permx,
                       int wrong_order /* test hook */, const double *intra, const int *permn, const double *rhs,
-                      const double *own, double *w, double *out, int *err);
+                      const double *own, double *w, double *out, double *reset, int *err);
 
 // ---- window format (nsk_win.hpp): LDS-staged column tiles, 16-bit window positions, transposed value stream ----
 struct WinView {

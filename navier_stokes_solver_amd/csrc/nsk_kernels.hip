@@ -487,7 +487,7 @@ __global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, i
                                                             const double *__restrict__ dinv,
                                                             const int *__restrict__ perm,
                                                             const double *__restrict__ rhs,
-                                                            const double *__restrict__ ownv, double *w, int *err) {
+                                                            const double *ownv, double *w, double *reset, int *err) {
   __shared__ double prod[NNZ];
   // M.desc is in DISPATCH order (TriSolve::sf_dispatch_order): colours in dependency order, so producers
   // always sit in workgroups the dispatcher has started earlier; inside a colour (padded to a multiple of 8
@@ -535,6 +535,10 @@ __global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, i
     if (LOWER) x = KIND == 0 ? (own - sum) : (own - sum) * dv;
     else x = KIND == 0 ? (own - sum) * dv : own - sum * dv;
     sf_store(w + i, x);
+    // leave the sentinel where the NEXT launch expects it (no separate fill launches): the lower half arms the
+    // upper half's result vector, the upper half re-arms the lower result it has just consumed (every other reader
+    // of that entry ran in the lower launch, which has completed)
+    reinterpret_cast<unsigned long long *>(reset)[i] = kSentinel;
   }
 }
 
@@ -546,8 +550,8 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int w
                                                          const double *__restrict__ intra,
                                                          const int *__restrict__ permn,
                                                          const double *__restrict__ rhs,
-                                                         const double *__restrict__ ownv, double *x,
-                                                         double *__restrict__ out, int *err) {
+                                                         const double *ownv, double *x,
+                                                         double *__restrict__ out, double *reset, int *err) {
   __shared__ double p0[kBlkMax];
   __shared__ double p1[kBlkMax];
   // M.desc is in DISPATCH order (TriSolve::sf_dispatch_order): colours in dependency order, so producers sit in
@@ -619,6 +623,9 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int w
     if (PERMX && !LOWER) *reinterpret_cast<double2 *>(out + 2 * (size_t)permn[r]) = make_double2(v0, v1);
     sf_store(x + i, v0);
     sf_store(x + i + 1, v1);
+    // arm the vector of the next launch (see tri_stream_sf_kernel)
+    reinterpret_cast<unsigned long long *>(reset)[i] = kSentinel;
+    reinterpret_cast<unsigned long long *>(reset)[i + 1] = kSentinel;
   }
 }
 
@@ -1386,9 +1393,9 @@ void vec_fill_sentinel(hipStream_t s, int n, double *y) {
 }
 void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int kind, int run_nnz, int wrong_order,
                          const double *dinv, const int *perm, const double *rhs, const double *own, double *w,
-                         int *err) {
+                         double *reset, int *err) {
   if (nb <= 0) return;
-#define NSK_SF(L, K, N) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, dinv, perm, rhs, own, w, err)
+#define NSK_SF(L, K, N) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, dinv, perm, rhs, own, w, reset, err)
 #define NSK_SFN(L, K)                                      \
   do {                                                     \
     if (run_nnz <= 512) NSK_SF(L, K, 512);                 \
@@ -1402,9 +1409,9 @@ void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int
 }
 void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int nb, int lower, int kind, int permx, int wrong_order,
                       const double *intra, const int *permn, const double *rhs, const double *own, double *w, double *out,
-                      int *err) {
+                      double *reset, int *err) {
   if (nb <= 0) return;
-#define NSK_SB(L, K, P) hipLaunchKernelGGL((tri_blk_sf_kernel<L, K, P>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, intra, permn, rhs, own, w, out, err)
+#define NSK_SB(L, K, P) hipLaunchKernelGGL((tri_blk_sf_kernel<L, K, P>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, intra, permn, rhs, own, w, out, reset, err)
   if (permx) {
     if (lower) { if (kind == 0) NSK_SB(1, 0, 1); else NSK_SB(1, 1, 1); }
     else { if (kind == 0) NSK_SB(0, 0, 1); else NSK_SB(0, 1, 1); }

@@ -262,6 +262,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   hipStream_t s = ctx->stream;
   block2_ready = false;
   stream_ready = false;
+  sf_armed = false;
   if (!perm.empty() && block2) {
     // node rows in colour order; 2x2 blocks towards earlier (L) / later (U) colours, column ids = caller-order node ids
     const int nn = n / 2;
@@ -590,6 +591,8 @@ void TriSolve::apply(const double *b, double *x) {
   // Tiny factors (a few MB: they sit in one XCD's L2) are latency-bound on the ~5 us per level launch:
   // one 1024-thread workgroup walking all levels with __syncthreads in between is faster there.
   const bool tiny = (double)nnz * 12.0 < tiny_bytes && !schedL.empty();
+  // y stays armed with the sentinel only while consecutive applies go through the single-launch CSR kernels
+  if (!(sync_free && use_stream && !tiny && (stream_ready || block2_ready) && !(win_ready && !block2_ready))) sf_armed = false;
   if (win_ready && use_stream && !tiny) {
     // scalar multicolour factor in the window format, colour-ordered working vectors (see nsk_kernels.h: tri_win_solve)
     if (!sf_err.p) {
@@ -625,10 +628,10 @@ void TriSolve::apply(const double *b, double *x) {
       NSK_HIP(hipMemsetAsync(sf_err.p, 0, sizeof(int), s));
     }
     const TriHalf L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
-    vec_fill_sentinel(s, n, y.p);
-    tri_stream_syncfree(s, L, n_Lsf, 1, kind, kStreamNnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, sf_err.p);
-    vec_fill_sentinel(s, n, x);
-    tri_stream_syncfree(s, U, n_Usf, 0, kind, kStreamNnz, sf_fault ? 1 : 0, dinv.p, d_perm.p, nullptr, y.p, x, sf_err.p);
+    // the lower half arms x for the upper half, the upper half re-arms y for the next call: no fill launches
+    if (!sf_armed) { vec_fill_sentinel(s, n, y.p); sf_armed = true; }
+    tri_stream_syncfree(s, L, n_Lsf, 1, kind, kStreamNnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, x, sf_err.p);
+    tri_stream_syncfree(s, U, n_Usf, 0, kind, kStreamNnz, sf_fault ? 1 : 0, dinv.p, d_perm.p, nullptr, y.p, x, y.p, sf_err.p);
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
     return;
@@ -647,17 +650,17 @@ void TriSolve::apply(const double *b, double *x) {
       sf_err.alloc(1);
       NSK_HIP(hipMemsetAsync(sf_err.p, 0, sizeof(int), s));
     }
-    // lower half into y (pre-filled with the sentinel), upper half into x; each half is ONE launch
-    vec_fill_sentinel(s, n, y.p);
+    // lower half into y, upper half into x (xc); each half is ONE launch.  The lower half arms the upper half's
+    // vector with the sentinel, the upper half re-arms y for the next call: no fill launches
+    if (!sf_armed) { vec_fill_sentinel(s, n, y.p); sf_armed = true; }
     const TriBlk L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
-    tri_blk_syncfree(s, L, n_Lsf, 1, kind, x_layout, 0, intra.p, permn.p, b, nullptr, y.p, nullptr, sf_err.p);
     if (x_layout) {  // colour-ordered working vectors y, xc; the upper half also writes the caller-order result
       if (xc.n != (size_t)n + 1) xc.alloc((size_t)n + 1);
-      vec_fill_sentinel(s, n, xc.p);
-      tri_blk_syncfree(s, U, n_Usf, 0, kind, 1, sf_fault ? 1 : 0, intra.p, permn.p, nullptr, y.p, xc.p, x, sf_err.p);
+      tri_blk_syncfree(s, L, n_Lsf, 1, kind, 1, 0, intra.p, permn.p, b, nullptr, y.p, nullptr, xc.p, sf_err.p);
+      tri_blk_syncfree(s, U, n_Usf, 0, kind, 1, sf_fault ? 1 : 0, intra.p, permn.p, nullptr, y.p, xc.p, x, y.p, sf_err.p);
     } else {
-      vec_fill_sentinel(s, n, x);
-      tri_blk_syncfree(s, U, n_Usf, 0, kind, 0, sf_fault ? 1 : 0, intra.p, permn.p, nullptr, y.p, x, nullptr, sf_err.p);
+      tri_blk_syncfree(s, L, n_Lsf, 1, kind, 0, 0, intra.p, permn.p, b, nullptr, y.p, nullptr, x, sf_err.p);
+      tri_blk_syncfree(s, U, n_Usf, 0, kind, 0, sf_fault ? 1 : 0, intra.p, permn.p, nullptr, y.p, x, nullptr, y.p, sf_err.p);
     }
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();

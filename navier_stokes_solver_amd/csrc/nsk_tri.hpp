@@ -48,6 +48,7 @@ struct TriSolve {
   bool use_window = false;    // NSK_IOPT_TRI_WINDOW: scalar factors on the window format (study variant)
   double tiny_bytes = 4.0e6;  // factors below this size take the single-workgroup path (NSK_IOPT_TINY_BYTES)
   bool sync_free = false;  // one launch per half with in-kernel producer/consumer hand-off (see nsk_kernels.h)
+  bool sf_armed = false;   // y holds the sentinel everywhere (left so by every completed single-launch apply)
   bool sf_fault = false;   // test hook: wrong workgroup order in the upper half of the single-launch solves
   DBuf<double> xc;         // colour-ordered result vector of the upper half (x_layout = 1, blocked factor)
   DBuf<int> sf_err;        // raised by a bounded spin that ran out

@@ -12,7 +12,7 @@ ap.add_argument("--prec", type=int, default=2)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--xlayout", type=int, default=2)
 ap.add_argument("--syncfree", type=int, default=2)
-ap.add_argument("--win-spmv", type=int, default=1)
+ap.add_argument("--win-spmv", type=int, default=0)
 ap.add_argument("--tri-window", type=int, default=0)
 a = ap.parse_args()
 nx, ny = (int(v) for v in a.mesh.split(","))
