@@ -2,14 +2,19 @@
 """bench.py — DoF·iters/s of the FGMRES + aSIMPLE velocity-pressure solve on MI355X.
 
 Metric (BASELINE.json): DoF·iters/sec (FGMRES+aSIMPLE, Re=100) at 1/2/4/8 GPUs; achieved HBM GB/s.
-Workload at N=1: BASELINE configs[2] — stationary 1200x400, Re=100 (nu=1/90, Newton system),
-FGMRES + aSIMPLE on one MI355X.  For N>1 the mesh grows along x (1200*N x 400, x-strip row
-partition, weak scaling): per-GPU work is fixed, halo exchange + all-reduce go over RCCL.
 
-A step is ONE outer FGMRES iteration: aSIMPLE apply (inner FGMRES on F with ILU(0), B, inner CG
-on S with ILU(0), B^T, D^-1) + jacobian SpMV + modified Gram-Schmidt + least squares/check.
-The timed region is `solve_system`'s solver.solve() limited to exactly K iterations (tolerance 0),
-inputs resident in HBM; preconditioner setup (diag, SpGEMM, 2x ILU(0)) is reported separately.
+Workload
+  N = 1   BASELINE configs[2]: stationary 1200x400, Re=100 (nu = 1/90, Newton system), FGMRES + aSIMPLE on one MI355X.
+  N >= 2  BASELINE configs[3] (north_star): stationary 4800x1600, Re=200 (nu = 1/190), FGMRES + aSIMPLE, row-partitioned
+          in x-strips over the N GPUs (STRONG scaling: halo exchange + all-reduce over RCCL) — whenever its working set
+          (about 3.9 KB per DoF: blocks, factors, node-block copies, Krylov bases) fits the N GPUs, i.e. from N = 4;
+          otherwise (N = 2) the weak-scaling mesh 1200 N x 400 at Re=100.  `--scaling weak|strong` and `--mesh` override.
+
+A step is ONE outer FGMRES iteration: aSIMPLE apply (inner FGMRES on F with ILU(0), B, inner CG on S with ILU(0), B^T,
+D^-1) + jacobian SpMV + modified Gram-Schmidt + least squares/check.  The timed region is `solve_system`'s solver.solve()
+limited to exactly K iterations from the initial guess (tolerance 0: nothing converges in K steps — the inner iteration
+counts, hence the time per step, grow along the Krylov space, so K is part of the metric label), inputs resident in HBM;
+the preconditioner set-up (diag, SpGEMM, 2x ILU(0)) is reported separately.
 
 One process per GPU: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`.
 """
@@ -19,13 +24,19 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+HBM_BYTES = 288e9
+BYTES_PER_DOF = 3.9e3          # measured working set of FGMRES + aSIMPLE at 1200x400 (41 GB / 10.48 M DoFs)
+N_DOFS_NORTH_STAR = 167_545_276  # 4800x1600
+NAMES_S = ["GMRES", "FGMRES", "Bicgstab"]
+NAMES_P = ["blockDiagonal", "blockTriangular", "aSIMPLE"]
 
 
 def parse():
@@ -33,28 +44,74 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=58)     # two full restart cycles of 29 counted iterations
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mesh", type=str, default="1200,400", help="per-GPU mesh X,Y (weak) or global (strong)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--reynolds", type=float, default=100.0)
+    ap.add_argument("--mesh", type=str, default="", help="X,Y: per-GPU mesh (weak) or global mesh (strong); default per --scaling")
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto")
+    ap.add_argument("--reynolds", type=float, default=0.0, help="default: 100 (N = 1, weak) / 200 (strong: configs[3])")
     ap.add_argument("--solver", type=int, default=1)
     ap.add_argument("--preconditioner", type=int, default=2)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--ordering", type=int, default=1, help="0 natural, 1 multicolour (triangular solves)")
     ap.add_argument("--subdomains", type=int, default=1)
-    ap.add_argument("--sync-free", type=int, default=2, help="0 per-level launches, 1 single-launch S/Mp solves, 2 also F")
+    ap.add_argument("--sync-free", type=int, default=2, help="0 per-colour launches, 1 single-launch S/Mp solves, 2 also F")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mesh", type=str, default="300,100")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
-    ap.add_argument("--converge", type=float, default=0.0, help="if > 0: also run a full solve to this tolerance")
+    ap.add_argument("--converge", type=float, default=0.0, help="if > 0: also one full solve to this tolerance (see --converge-*)")
+    ap.add_argument("--converge-mesh", type=str, default="300,100")
+    ap.add_argument("--converge-preconditioner", type=int, default=0, help="default: BASELINE configs[1], FGMRES + blockDiagonal")
+    ap.add_argument("--converge-budget", type=float, default=600.0, help="seconds after which the solve is cancelled")
     return ap.parse_args()
 
 
+def make_solver(S, PT, P, dist, args, nx, ny, nu, inv_dt, world, rank, local_rank):
+    """Generate this rank's hand-off, create the handle, upload.  Returns (ls, pr, n_global, t_gen, t_upload)."""
+    t0 = time.time()
+    pr = P.generate(nx, ny, nu=nu, mode=1, state=1, inv_dt=inv_dt, U=0.1 if args.variant == 0 else 0.3,
+                    nranks=world, rank=rank)
+    t_gen = time.time() - t0
+    n_global = int(pr.info["n_u_global"] + pr.info["n_p_global"])
+    uid, plan = None, None
+    if world > 1:
+        box = [S.get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+        gu, gp = [None] * world, [None] * world
+        dist.all_gather_object(gu, pr.ghost_u)
+        dist.all_gather_object(gp, pr.ghost_p)
+        plan = {S.SPACE_U: PT.build_halo_plan(rank, pr.u_ranges, gu),
+                S.SPACE_P: PT.build_halo_plan(rank, pr.p_ranges, gp)}
+    ls = S.LinearSolver(rank, world, local_rank, uid)
+    ls.set_option(S.OPT_TRI_ORDERING, args.ordering)
+    ls.set_option(S.OPT_SUBDOMAINS, args.subdomains)
+    ls.set_option(S.OPT_TRI_SYNC_FREE, args.sync_free)
+    t0 = time.time()
+    ls.set_problem(pr, plan)
+    return ls, pr, n_global, t_gen, time.time() - t0
+
+
+def timed_steps(ls, pr, solver, prec, variant, steps, warmup, barrier, sync):
+    """W untimed + exactly K timed outer iterations from the same initial state, fresh preconditioner object each."""
+    ls.setup_preconditioner(prec, variant, 0.5)
+    ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    ls.solve_resident(solver, 0.0, max(1, warmup))   # (falls back to per-colour launches by itself if a hand-off gives up)
+    ls.setup_preconditioner(prec, variant, 0.5)
+    ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    ls.reset_stats()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    its, res, rc = ls.solve_resident(solver, 0.0, steps)
+    sync()
+    barrier()
+    return its, res, rc, time.perf_counter() - t0
+
+
 def cpu_baseline(args, nu):
-    """Oracle (CPU restatement of the reference path, kind 'port') on a bounded sample of the same
-    workload: same solver / preconditioner / Reynolds number on a smaller mesh, a few outer iterations,
-    run the way the reference runs on a node: one emulated MPI rank per host core (x-strip shards,
-    block-Jacobi ILU(0) = Ifpack overlap 0), OpenMP threads standing in for the ranks."""
+    """Oracle (CPU restatement of the reference path, kind 'port') on a bounded sample of the same workload: same
+    solver / preconditioner / Reynolds number on a smaller mesh, a few outer iterations, run the way the reference runs
+    on a node: one emulated MPI rank per host core (x-strip shards, block-Jacobi ILU(0) = Ifpack overlap 0), OpenMP
+    threads standing in for the ranks."""
     import numpy as np
     from navier_stokes_solver_amd import problem as P
     from oracle import oracle as O
@@ -79,12 +136,61 @@ def cpu_baseline(args, nu):
     return {
         "value": pr.n * its / info["solve_seconds"], "unit": "DoF*iters/s", "cores": cores, "kind": "port",
         "sample": f"oracle (C restatement, {cores} OpenMP threads = {cores} emulated MPI ranks with block-Jacobi ILU(0)), "
-                  f"stationary {nx}x{ny} Re={args.reynolds:g}, {its} outer iterations, "
+                  f"stationary {nx}x{ny} Re={args.reynolds:g}, first {its} outer iterations, "
                   f"{info['inner_u_its'] / max(1, info['prec_applies']):.0f} / {info['inner_p_its'] / max(1, info['prec_applies']):.0f} "
                   f"inner F / S iterations per step; solve {info['solve_seconds']:.1f}s + setup {info['setup_seconds']:.1f}s "
                   f"(wall {wall:.1f}s)",
         "incl_setup_value": pr.n * its / (info["solve_seconds"] + info["setup_seconds"]),
+        "mesh": f"{nx}x{ny}", "K": its,
     }
+
+
+def converged_solve(S, PT, P, dist, args, world, rank, local_rank, sync):
+    """One full solve to a tolerance with a stated time budget (default: BASELINE configs[1], 300x100 FGMRES +
+    blockDiagonal).  A heartbeat prints outer iterations and the current residual; past the budget the solve is
+    cancelled (nsk_cancel) and reported as such — a run can no longer end without a record."""
+    import numpy as np
+    nx, ny = (int(v) for v in args.converge_mesh.split(","))
+    nu = P.reynolds_to_nu(100.0, stationary=True)
+    ls, pr, n_global, _, _ = make_solver(S, PT, P, dist, args, nx, ny, nu, 0.0, world, rank, local_rank)
+    prec = args.converge_preconditioner
+    ls.setup_preconditioner(prec, 0, 0.5)
+    ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    sync()
+    done = threading.Event()
+    cancelled = [False]
+    t_start = time.time()
+
+    def heartbeat():   # the C call blocks (GIL released): report progress, enforce the budget
+        while not done.wait(20.0):
+            st = ls.stats()
+            el = time.time() - t_start
+            print(f"[bench] converging {nx}x{ny} {NAMES_P[prec]}: {el:.0f} s, outer iteration {st['cur_outer_iters']}, "
+                  f"residual {st['cur_residual']:.3e} (target {args.converge:g})", file=sys.stderr, flush=True)
+            if el > args.converge_budget and not cancelled[0]:
+                cancelled[0] = True
+                ls.cancel()
+
+    hb = threading.Thread(target=heartbeat, daemon=True)
+    hb.start()
+    t0 = time.perf_counter()
+    its, res, rc = ls.solve_resident(args.solver, args.converge, 20000)
+    sync()
+    dt = time.perf_counter() - t0
+    done.set()
+    out = {"workload": f"stationary {nx}x{ny} Re=100 (nu=1/90) Newton system, {NAMES_S[args.solver]} + {NAMES_P[prec]}",
+           "dofs": n_global, "tol": args.converge, "iters": its, "final_res": res, "status": rc, "seconds": dt,
+           "cancelled_after_budget_s": args.converge_budget if cancelled[0] else None,
+           "dof_iters_per_s": n_global * its / dt}
+    if world == 1 and rc == 0 and n_global <= 1_000_000:
+        xu, xp = ls.download_solution()
+        J = pr.jacobian_scipy()
+        out["true_residual"] = float(np.linalg.norm(np.concatenate([pr.rhs_u, pr.rhs_p]) - J @ np.concatenate([xu, xp])))
+    st = ls.stats()
+    out["inner_F_its_per_step"] = st["inner_u_its"] / max(1, st["prec_applies"])
+    out["inner_P_its_per_step"] = st["inner_p_its"] / max(1, st["prec_applies"])
+    ls.close()
+    return out
 
 
 def main():
@@ -102,7 +208,6 @@ def main():
         # the ranks of this node (torch.distributed.run pins OMP_NUM_THREADS=1).  Set before any OpenMP runtime loads.
         from navier_stokes_solver_amd._threads import cpu_budget
         os.environ["OMP_NUM_THREADS"] = str(max(1, min(32, cpu_budget() // world)))
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -117,37 +222,29 @@ def main():
     from navier_stokes_solver_amd import problem as P
     from navier_stokes_solver_amd import solver as S
 
-    mx, my = (int(v) for v in args.mesh.split(","))
-    nx = mx * world if args.scaling == "weak" else mx
+    # ---- workload (see the module docstring)
+    scaling = args.scaling
+    if scaling == "auto":
+        scaling = "weak"
+        if world > 1 and not args.mesh and BYTES_PER_DOF * N_DOFS_NORTH_STAR / world <= 0.8 * HBM_BYTES:
+            scaling = "strong"
+    if args.mesh:
+        mx, my = (int(v) for v in args.mesh.split(","))
+    else:
+        mx, my = (4800, 1600) if scaling == "strong" else (1200, 400)
+    nx = mx * world if scaling == "weak" else mx
     ny = my
+    if args.reynolds <= 0.0:
+        args.reynolds = 200.0 if (scaling == "strong" and not args.mesh) else 100.0
     nu = P.reynolds_to_nu(args.reynolds, stationary=(args.variant == 0))
     inv_dt = 0.0 if args.variant == 0 else 100.0
 
-    t0 = time.time()
-    pr = P.generate(nx, ny, nu=nu, mode=1, state=1, inv_dt=inv_dt, U=0.1 if args.variant == 0 else 0.3,
-                    nranks=world, rank=rank)
-    t_gen = time.time() - t0
-    n_global = int(pr.info["n_u_global"] + pr.info["n_p_global"])
+    def barrier():
+        if world > 1:
+            dist.barrier()
 
-    uid = None
-    plan = None
-    if world > 1:
-        box = [S.get_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
-        gu, gp = [None] * world, [None] * world
-        dist.all_gather_object(gu, pr.ghost_u)
-        dist.all_gather_object(gp, pr.ghost_p)
-        plan = {S.SPACE_U: PT.build_halo_plan(rank, pr.u_ranges, gu),
-                S.SPACE_P: PT.build_halo_plan(rank, pr.p_ranges, gp)}
-
-    ls = S.LinearSolver(rank, world, local_rank, uid)
-    ls.set_option(S.OPT_TRI_ORDERING, args.ordering)
-    ls.set_option(S.OPT_SUBDOMAINS, args.subdomains)
-    ls.set_option(S.OPT_TRI_SYNC_FREE, args.sync_free)
-    t0 = time.time()
-    ls.set_problem(pr, plan)
-    t_upload = time.time() - t0
+    sync = torch.cuda.synchronize
+    ls, pr, n_global, t_gen, t_upload = make_solver(S, PT, P, dist, args, nx, ny, nu, inv_dt, world, rank, local_rank)
     t0 = time.time()
     ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
     t_setup_first = time.time() - t0     # includes the one-off symbolic analysis
@@ -155,28 +252,25 @@ def main():
     ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
     t_setup = time.time() - t0           # numeric refactorisation only (what every Newton step pays)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    # warm-up
+    aS = args.preconditioner == 2
+    ops = (20, 0, 21) + ((5,) if aS else (3,))
+    # warm-up + timed region; HIP events around every launch of the sampled ops inside the timed solve
+    ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
     ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
-    ls.solve_resident(args.solver, 0.0, max(1, args.warmup))   # (falls back to per-colour launches by itself if a hand-off gives up)
-    # timed: exactly K outer iterations from the same initial state, fresh preconditioner object
+    ls.solve_resident(args.solver, 0.0, max(1, args.warmup))   # (falls back to per-colour launches by itself if needed)
     ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
     ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
     ls.reset_stats()
-    aS = args.preconditioner == 2
-    for op in (20, 0, 21) + ((5,) if aS else (3,)):
-        ls.profile_begin(op, 1024)     # HIP events around every launch of these ops inside the timed solve
+    for op in ops:
+        ls.profile_begin(op, 1024)
     barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     its, res, rc = ls.solve_resident(args.solver, 0.0, args.steps)
-    torch.cuda.synchronize()
+    sync()
     barrier()
     dt = time.perf_counter() - t0
-    prof = {op: ls.profile_read(op) for op in (20, 0, 21) + ((5,) if aS else (3,))}
+    prof = {op: ls.profile_read(op) for op in ops}
     ls.profile_end()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64)
@@ -184,29 +278,27 @@ def main():
         dt = float(tt.item())
     st = ls.stats()
     assert its == args.steps, (its, args.steps)
+    n_u_local, n_p_local, nnz_F_local = pr.n_u, pr.n_p, pr.F.nnz
+    ls.close()
+    del pr
+
+    # ---- like-for-like pair of the CPU baseline: the same K iterations on the CPU baseline's mesh, on the GPU
+    gpu_same = None
+    if world == 1 and not args.no_cpu_baseline:
+        cx, cy = (int(v) for v in args.cpu_mesh.split(","))
+        ls2, pr2, n2, _, _ = make_solver(S, PT, P, dist, args, cx, cy, nu, inv_dt, 1, 0, local_rank)
+        i2, r2, _, dt2 = timed_steps(ls2, pr2, args.solver, args.preconditioner, args.variant, args.cpu_steps, 2,
+                                     lambda: None, sync)
+        st2 = ls2.stats()
+        gpu_same = {"value": n2 * i2 / dt2, "unit": "DoF*iters/s", "mesh": f"{cx}x{cy}", "K": i2,
+                    "ms_per_step": 1e3 * dt2 / max(1, i2),
+                    "inner_F_its_per_step": st2["inner_u_its"] / max(1, st2["prec_applies"]),
+                    "inner_S_its_per_step": st2["inner_p_its"] / max(1, st2["prec_applies"])}
+        ls2.close()
 
     conv = None
     if args.converge > 0:
-        ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
-        ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
-        torch.cuda.synchronize()
-        import threading
-        done = threading.Event()
-
-        def heartbeat():   # the C call blocks (GIL released): keep the log alive for long solves
-            t_start = time.time()
-            while not done.wait(60.0):
-                print(f"[bench] converging ... {time.time() - t_start:.0f} s", file=sys.stderr, flush=True)
-
-        hb = threading.Thread(target=heartbeat, daemon=True)
-        hb.start()
-        t0 = time.perf_counter()
-        cits, cres, crc = ls.solve_resident(args.solver, args.converge, 20000 if args.variant == 0 else 100000)
-        torch.cuda.synchronize()
-        cdt = time.perf_counter() - t0
-        done.set()
-        conv = {"tol": args.converge, "iters": cits, "final_res": cres, "status": crc, "seconds": cdt,
-                "dof_iters_per_s": n_global * cits / cdt}
+        conv = converged_solve(S, PT, P, dist, args, world, rank, local_rank, sync)
 
     if rank == 0:
         value = n_global * args.steps / dt
@@ -221,35 +313,41 @@ def main():
                       f"tri_stream_kernel: ILU(0)/SGS apply on the pressure block ({lp}+{lp} level "
                       "launches of one apply)")}
         klass = {}
-        for op, (ms, cnt, by, ncalls) in prof.items():
-            klass[op] = dict(kernel=names[op], avg_ms=ms, launches_sampled=cnt, calls=ncalls, bytes_per_launch=by,
-                             achieved=(by / 1e9) / (ms / 1e3) if ms > 0 else 0.0,
+        for op, (ms, cnt, by, ncalls, byf) in prof.items():
+            ach = (by / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+            achf = (byf / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+            klass[op] = dict(kernel=names[op], avg_ms=ms, launches_sampled=cnt, calls=ncalls,
+                             bytes_csr_algorithmic=by, bytes_format=byf,
+                             achieved_algorithmic=ach, achieved_format=achf,
+                             # fraction of the HBM peak from the bytes the storage format really streams: cannot exceed 1
+                             frac=achf / HBM_PEAK_GBS, frac_algorithmic=ach / HBM_PEAK_GBS,
                              time_share=ncalls * ms / 1e3 / dt)   # share of the timed solve spent in this class
         dom = max(klass, key=lambda o: klass[o]["time_share"])
-        k_ms, k_n, k_bytes, achieved = (klass[dom]["avg_ms"], klass[dom]["launches_sampled"],
-                                        klass[dom]["bytes_per_launch"], klass[dom]["achieved"])
+        D = klass[dom]
         # HBM traffic of the dominant class from the committed PMC passes (rocprofv3 --pmc cannot run inside
         # this process); only quoted when it was measured on this very workload
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_1200x400.json")
-        if (nx, ny, world) == (1200, 400, 1) and os.path.exists(pmc):
-            kk = json.load(open(pmc)).get("by_op", {})
-            if str(dom) in kk:
-                traffic = kk[str(dom)]["traffic_bytes_corrected"]
-                traffic_src = "profiles/r01_pmc_traffic_1200x400.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+        for pmc_name in ("r02_pmc_traffic_1200x400.json", "r01_pmc_traffic_1200x400.json"):
+            pmc = os.path.join(ROOT, "profiles", pmc_name)
+            if (nx, ny, world) == (1200, 400, 1) and os.path.exists(pmc):
+                kk = json.load(open(pmc)).get("by_op", {})
+                if str(dom) in kk:
+                    traffic = kk[str(dom)]["traffic_bytes_corrected"]
+                    traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                    break
+        label = f"{NAMES_S[args.solver]}+{NAMES_P[args.preconditioner]}, Re={args.reynolds:g}"
         out = {
-            "metric": f"DoF*iters/s ({['GMRES', 'FGMRES', 'Bicgstab'][args.solver]}+"
-                      f"{['blockDiagonal', 'blockTriangular', 'aSIMPLE'][args.preconditioner]}, Re={args.reynolds:g})",
+            "metric": f"DoF*iters/s ({label}; first K={args.steps} outer iterations)",
             "value": value, "unit": "DoF*iters/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"{'stationary' if args.variant == 0 else 'unsteady (dt=0.01)'} {nx}x{ny} Q3/Q2, "
                             f"Re={args.reynolds:g} (nu=1/{1 / nu:g}) Newton system, "
-                            f"solver {['GMRES', 'FGMRES', 'Bicgstab'][args.solver]} + "
-                            f"{['blockDiagonal', 'blockTriangular', 'aSIMPLE'][args.preconditioner]}",
-                "dofs": n_global, "n_u_local": pr.n_u, "n_p_local": pr.n_p, "nnz_F_local": pr.F.nnz,
+                            f"solver {NAMES_S[args.solver]} + {NAMES_P[args.preconditioner]}",
+                "K": args.steps, "restart": 30, "tolerance": 0.0,
+                "dofs": n_global, "n_u_local": n_u_local, "n_p_local": n_p_local, "nnz_F_local": nnz_F_local,
                 "nnz_S_local": st["nnz_s"], "partition": f"x-strips x{world}",
                 "tri_ordering": ["natural", "multicolor"][args.ordering], "colors_u": st["n_colors_u"],
                 "colors_p": st["n_colors_p"], "subdomains_per_gpu": args.subdomains,
@@ -258,28 +356,34 @@ def main():
                 "residual_after_K": res,
             },
             "roofline": {
-                "bound": "hbm", "kernel": klass[dom]["kernel"], "time_share": klass[dom]["time_share"],
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                "bound": "hbm", "kernel": D["kernel"], "time_share": D["time_share"],
+                "achieved": D["achieved_algorithmic"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": D["achieved_algorithmic"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                 "traffic_source": traffic_src,
-                "bytes_per_launch": k_bytes, "avg_ms": k_ms, "launches_sampled": k_n,
+                "bytes_per_launch": D["bytes_csr_algorithmic"], "bytes_format": D["bytes_format"],
+                "frac_format": D["frac"], "avg_ms": D["avg_ms"], "launches_sampled": D["launches_sampled"],
             },
-            "kernel_classes": [dict(klass[o], frac=klass[o]["achieved"] / HBM_PEAK_GBS) for o in sorted(klass)],
+            "kernel_classes": [klass[o] for o in sorted(klass)],
             "phases": {
                 "generate_s": t_gen, "upload_s": t_upload, "setup_first_s": t_setup_first, "setup_numeric_s": t_setup,
                 "solve_s": dt, "spmv_GB": st["spmv_bytes"] / 1e9, "tri_GB": st["tri_bytes"] / 1e9,
                 "blas1_GB": st["blas1_bytes"] / 1e9,
                 "algorithmic_GBps_whole_solve": (st["spmv_bytes"] + st["tri_bytes"] + st["blas1_bytes"]) / 1e9 / dt,
                 "host_syncs": st["host_syncs"], "reductions": st["reductions"],
+                "host_syncs_per_step": st["host_syncs"] / args.steps, "reductions_per_step": st["reductions"] / args.steps,
+                "sync_free_fallbacks": st["sync_free_fallbacks"],
                 "dof_iters_per_s_incl_setup": n_global * args.steps / (dt + t_setup),
             },
         }
         if conv:
             out["converged_solve"] = conv
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, nu)
+            cb = cpu_baseline(args, nu)
+            cb["gpu_same_mesh"] = gpu_same    # the like-for-like pair: same mesh, same K, same inner work per iteration
+            if gpu_same:
+                cb["gpu_over_cpu_same_mesh"] = gpu_same["value"] / cb["value"]
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
-    ls.close()
     if world > 1:
         dist.destroy_process_group()
 

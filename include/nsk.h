@@ -147,6 +147,11 @@ int nsk_spmv(nsk_handle h, int blk, const double *x_owned, double *y, int add);
 int nsk_jacobian_vmult(nsk_handle h, const double *x_u, const double *x_p, double *y_u, double *y_p);
 /* dot(x,y) and ||x||_2 over the owned entries of all ranks */
 int nsk_dot(nsk_handle h, int n, const double *x, const double *y, double *dot_out, double *norm_x_out);
+/* One vector operation of the path on caller vectors of length n (parity tests of SURVEY 8a row a4).  op: 0 y=x,
+ * 1 y=a x (equ), 2 y+=a x (add), 3 y=c y+a x (sadd), 4 y+=a x+c z, 5 y*=a, 6 y.*=d (scale(vec)), 7 y-=d.*x,
+ * 8 y=(y-x).*d, 9 y=1/d, 10 add_and_dot: y+=a x, *scalar_out=y.z, 11 y+=a x, *scalar_out=y.y.  y is in/out. */
+int nsk_vec_op(nsk_handle h, int op, int n, double a, double c, const double *x, double *y, const double *z,
+               const double *d, double *scalar_out);
 /* x = M^-1 b with the velocity / pressure preconditioner of the current setup (triangular solves, or one AMG
  * V-cycle for the velocity block of the stationary blockTriangular setup) */
 int nsk_tri_apply(nsk_handle h, int which, const double *b, double *x);
@@ -208,6 +213,13 @@ int nsk_download_rhs(nsk_handle h, double *rhs_u, double *rhs_p);
 int nsk_time_assemble(nsk_handle h, double nu, double inv_dt, int reps, double *avg_ms);
 
 int nsk_get_stats(nsk_handle h, nsk_stats *out);
+/* Residuals SolverControl::check saw during the last outer solve, in order (start value, then one per counted
+ * iteration; FGMRES / BiCGStab add the true residual at every restart).  Returns how many there were; at most `cap`
+ * are copied (the library keeps the first 65536). */
+int nsk_get_history(nsk_handle h, double *out, int cap);
+/* End the outer solve running on this handle at its next SolverControl check (status 1, iters/final_res valid).
+ * The only entry point that may be called from another thread while a solve is in progress. */
+int nsk_cancel(nsk_handle h);
 int nsk_reset_stats(nsk_handle h);
 
 /* Device-side timing of one operation repeated `reps` times between HIP events on the
@@ -220,8 +232,10 @@ int nsk_time_op(nsk_handle h, int op, int reps, double *avg_ms, double *bytes);
  * (same ids as nsk_time_op: 0..5 SpMV of that block, 20/21 triangular applies; up to four ops at once)
  * is bracketed by events on the library's stream until max_samples are taken. */
 int nsk_profile_begin(nsk_handle h, int op, int max_samples);
+/* bytes_per_launch: algorithmic bytes (CSR); bytes_format: what the storage format the kernel streams
+ * really holds (node-block copies are smaller than CSR) — roofline fractions from the latter cannot exceed 1 */
 int nsk_profile_read(nsk_handle h, int op, double *avg_ms, int *n_samples, double *bytes_per_launch,
-                     int64_t *n_calls);
+                     int64_t *n_calls, double *bytes_format);
 int nsk_profile_end(nsk_handle h);
 
 #ifdef __cplusplus

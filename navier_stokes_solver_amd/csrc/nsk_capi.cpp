@@ -105,6 +105,8 @@ struct nsk_handle_s {
   double *rhs_b = nullptr, *x_b = nullptr, *x_keep = nullptr;
   volatile long progress_step = 0;      // outer iterations / residual of the running solve (nsk_get_stats from another thread)
   volatile double progress_value = 0.0;
+  volatile int cancel = 0;              // nsk_cancel: ends the running outer solve at its next SolverControl check
+  std::vector<double> history;          // residuals the outer SolverControl saw in the last solve (nsk_get_history)
   long inner_u = 0, inner_p = 0, prec_applies = 0, outer_iters = 0;
   double setup_ms = 0, solve_ms = 0;
 
@@ -486,6 +488,9 @@ int H::solve_once(int solver, double tol, int max_iter, int *iters, double *fina
   SolverControl control(max_iter, tol);
   control.progress_step = &progress_step;
   control.progress_value = &progress_value;
+  history.clear();
+  control.history = &history;
+  control.cancel = &cancel;
   MatVec A = [&](const DVec &x, double *y) { jacobian_vmult(x, y); };
   PrecVmult P = [&](DVec &d, const DVec &r) { prec_vmult(d, r); };
   DVec x = bb(x_b);
@@ -516,6 +521,7 @@ int H::solve_resident(int solver, double tol, int max_iter, int *iters, double *
   if (prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
   if (solver < 0 || solver > 2) throw Error(-47, "Invalid solver type. Use 0: GMRES, 1: FGMRES, 2: Bicgstab.");
   const double t0 = wall_ms();
+  cancel = 0;
   const bool guarded = sync_free_mode > 0;
   if (guarded) {   // keep the initial guess: a failed attempt leaves garbage in x_b
     if (!x_keep) x_keep = pool_b.get(false);
@@ -837,6 +843,44 @@ int nsk_dot(nsk_handle h, int n, const double *x, const double *y, double *dot_o
   if (dot_out) *dot_out = r[0];
   if (norm_out) *norm_out = r[2];
   h->ctx.slot_top = sl;
+  return 0;
+  NSK_CATCH(h)
+}
+
+// One BLAS-1 operation of the path on caller vectors (a4: the TrilinosWrappers::MPI::Vector family as the solvers use
+// it).  op: 0 copy y=x | 1 equ y=a x | 2 axpy y+=a x | 3 sadd y=c y+a x | 4 axpy2 y+=a x+c z | 5 scale y*=a | 6 mul y.*=d
+// | 7 submul y-=d.*x | 8 sub_then_mul y=(y-x).*d | 9 recip y=1/d | 10 add_and_dot y+=a x, s=y.z | 11 y+=a x, s=y.y
+int nsk_vec_op(nsk_handle h, int op, int n, double a, double c, const double *x, double *y, const double *z, const double *d,
+               double *scalar_out) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  if (n <= 0 || op < 0 || op > 11) throw Error(-50, "nsk_vec_op: bad arguments");
+  DBuf<double> dx, dy, dz, dd;
+  hipStream_t s = h->s();
+  dx.upload(x, (size_t)n, s);
+  dy.upload(y, (size_t)n, s);
+  dz.upload(z, (size_t)n, s);
+  dd.upload(d, (size_t)n, s);
+  const int sl = h->ctx.alloc_slots(2);
+  struct Rel { Ctx &c; int sl; ~Rel() { c.slot_top = sl; } } rel{h->ctx, sl};
+  double sc = 0.0;
+  switch (op) {
+    case 0: vec_copy(s, n, dx.p, dy.p); break;
+    case 1: vec_equ(s, n, sref(a), dx.p, dy.p); break;
+    case 2: vec_axpy(s, n, sref(a), dx.p, dy.p); break;
+    case 3: vec_sadd(s, n, sref(c), sref(a), dx.p, dy.p); break;
+    case 4: vec_axpy2(s, n, sref(a), dx.p, sref(c), dz.p, dy.p); break;
+    case 5: vec_scale(s, n, sref(a), dy.p); break;
+    case 6: vec_mul(s, n, dd.p, dy.p); break;
+    case 7: vec_submul(s, n, dd.p, dx.p, dy.p); break;
+    case 8: vec_sub_then_mul(s, n, dx.p, dd.p, dy.p); break;
+    case 9: vec_recip(s, n, dd.p, dy.p); break;
+    case 10: h->ctx.axpy_dot(n, sref(a), dx.p, dy.p, dz.p, sl); sc = h->ctx.read_slots(sl, 1)[0]; break;
+    default: h->ctx.axpy_norm2(n, sref(a), dx.p, dy.p, sl); sc = h->ctx.read_slots(sl, 1)[0]; break;
+  }
+  NSK_HIP(hipMemcpyAsync(y, dy.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+  h->ctx.sync();
+  if (scalar_out) *scalar_out = sc;
   return 0;
   NSK_CATCH(h)
 }
@@ -1256,6 +1300,20 @@ int nsk_get_stats(nsk_handle h, nsk_stats *o) {
   NSK_CATCH(h)
 }
 
+int nsk_cancel(nsk_handle h) {   // callable from another thread while a solve runs on this handle
+  if (!h) return -1;
+  h->cancel = 1;
+  return 0;
+}
+
+int nsk_get_history(nsk_handle h, double *out, int cap) {
+  NSK_TRY(h)
+  const int n = (int)h->history.size();
+  for (int i = 0; i < std::min(n, cap); ++i) out[i] = h->history[(size_t)i];
+  return n;
+  NSK_CATCH(h)
+}
+
 int nsk_reset_stats(nsk_handle h) {
   NSK_TRY(h)
   h->ctx.st = Stats{};
@@ -1273,7 +1331,8 @@ int nsk_profile_begin(nsk_handle h, int op, int max_samples) {
   NSK_CATCH(h)
 }
 
-int nsk_profile_read(nsk_handle h, int op, double *avg_ms, int *n_samples, double *bytes, int64_t *n_calls) {
+int nsk_profile_read(nsk_handle h, int op, double *avg_ms, int *n_samples, double *bytes, int64_t *n_calls,
+                     double *bytes_format) {
   NSK_TRY(h)
   (void)hipSetDevice(h->ctx.device);
   h->ctx.sync();
@@ -1293,6 +1352,12 @@ int nsk_profile_read(nsk_handle h, int op, double *avg_ms, int *n_samples, doubl
     else if (op == 20) *bytes = (double)h->tF.apply_bytes();
     else if (op == 21 && h->tP) *bytes = (double)h->tP->apply_bytes();
     else *bytes = 0.0;
+  }
+  if (bytes_format) {   // what the storage format in use really holds (<= the CSR figure for the node-block copies)
+    if (op >= 0 && op <= NSK_BLK_S) *bytes_format = h->blk[op].format_bytes(h->use_stream && h->use_bsr, h->use_stream && h->use_win_spmv);
+    else if (op == 20) *bytes_format = h->tF.format_bytes();
+    else if (op == 21 && h->tP) *bytes_format = h->tP->format_bytes();
+    else *bytes_format = 0.0;
   }
   return 0;
   NSK_CATCH(h)

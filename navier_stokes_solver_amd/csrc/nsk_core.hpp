@@ -126,6 +126,13 @@ struct Csr {  // device CSR block with host copy of the pattern
     return WinView{win_runs.p, win_lines.p, win_roff.p, reinterpret_cast<const unsigned *>(win_pos.p), win_val.p};
   }
   CsrView view() const { return CsrView{n_rows, n_own_cols, rowptr.p, col.p, val.p}; }
+  // bytes the storage format the SpMV kernels actually stream holds (values, indices, descriptors) + y + x once
+  double format_bytes(bool blocked, bool window) const {
+    if (blocked && blk_ok)
+      return (double)blk_count * (4.0 + 8.0 * blk_R * blk_C) + 4.0 * (blk_rows + 1.0) + 8.0 * n_rows + 8.0 * n_cols;
+    if (window && win_ok) return win_bytes + 8.0 * n_rows + 8.0 * n_cols;
+    return (double)spmv_bytes();
+  }
   size_t spmv_bytes() const {  // 12 nnz + 4 (rows+1) + 8 rows + 8 cols
     return (size_t)12 * nnz + 4 * ((size_t)n_rows + 1) + 8 * (size_t)n_rows + 8 * (size_t)n_cols;
   }

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <functional>
 #include <limits>
+#include <vector>
 
 #include "nsk_core.hpp"
 
@@ -32,13 +33,16 @@ struct SolverControl {
   double lvalue = 0.0;
   volatile long *progress_step = nullptr;     // optional: where a watcher (bench heartbeat) reads the progress
   volatile double *progress_value = nullptr;
+  std::vector<double> *history = nullptr;     // optional: every value check() sees, in order (capped)
+  volatile int *cancel = nullptr;             // optional: set to 1 from another thread to end the solve (failure)
   SolverControl(int n, double t) : max_steps(n), tol(t) {}
   State check(int step, double value) {
     lstep = step;
     lvalue = value;
     if (progress_step) { *progress_step = step; *progress_value = value; }
+    if (history && history->size() < 65536) history->push_back(value);
     if (value <= tol) return success;
-    if (step >= max_steps || std::isnan(value)) return failure;
+    if (step >= max_steps || std::isnan(value) || (cancel && *cancel)) return failure;
     return iterate;
   }
   int last_step() const { return lstep; }

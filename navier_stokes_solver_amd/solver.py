@@ -34,9 +34,9 @@ ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
 EXPORTS = [
     "nsk_get_unique_id", "nsk_local_group_id", "nsk_create", "nsk_destroy", "nsk_last_error", "nsk_set_partition", "nsk_set_halo_plan",
     "nsk_set_block_csr", "nsk_update_values", "nsk_set_option", "nsk_setup_preconditioner", "nsk_solve",
-    "nsk_upload_system", "nsk_solve_resident", "nsk_download_solution", "nsk_spmv", "nsk_jacobian_vmult", "nsk_dot",
+    "nsk_upload_system", "nsk_solve_resident", "nsk_download_solution", "nsk_spmv", "nsk_jacobian_vmult", "nsk_dot", "nsk_vec_op",
     "nsk_tri_apply", "nsk_amg_info", "nsk_tri_get_perm", "nsk_precond_vmult", "nsk_block_nnz", "nsk_get_block", "nsk_get_stats",
-    "nsk_reset_stats", "nsk_assembly_set_cells", "nsk_assembly_set_dirichlet", "nsk_state_set", "nsk_state_get",
+    "nsk_reset_stats", "nsk_get_history", "nsk_cancel", "nsk_assembly_set_cells", "nsk_assembly_set_dirichlet", "nsk_state_set", "nsk_state_get",
     "nsk_state_save", "nsk_state_save_old", "nsk_state_update", "nsk_assemble", "nsk_scale_values", "nsk_download_rhs", "nsk_time_assemble", "nsk_time_op", "nsk_profile_begin", "nsk_profile_read", "nsk_profile_end",
 ]
 
@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
         L.nsk_spmv.argtypes = [vp, C.c_int, f64p, f64p, C.c_int]
         L.nsk_jacobian_vmult.argtypes = [vp, f64p, f64p, f64p, f64p]
         L.nsk_dot.argtypes = [vp, C.c_int, f64p, f64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.nsk_vec_op.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, f64p, f64p, f64p, f64p, C.POINTER(C.c_double)]
         L.nsk_assembly_set_cells.argtypes = [vp, C.c_int64, i32p, i32p, vp, f64p, C.c_int32]
         L.nsk_assembly_set_dirichlet.argtypes = [vp, vp, f64p]
         L.nsk_state_set.argtypes = [vp, f64p, f64p]
@@ -122,10 +123,12 @@ def lib() -> C.CDLL:
         L.nsk_get_block.argtypes = [vp, C.c_int, i32p, i32p, f64p]
         L.nsk_get_stats.argtypes = [vp, C.POINTER(Stats)]
         L.nsk_reset_stats.argtypes = [vp]
+        L.nsk_get_history.argtypes = [vp, f64p, C.c_int]
+        L.nsk_cancel.argtypes = [vp]
         L.nsk_time_op.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.nsk_profile_begin.argtypes = [vp, C.c_int, C.c_int]
         L.nsk_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double),
-                                       C.POINTER(C.c_int64)]
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         L.nsk_profile_end.argtypes = [vp]
         _LIB = L
     return _LIB
@@ -286,6 +289,18 @@ class LinearSolver:
         self._ck(self.L.nsk_dot(self.h, len(x), x.ctypes.data, y.ctypes.data, C.byref(d), C.byref(nrm)))
         return d.value, nrm.value
 
+    VEC_OPS = {"copy": 0, "equ": 1, "axpy": 2, "sadd": 3, "axpy2": 4, "scale": 5, "mul": 6, "submul": 7,
+               "sub_then_mul": 8, "recip": 9, "axpy_dot": 10, "axpy_norm2": 11}
+
+    def vec_op(self, op, a, c, x, y, z, d):
+        """One BLAS-1 operation of the path (see nsk_vec_op); returns (y_after, scalar)."""
+        x, z, d = _f64(x), _f64(z), _f64(d)
+        out = _f64(y).copy()
+        sc = C.c_double(0)
+        self._ck(self.L.nsk_vec_op(self.h, self.VEC_OPS[op], len(out), a, c, x.ctypes.data, out.ctypes.data, z.ctypes.data,
+                                   d.ctypes.data, C.byref(sc)))
+        return out, sc.value
+
     def tri_apply(self, which, b):
         b = _f64(b)
         x = np.empty_like(b)
@@ -383,6 +398,16 @@ class LinearSolver:
         self._ck(self.L.nsk_get_stats(self.h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in Stats._fields_}
 
+    def history(self, cap=65536):
+        """Residuals the outer solver's SolverControl saw during the last solve."""
+        out = np.zeros(cap)
+        n = self._ck(self.L.nsk_get_history(self.h, out.ctypes.data, cap))
+        return out[:min(n, cap)].copy()
+
+    def cancel(self):
+        """End the solve running on this handle (callable from another thread)."""
+        self.L.nsk_cancel(self.h)
+
     def reset_stats(self):
         self._ck(self.L.nsk_reset_stats(self.h))
 
@@ -390,9 +415,9 @@ class LinearSolver:
         self._ck(self.L.nsk_profile_begin(self.h, op, max_samples))
 
     def profile_read(self, op):
-        ms, n, by, calls = C.c_double(0), C.c_int(0), C.c_double(0), C.c_int64(0)
-        self._ck(self.L.nsk_profile_read(self.h, op, C.byref(ms), C.byref(n), C.byref(by), C.byref(calls)))
-        return ms.value, n.value, by.value, calls.value
+        ms, n, by, calls, byf = C.c_double(0), C.c_int(0), C.c_double(0), C.c_int64(0), C.c_double(0)
+        self._ck(self.L.nsk_profile_read(self.h, op, C.byref(ms), C.byref(n), C.byref(by), C.byref(calls), C.byref(byf)))
+        return ms.value, n.value, by.value, calls.value, byf.value
 
     def profile_end(self):
         self._ck(self.L.nsk_profile_end(self.h))

@@ -92,11 +92,14 @@ typedef struct {
   double tol;
   int last_step;
   double last_value;
+  double *hist;   /* optional: every value passed to check(), in order (outer solver only) */
+  int hist_cap, hist_n;
 } control_t;
 enum { ST_ITERATE = 0, ST_SUCCESS = 1, ST_FAILURE = 2 };
 static int control_check(control_t *c, int step, double value) {
   c->last_step = step;
   c->last_value = value;
+  if (c->hist) { if (c->hist_n < c->hist_cap) c->hist[c->hist_n] = value; ++c->hist_n; }
   if (value <= c->tol) return ST_SUCCESS;
   if (step >= c->max_steps || isnan(value)) return ST_FAILURE;
   return ST_ITERATE;
@@ -675,11 +678,11 @@ static int prec_vmult(void *ctx, double *dst, const double *src) {
   if (o->prec == 0) {
     control_t cu, cp;
     if (o->variant == 0) { /* NSSolverStationary.hpp:132-153 */
-      cu = (control_t){100001, 1e-1 * orc_norm2(nu, su), 0, 0};
-      cp = (control_t){100000, 1e-1 * orc_norm2(np, sp), 0, 0};
+      cu = (control_t){100001, 1e-1 * orc_norm2(nu, su), 0, 0, NULL, 0, 0};
+      cp = (control_t){100000, 1e-1 * orc_norm2(np, sp), 0, 0, NULL, 0, 0};
     } else { /* NSSolver.hpp:155-176: absolute tolerance 1e-1, 1000 iterations */
-      cu = (control_t){1000, 1e-1, 0, 0};
-      cp = (control_t){1000, 1e-1, 0, 0};
+      cu = (control_t){1000, 1e-1, 0, 0, NULL, 0, 0};
+      cp = (control_t){1000, 1e-1, 0, 0, NULL, 0, 0};
     }
     rc = solve_fgmres(op_csr, (void *)&P->F, prec_tri, pc->tF, nu, du, su, &cu, uit, NULL);
     if (rc) return 3;
@@ -689,11 +692,11 @@ static int prec_vmult(void *ctx, double *dst, const double *src) {
   if (o->prec == 1) {
     control_t cu, cp;
     if (o->variant == 0) { /* NSSolverStationary.hpp:189-218 */
-      cu = (control_t){10000001, 1e-2 * orc_norm2(nu, su), 0, 0};
-      cp = (control_t){100000, 1e-2 * orc_norm2(np, sp), 0, 0};
+      cu = (control_t){10000001, 1e-2 * orc_norm2(nu, su), 0, 0, NULL, 0, 0};
+      cp = (control_t){100000, 1e-2 * orc_norm2(np, sp), 0, 0, NULL, 0, 0};
     } else { /* NSSolver.hpp:212-237 */
-      cu = (control_t){2000001, 1e-4 * orc_norm2(nu, su), 0, 0};
-      cp = (control_t){2000000, 1e-5 * orc_norm2(np, sp), 0, 0};
+      cu = (control_t){2000001, 1e-4 * orc_norm2(nu, su), 0, 0, NULL, 0, 0};
+      cp = (control_t){2000000, 1e-5 * orc_norm2(np, sp), 0, 0, NULL, 0, 0};
     }
     if (pc->aF) rc = solve_fgmres(op_csr, (void *)&P->F, prec_amg, pc->aF, nu, du, su, &cu, uit, NULL);
     else rc = solve_fgmres(op_csr, (void *)&P->F, prec_tri, pc->tF, nu, du, su, &cu, uit, NULL);
@@ -705,12 +708,12 @@ static int prec_vmult(void *ctx, double *dst, const double *src) {
   }
   if (o->variant == 0) {
     /* PreconditionaSIMPLE::vmult, stationary (NSSolverStationary.hpp:282-311) */
-    control_t cF = {100000, 1e-1 * orc_norm2(nu, su), 0, 0};
+    control_t cF = {100000, 1e-1 * orc_norm2(nu, su), 0, 0, NULL, 0, 0};
     rc = solve_fgmres(op_csr, (void *)&P->F, prec_tri, pc->tF, nu, du, su, &cF, uit, NULL);
     if (rc) return 3;
     orc_spmv(&P->B, du, pc->tmp_p, 0);
     v_sadd(np, -1.0, 1.0, sp, pc->tmp_p);                         /* tmp_p = src_p - B u~ */
-    control_t cS = {100000, 1e-1 * orc_norm2(np, pc->tmp_p), 0, 0};
+    control_t cS = {100000, 1e-1 * orc_norm2(np, pc->tmp_p), 0, 0, NULL, 0, 0};
     rc = solve_cg(op_csr, (void *)&pc->S, prec_tri, pc->tP, np, pc->delta_p, pc->tmp_p, &cS, pit); /* stale delta_p start */
     if (rc) return 3;
     for (int i = 0; i < np; ++i) pc->delta_p[i] *= o->alpha;
@@ -739,6 +742,12 @@ static void op_jacobian(void *ctx, const double *x, double *y) {
   orc_spmv(&P->B, x, y + P->n_u, 0);
 }
 
+/* residual history of the next orc_solve calls (test infrastructure of the test infrastructure: not thread-safe) */
+static double *g_hist = NULL;
+static int g_hist_cap = 0, g_hist_n = 0;
+void orc_set_history(double *buf, int cap) { g_hist = buf; g_hist_cap = buf ? cap : 0; g_hist_n = 0; }
+int orc_history_count(void) { return g_hist_n; }
+
 int orc_solve(const orc_problem *P, const orc_opts *o, const double *rhs, double *x, orc_result *res) {
   orc_result local;
   if (!res) res = &local;
@@ -749,7 +758,7 @@ int orc_solve(const orc_problem *P, const orc_opts *o, const double *rhs, double
   prec_setup(&pc, P, o, res);
   double t1 = now_s();
   res->setup_seconds = t1 - t0;
-  control_t c = {o->max_iter, o->tol, 0, 0.0};
+  control_t c = {o->max_iter, o->tol, 0, 0.0, g_hist, g_hist_cap, 0};
   const int n = P->n_u + P->n_p;
   int rc;
   if (o->solver == 0) rc = solve_gmres(op_jacobian, (void *)P, prec_vmult, &pc, n, x, rhs, &c, &res->outer_spmv);
@@ -759,6 +768,7 @@ int orc_solve(const orc_problem *P, const orc_opts *o, const double *rhs, double
   res->status = rc;
   res->iters = c.last_step;
   res->final_res = c.last_value;
+  g_hist_n = c.hist_n;
   prec_free(&pc);
   return rc;
 }

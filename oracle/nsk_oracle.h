@@ -101,6 +101,9 @@ typedef struct {
 } orc_result;
 
 /* x (n_u + n_p) is the initial guess on entry and the solution on exit. */
+/* record every residual the OUTER solver's SolverControl::check sees during the next orc_solve calls */
+void orc_set_history(double *buf, int cap);
+int orc_history_count(void);
 int orc_solve(const orc_problem *P, const orc_opts *o, const double *rhs, double *x, orc_result *res);
 
 /* One application of a block preconditioner to src (for kernel-level parity tests):

@@ -72,6 +72,7 @@ def lib() -> C.CDLL:
         L.orc_amg_level_lambda.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_amg_level_lambda.restype = C.c_double
         L.orc_solve.argtypes = [C.POINTER(Problem), C.POINTER(Opts), C.c_void_p, C.c_void_p, C.POINTER(Result)]
+        L.orc_set_history.argtypes = [C.c_void_p, C.c_int]
         L.orc_prec_apply.argtypes = [C.POINTER(Problem), C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
@@ -205,15 +206,24 @@ class OracleProblem:
         return cls(CsrHolder.from_block(pr.F), CsrHolder.from_block(pr.Bt), CsrHolder.from_block(pr.B),
                    CsrHolder.from_block(pr.Mp), **kw)
 
-    def solve(self, rhs, x0, solver=1, prec=0, variant=0, tol=1e-6, max_iter=None, alpha=0.5, velocity_amg=0):
+    def solve(self, rhs, x0, solver=1, prec=0, variant=0, tol=1e-6, max_iter=None, alpha=0.5, velocity_amg=0, history=0):
         if max_iter is None:
             max_iter = 20000 if variant == 0 else 100000  # NSSolverStationary.cpp:580 / NSSolver.cpp:604
         o = Opts(solver, prec, variant, max_iter, tol, alpha, velocity_amg)
         r = Result()
         x = _f64(x0).copy()
         rhs = _f64(rhs)
-        lib().orc_solve(C.byref(self.c), C.byref(o), rhs.ctypes.data, x.ctypes.data, C.byref(r))
-        info = {k: getattr(r, k) for k, _ in Result._fields_}
+        hist = np.zeros(history) if history else None
+        if history:
+            lib().orc_set_history(hist.ctypes.data, history)
+        try:
+            lib().orc_solve(C.byref(self.c), C.byref(o), rhs.ctypes.data, x.ctypes.data, C.byref(r))
+            info = {k: getattr(r, k) for k, _ in Result._fields_}
+            if history:
+                info["history"] = hist[:min(history, lib().orc_history_count())].copy()
+        finally:
+            if history:
+                lib().orc_set_history(None, 0)
         return x, info
 
     def prec_apply(self, src, dst0=None, prec=2, variant=0, alpha=0.5, calls=1, velocity_amg=0):

@@ -208,8 +208,9 @@ def test_solve_matches_oracle_and_direct(handles, name, solver, prec, variant, t
     else:
         assert true_res <= 1.05 * tol
     if solver == 2:
-        # BiCGStab's recurrences amplify rounding differences (iteration counts differ between any two
-        # summation orders) and tol 1e-4 pins x only to kappa*tol: the residual bound above is the check.
+        # tol 1e-4 pins x only to kappa * tol and BiCGStab's residual is not monotone (it crosses 1e-4 at a step that
+        # depends on the last bits): test_bicgstab_* below compare what CAN agree — the residual history while the two
+        # runs still track each other, and x / the iteration count of a solve that ends inside that window.
         return
     xs = spl.splu(J).solve(b)
     assert rel_err(x, xo) <= 1e-7, (rel_err(x, xo), its, info["iters"])
@@ -220,6 +221,105 @@ def test_solve_matches_oracle_and_direct(handles, name, solver, prec, variant, t
     # after a 1-ulp change of the input).  The solution checks above are the parity statement; elsewhere 20 % holds.
     slack = 0.5 if variant == 1 else 0.2
     assert abs(its - info["iters"]) <= max(3, slack * info["iters"]), (its, info["iters"])
+
+
+def _first_divergence(a, b, rel):
+    n = min(len(a), len(b))
+    bad = np.nonzero(np.abs(a[:n] - b[:n]) > rel * np.abs(b[:n]))[0]
+    return int(bad[0]) if len(bad) else n
+
+
+@pytest.mark.parametrize("ordering", [0, 1])
+def test_bicgstab_history_and_solution_match_oracle(handles, ordering):
+    """a7, SolverBicgstab (NSSolverStationary.cpp:595-597; NSSolver.cpp:636-638) with the unsteady aSIMPLE, a FIXED linear
+    preconditioner (NSSolver.hpp:294-350: two ILU applies, no inner Krylov solve), so GPU and oracle run the same
+    recurrence and differ by rounding only.
+      * the residuals SolverControl sees (two per step: after r -= alpha v and the exact residual) agree to 1e-9
+        relative over the first 5 steps and to 1e-3 over the first 9: the runs track each other, then rounding differences
+        grow about tenfold per step — tests/test_oracle.py::test_bicgstab_amplifies_the_last_bits shows the ORACLE ALONE
+        doing the same under a 1e-15 perturbation of the right-hand side (67 -> 91...202 iterations).  That is why the
+        iteration count of a solve that hovers around its tolerance for dozens of steps (55 against 125 in the first GPU
+        run of round 1, tol 1e-4) is not comparable;
+      * a solve that ends INSIDE that window (tol 1e-2, an 8-fold reduction) takes the same number of steps on both
+        sides and returns the same x to 1e-7;
+      * deal.II's ABSOLUTE breakdown threshold 1e-10 on r.rbar makes every step a breakdown once
+        ||r|| < 1e-5: no tolerance below that can be reached (the oracle ends with status 2 at 8e-5 on this system),
+        so there is no BiCGStab case at 1e-10; at 1e-4 the true residual is checked."""
+    S, O = _S(), _O()
+    pr = problem("unsteady16")
+    ls = handles("unsteady16", ordering)
+    ls.setup_preconditioner(S.ASIMPLE, S.UNSTEADY, 0.5)
+    kw = {}
+    if ordering:
+        kw = dict(perm_F=ls.tri_perm(S.TRI_VELOCITY), perm_S=ls.tri_perm(S.TRI_PRESSURE))
+    op = O.OracleProblem.from_local(pr, **kw)
+    J = pr.jacobian_scipy()
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    x0 = np.concatenate([pr.x0_u, pr.x0_p])
+    # (i) histories
+    ls.setup_preconditioner(S.ASIMPLE, S.UNSTEADY, 0.5)
+    xu, xp, its, res, rc = ls.solve(S.BICGSTAB, 1e-4, 100000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    hg = ls.history()
+    xo, info = op.solve(b, x0, solver=2, prec=2, variant=1, tol=1e-4, history=4096)
+    ho = info["history"]
+    assert rc == 0 and info["status"] == 0
+    assert np.linalg.norm(b - J @ np.concatenate([xu, xp])) <= 1.05e-4 and np.linalg.norm(b - J @ xo) <= 1.05e-4
+    assert len(hg) >= 19 and len(ho) >= 19
+    assert _first_divergence(hg, ho, 1e-9) >= 11, (_first_divergence(hg, ho, 1e-9), hg[:12], ho[:12])
+    assert _first_divergence(hg, ho, 1e-3) >= 19, (_first_divergence(hg, ho, 1e-3), its, info["iters"])
+    # (ii) a solve that ends while the runs still track each other
+    ls.setup_preconditioner(S.ASIMPLE, S.UNSTEADY, 0.5)
+    xu, xp, its, res, rc = ls.solve(S.BICGSTAB, 1e-2, 100000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    xo, info = op.solve(b, x0, solver=2, prec=2, variant=1, tol=1e-2)
+    assert rc == 0 and info["status"] == 0 and its == info["iters"] and 2 <= its <= 8, (its, info["iters"])
+    assert rel_err(np.concatenate([xu, xp]), xo) <= 1e-7
+    assert abs(res - info["final_res"]) <= 1e-8 * info["final_res"]
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_first_restart_cycle_matches_oracle(handles, prec, solver):
+    """The unsteady systems make restarted (F)GMRES stagnate for thousands of iterations, so total iteration counts only
+    agree to tens of percent (test_solve_matches_oracle_and_direct); the FIRST restart cycle, where GPU and oracle
+    have done the same arithmetic, must agree to rounding: the 30 residuals SolverControl sees (start value + 29
+    estimates; GMRES: 28) to 1e-8 relative.  Inner solves with the absolute tolerance 1e-1 (blockDiagonal,
+    NSSolver.hpp:159-169) stop at the same inner step on both sides unless a residual sits within rounding of the
+    threshold."""
+    S, O = _S(), _O()
+    pr = problem("unsteady16")
+    ls = handles("unsteady16", 1)
+    ls.setup_preconditioner(prec, S.UNSTEADY, 0.5)
+    op = O.OracleProblem.from_local(pr, perm_F=ls.tri_perm(S.TRI_VELOCITY),
+                                    **{"perm_S" if prec == 2 else "perm_Mp": ls.tri_perm(S.TRI_PRESSURE)})
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    n = 30 if solver == 1 else 29
+    ls.setup_preconditioner(prec, S.UNSTEADY, 0.5)
+    ls.solve(solver, 0.0, n - 1, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    hg = ls.history()
+    _, info = op.solve(b, np.concatenate([pr.x0_u, pr.x0_p]), solver=solver, prec=prec, variant=1, tol=0.0, max_iter=n - 1,
+                       history=64)
+    ho = info["history"]
+    assert len(hg) >= n and len(ho) >= n, (len(hg), len(ho))
+    assert np.abs(hg[:n] - ho[:n]).max() <= 1e-8 * np.abs(ho[:n]).max(), np.abs(hg[:n] / ho[:n] - 1).max()
+
+
+def test_vector_ops_directly(handles):
+    """a4: the BLAS-1 family of TrilinosWrappers::MPI::Vector as the library runs it (sadd, scale, add, equ, *=,
+    add_and_dot ...), element-wise against NumPy (one multiply-add per entry: 1e-15), through nsk_vec_op."""
+    S = _S()
+    ls = handles("stokes16")
+    for n in (1, 255, 4097, 1 << 20):
+        x, y, z, d = rng_vec(n, 1), rng_vec(n, 2), rng_vec(n, 3), rng_vec(n, 4) + 1.5
+        a, c = 0.37, -1.9
+        for op, ref in (("copy", x), ("equ", a * x), ("axpy", y + a * x), ("sadd", c * y + a * x),
+                        ("axpy2", y + a * x + c * z), ("scale", a * y), ("mul", y * d), ("submul", y - d * x),
+                        ("sub_then_mul", (y - x) * d), ("recip", 1.0 / d)):
+            got, _ = ls.vec_op(op, a, c, x, y, z, d)
+            assert np.abs(got - ref).max() <= 4e-16 * max(1.0, np.abs(ref).max()), (op, n)
+        got, dot = ls.vec_op("axpy_dot", a, c, x, y, z, d)          # add_and_dot(a, x, z): y += a x ; y . z
+        assert np.abs(got - (y + a * x)).max() <= 4e-16 * 3 and abs(dot - np.dot(y + a * x, z)) <= 1e-12 * n
+        got, nrm2 = ls.vec_op("axpy_norm2", a, c, x, y, z, d)
+        assert abs(nrm2 - np.dot(y + a * x, y + a * x)) <= 1e-12 * n
 
 
 @pytest.mark.parametrize("name,subdomains", [("ns16", 1), ("ns60", 1), ("ns60", 3)])
