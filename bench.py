@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--ordering", type=int, default=1, help="0 natural, 1 multicolour (triangular solves)")
     ap.add_argument("--subdomains", type=int, default=1)
     ap.add_argument("--sync-free", type=int, default=2, help="0 per-colour launches, 1 single-launch S/Mp solves, 2 also F")
+    ap.add_argument("--cg-single-reduction", type=int, default=-1,
+                    help="inner CG with one fused all-reduce per iteration (NSK_OPT_CG_SINGLE_REDUCTION); default: on for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mesh", type=str, default="300,100")
     ap.add_argument("--cpu-steps", type=int, default=12)
@@ -85,6 +87,7 @@ def make_solver(S, PT, P, dist, args, nx, ny, nu, inv_dt, world, rank, local_ran
     ls.set_option(S.OPT_TRI_ORDERING, args.ordering)
     ls.set_option(S.OPT_SUBDOMAINS, args.subdomains)
     ls.set_option(S.OPT_TRI_SYNC_FREE, args.sync_free)
+    ls.set_option(S.OPT_CG_SINGLE_REDUCTION, int(args.cg_single_reduction if args.cg_single_reduction >= 0 else world > 1))
     t0 = time.time()
     ls.set_problem(pr, plan)
     return ls, pr, n_global, t_gen, time.time() - t0
@@ -354,6 +357,8 @@ def main():
                 "inner_F_its_per_step": st["inner_u_its"] / max(1, st["prec_applies"]),
                 "inner_S_its_per_step": st["inner_p_its"] / max(1, st["prec_applies"]),
                 "residual_after_K": res,
+                "inner_cg": "single-reduction (Chronopoulos-Gear)" if (args.cg_single_reduction if args.cg_single_reduction >= 0
+                                                                      else world > 1) else "deal.II recurrence",
             },
             "roofline": {
                 "bound": "hbm", "kernel": D["kernel"], "time_share": D["time_share"],

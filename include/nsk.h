@@ -72,6 +72,10 @@ enum {
   NSK_OPT_INNER_FUSED_GS = 4, /* 1 (default): inner FGMRES (on F) orthogonalises with fused classical Gram-Schmidt
                                  (two sweeps, 8 vectors per pass); 0: deal.II's modified Gram-Schmidt (add_and_dot) */
   NSK_OPT_OUTER_FUSED_GS = 5, /* same for the outer FGMRES; default 0 (modified Gram-Schmidt, as deal.II) */
+  NSK_OPT_CG_SINGLE_REDUCTION = 11, /* 0 (default): inner CG (on S / Mp) with deal.II's recurrence — three reductions per
+                                 iteration; 1: Chronopoulos-Gear form, ONE fused reduction (one all-reduce) per iteration:
+                                 same iterates in exact arithmetic, one more preconditioner + matrix application per solve.
+                                 For several GPUs, where every reduction is a latency-bound collective */
   NSK_OPT_BSR_VELOCITY = 7,   /* 1 (default): SpMVs with the jacobian blocks use 2x2 / 2x1 / 1x2 node-block copies when the pattern allows */
   NSK_OPT_TRI_SYNC_FREE = 9,  /* multicolour triangular solves in ONE launch instead of one per colour: rows wait in-kernel for
                                  the entries they depend on (bounded spins on sentinel-filled working vectors, see

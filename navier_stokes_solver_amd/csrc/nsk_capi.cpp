@@ -79,7 +79,7 @@ struct nsk_handle_s {
   VecPool pool_u, pool_p, pool_b;
   bool pools_ready = false;
   int tri_ordering = ORDER_MULTICOLOR, subdomains = 1, fuse_block_row = 1, use_stream = 1;
-  bool inner_fused_gs = true, outer_fused_gs = false;
+  bool inner_fused_gs = true, outer_fused_gs = false, cg_fused = false;
   int use_bsr = 1;
   int sync_free_fallbacks = 0;
   int x_layout_mode = 2;   // NSK_IOPT_TRI_X_LAYOUT
@@ -168,8 +168,7 @@ struct nsk_handle_s {
   // BlockSparseMatrix::vmult on jacobian_matrix: y_u = F x_u + Bt x_p ; y_p = B x_u (+ 0 x_p)
   void jacobian_vmult(const DVec &xb, double *yb) {
     const DVec xu = ub(xb.own), xp = pb(xb.own);
-    halo(0, xu);
-    halo(1, xp);
+    ctx.comm.halo_exchange2(sp[0], xu, sp[1], xp, s());   // both ghost imports in one RCCL group
     Csr &F = blk[NSK_BLK_F], &Bt = blk[NSK_BLK_BT], &B = blk[NSK_BLK_B];
     const bool blocked = use_stream && use_bsr && F.blk_ok && Bt.blk_ok && F.blk_R == 2 && Bt.blk_R == 2 &&
                          F.blk_rows == Bt.blk_rows;
@@ -428,6 +427,7 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
       inner_u += cu.last_step();
       if (prec_type == 0) {
         SolverCG sc(ctx, pool_p, cp);
+        sc.fused = cg_fused;
         sc.solve(A_M, dp, spv, P_P);
       } else {
         // tmp.reinit; B->vmult(tmp, dst_u); tmp.sadd(-1, src_p)  =>  tmp = src_p - B u
@@ -435,6 +435,7 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
         spmv_nohalo(B, du, tmp_p, 2, spv.own);
         DVec tp = pool_p.view(tmp_p);
         SolverCG sc(ctx, pool_p, cp);
+        sc.fused = cg_fused;
         sc.solve(A_M, dp, tp, P_P);
       }
       inner_p += cp.last_step();
@@ -457,6 +458,7 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
       spmv_nohalo(B, du, tmp_p, 2, spv.own);             // tmp_p = src_p - B u~
       SolverControl cS(100000, 1e-1 * norm_of(tmp_p, np));
       SolverCG sS(ctx, pool_p, cS);
+      sS.fused = cg_fused;
       DVec dlt = pool_p.view(delta_p), tp = pool_p.view(tmp_p);
       sS.solve(A_S, dlt, tp, P_P);                      // S delta_p = tmp_p, stale delta_p as start
       inner_p += cS.last_step();
@@ -736,6 +738,7 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
       break;
     case NSK_OPT_INNER_FUSED_GS: h->inner_fused_gs = v != 0.0; break;
     case NSK_OPT_OUTER_FUSED_GS: h->outer_fused_gs = v != 0.0; break;
+    case NSK_OPT_CG_SINGLE_REDUCTION: h->cg_fused = v != 0.0; break;
     default: throw Error(-61, "nsk_set_option: unknown option");
   }
   return 0;

@@ -165,6 +165,34 @@ void Comm::halo_exchange(Space &sp, const DVec &x, hipStream_t s) {
   NSK_NCCL(ncclGroupEnd());
 }
 
+// Both ghost imports of one block-matrix product (velocity and pressure part of x) in ONE RCCL group: one
+// launch-side round trip instead of two; the pack kernels of both spaces run before the group.
+void Comm::halo_exchange2(Space &sa, const DVec &xa, Space &sb, const DVec &xb, hipStream_t s) {
+  if (nranks <= 1) return;
+  if (local) {   // in-process test transport: no grouping to gain
+    halo_exchange(sa, xa, s);
+    halo_exchange(sb, xb, s);
+    return;
+  }
+  if (sa.peers.empty() && sb.peers.empty()) return;
+  if (sa.n_send > 0) halo_pack(s, sa.n_send, sa.d_send_idx.p, xa.own, sa.d_send_buf.p);
+  if (sb.n_send > 0) halo_pack(s, sb.n_send, sb.d_send_idx.p, xb.own, sb.d_send_buf.p);
+  NSK_NCCL(ncclGroupStart());
+  for (int pass = 0; pass < 2; ++pass) {
+    Space &sp = pass == 0 ? sa : sb;
+    const DVec &x = pass == 0 ? xa : xb;
+    for (size_t k = 0; k < sp.peers.size(); ++k) {
+      const int ns = sp.send_ptr[k + 1] - sp.send_ptr[k];
+      const int nr = sp.recv_ptr[k + 1] - sp.recv_ptr[k];
+      if (ns > 0)
+        NSK_NCCL(ncclSend(sp.d_send_buf.p + sp.send_ptr[k], (size_t)ns, ncclDouble, sp.peers[k], (ncclComm_t)comm, s));
+      if (nr > 0)
+        NSK_NCCL(ncclRecv(x.ghost + sp.recv_ptr[k], (size_t)nr, ncclDouble, sp.peers[k], (ncclComm_t)comm, s));
+    }
+  }
+  NSK_NCCL(ncclGroupEnd());
+}
+
 void Ctx::init(int device_id) {
   device = device_id;
   NSK_HIP(hipSetDevice(device));
@@ -245,6 +273,12 @@ void Ctx::cg_update(int n, SRef a, const double *d, const double *h, double *x, 
   st.blas1_bytes += 48.0 * n;
 }
 
+void Ctx::dot3(int n, const double *r, const double *u, const double *w, int so) {
+  vec_dot3(stream, ws, n, r, u, w, slot(so));
+  comm.allreduce_sum(slot(so), 3, stream);   // ONE all-reduce for the three scalars of a CG step
+  ++st.reductions;
+  st.blas1_bytes += 24.0 * n;
+}
 void Ctx::multi_dot(int n, const double *w, double *const *v, int m, int so) {
   VecPack P{};
   for (int k = 0; k < m; ++k) P.v[k] = v[k];

@@ -175,6 +175,7 @@ struct Comm {
   void destroy();
   void allreduce_sum(double *d, int count, hipStream_t s);
   void halo_exchange(Space &sp, const DVec &x, hipStream_t s);
+  void halo_exchange2(Space &sa, const DVec &xa, Space &sb, const DVec &xb, hipStream_t s);   // both in one RCCL group
 };
 
 // 128-byte pseudo unique id that makes nsk_create join an in-process group instead of RCCL
@@ -224,6 +225,7 @@ struct Ctx {
   void multi_dot(int n, const double *w, double *const *v, int m, int slot_out);
   void multi_axpy(int n, double *w, double *const *v, int m, int coef_slot, int norm_slot);
   void cg_update(int n, SRef a, const double *d, const double *h, double *x, double *g, int slot_out);
+  void dot3(int n, const double *r, const double *u, const double *w, int slot_out);   // r.u, w.u, r.r: one pass, one all-reduce
   void spmv(Csr &A, Space &colspace, const DVec &x, double *y, int mode = 0, const double *z = nullptr);
 };
 

@@ -105,6 +105,11 @@ struct VecPack {
 void vec_multi_dot(hipStream_t s, const ReduceWs &ws, int n, const double *w, const VecPack &P, int m, double *out);
 void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const VecPack &P, int m, const double *h,
                     double *norm_out);
+// single-reduction (Chronopoulos-Gear) CG building blocks: see SolverCG::solve_fused
+void vec_dot3(hipStream_t s, const ReduceWs &ws, int n, const double *r, const double *u, const double *w, double *out);
+void cg_fused_scalars(hipStream_t s, double *sc7, int first);
+void vec_cg_fused_update(hipStream_t s, int n, const double *sc7, const double *u, const double *w, double *p, double *sv,
+                         double *x, double *r);
 void scalar_sqrt(hipStream_t s, const double *in, double *out);                         // out = sqrt(|in|)
 void vec_gather(hipStream_t s, int n, const int *idx, const double *x, double *y);      // y[i] = x[idx[i]]
 void extract_diag(hipStream_t s, const CsrView &A, double *d, double *dinv);

@@ -1512,6 +1512,50 @@ void vec_cg_update(hipStream_t s, const ReduceWs &ws, int n, SRef a, const doubl
   });
 }
 
+// out[0] = r.u, out[1] = w.u, out[2] = r.r in ONE pass (single-reduction CG)
+__global__ __launch_bounds__(RBLK) void dot3_kernel(int n, const double *__restrict__ r, const double *__restrict__ u,
+                                                    const double *__restrict__ w, ReduceWs ws, double *out) {
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (long i = (long)blockIdx.x * RBLK + threadIdx.x; i < n; i += (long)gridDim.x * RBLK) {
+    const double ri = r[i], ui = u[i];
+    acc[0] += ri * ui;
+    acc[1] += w[i] * ui;
+    acc[2] += ri * ri;
+  }
+  reduce_finish<3>(acc, ws, out, 0);
+}
+void vec_dot3(hipStream_t s, const ReduceWs &ws, int n, const double *r, const double *u, const double *w, double *out) {
+  hipLaunchKernelGGL(dot3_kernel, dim3(red_grid(n)), dim3(RBLK), 0, s, n, r, u, w, ws, out);
+}
+// Scalars of one single-reduction CG step, on the device: sc = {gamma_new, delta, rr | gamma, alpha, beta, norm}
+//   first != 0:  beta = 0, alpha = gamma_new / delta
+//   else:        beta = gamma_new / gamma, alpha = gamma_new / (delta - beta gamma_new / alpha)
+void cg_fused_scalars(hipStream_t s, double *sc, int first) {
+  const int n = 1;
+  NSK_EW(n, [=] __device__(int) {
+    const double gn = sc[0], dl = sc[1];
+    double beta = 0.0, alpha;
+    if (first) alpha = gn / dl;
+    else { beta = gn / sc[3]; alpha = gn / (dl - beta * gn / sc[4]); }
+    sc[3] = gn;
+    sc[4] = alpha;
+    sc[5] = beta;
+    sc[6] = sqrt(fabs(sc[2]));
+  });
+}
+// p = u + beta p ; sv = w + beta sv ; x += alpha p ; r -= alpha sv   (alpha = sc[4], beta = sc[5]) in one pass
+void vec_cg_fused_update(hipStream_t s, int n, const double *sc, const double *u, const double *w, double *p, double *sv,
+                         double *x, double *r) {
+  NSK_EW(n, [=] __device__(int i) {
+    const double al = sc[4], be = sc[5];
+    const double pi = u[i] + be * p[i], si = w[i] + be * sv[i];
+    p[i] = pi;
+    sv[i] = si;
+    x[i] += al * pi;
+    r[i] -= al * si;
+  });
+}
+
 void vec_multi_dot(hipStream_t s, const ReduceWs &ws, int n, const double *w, const VecPack &P, int m, double *out) {
 #define NSK_MD(M) case M: hipLaunchKernelGGL((multi_dot_kernel<M>), dim3(red_grid(n)), dim3(RBLK), 0, s, n, w, P, ws, out); break;
   switch (m) { NSK_MD(1) NSK_MD(2) NSK_MD(3) NSK_MD(4) NSK_MD(5) NSK_MD(6) NSK_MD(7) NSK_MD(8) default: break; }

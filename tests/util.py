@@ -12,6 +12,8 @@ CASES = {
     "ns16": dict(nx=16, ny=10, nu=1.0 / 90.0, mode=1, state=1, inlet_bc=0),
     "stokes60": dict(nx=60, ny=20, nu=0.1, mode=0, state=0, inlet_bc=1),
     "ns60": dict(nx=60, ny=20, nu=1.0 / 90.0, mode=1, state=1, inlet_bc=0),
+    # BASELINE configs[3] runs at "Re = 200": the last continuation level is nu = 1/190 (NSSolverStationary.cpp:662-665)
+    "ns16_re200": dict(nx=16, ny=10, nu=1.0 / 190.0, mode=1, state=1, inlet_bc=0),
     "unsteady16": dict(nx=16, ny=10, nu=1.0 / 91.0, mode=1, state=1, inlet_bc=0, inv_dt=100.0, U=0.3),
 }
 
