@@ -299,6 +299,12 @@ def test_first_restart_cycle_matches_oracle(handles, prec, solver):
     _, info = op.solve(b, np.concatenate([pr.x0_u, pr.x0_p]), solver=solver, prec=prec, variant=1, tol=0.0, max_iter=n - 1,
                        history=64)
     ho = info["history"]
+    if (solver, prec) == (0, 0):
+        # left-preconditioned GMRES controls ||P r||, and this preconditioner's inner solves stop at the ABSOLUTE
+        # residual 1e-1 (NSSolver.hpp:159-169) > ||r0|| = 0.079: P r0 = 0, "converged" at step 0 with x untouched —
+        # on both sides
+        assert len(hg) == len(ho) == 1 and hg[0] == ho[0] == 0.0
+        return
     assert len(hg) >= n and len(ho) >= n, (len(hg), len(ho))
     assert np.abs(hg[:n] - ho[:n]).max() <= 1e-8 * np.abs(ho[:n]).max(), np.abs(hg[:n] / ho[:n] - 1).max()
 
