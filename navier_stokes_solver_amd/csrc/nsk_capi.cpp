@@ -1181,25 +1181,27 @@ int nsk_debug_tri_trace(nsk_handle h, int which, int64_t *out16, int max_runs, i
   (void)hipSetDevice(h->ctx.device);
   if (h->prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
   TriSolve *T = which == NSK_TRI_VELOCITY ? &h->tF : h->tP;
-  if (!T->win_ready) return 0;
+  const bool window = T->win_ready;
+  if (!window && !(T->stream_ready && T->sync_free)) return 0;
+  const int n_wg = window ? T->win_nruns : T->n_Lsf + T->n_Usf;
   VecPool &p = which == NSK_TRI_VELOCITY ? h->pool_u : h->pool_p;
   double *bv = p.get(true), *xv = p.get(true);
   vec_set(h->s(), p.n, bv, 1.0);
   T->apply(bv, xv);   // warm
   DBuf<long long> dbg;
-  dbg.alloc((size_t)T->win_nruns * 16);
+  dbg.alloc((size_t)n_wg * 16);
   NSK_HIP(hipMemsetAsync(dbg.p, 0, sizeof(long long) * dbg.n, h->s()));
   T->win_dbg = dbg.p;
   T->apply(bv, xv);
   T->win_dbg = nullptr;
-  const int n = std::min(max_runs, T->win_nruns);
+  const int n = std::min(max_runs, n_wg);
   NSK_HIP(hipMemcpyAsync(out16, dbg.p, sizeof(long long) * (size_t)n * 16, hipMemcpyDeviceToHost, h->s()));
   h->ctx.sync();
   p.put(bv);
   p.put(xv);
-  if (grid) *grid = T->sync_free ? std::min(T->win_grid, T->win_nruns) : 0;
+  if (grid) *grid = window ? (T->sync_free ? std::min(T->win_grid, T->win_nruns) : 0) : -T->n_Lsf;
   h->check_sync_free();
-  return T->win_nruns;
+  return n_wg;
   NSK_CATCH(h)
 }
 
@@ -1424,6 +1426,22 @@ int nsk_time_op(nsk_handle h, int op, int reps, double *avg_ms, double *bytes) {
   } else if (op == 32) {
     by = 32.0 * h->N();
     f = [=]() { h->ctx.axpy_dot(h->N(), sref(1e-9), xb, zb, yb, sl); };
+  } else if (op == 40 || op == 41) {
+    // host round trip of one device scalar (what every Krylov iteration pays for its SolverControl check): wall time
+    const double t0 = wall_ms();
+    for (int r = 0; r < reps; ++r) {
+      if (op == 41) h->ctx.dot(h->N(), xb, zb, sl);
+      (void)h->ctx.read_slots(sl, 1);
+    }
+    if (avg_ms) *avg_ms = (wall_ms() - t0) / reps;
+    if (bytes) *bytes = op == 41 ? 16.0 * h->N() : 0.0;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    h->ctx.slot_top = sl;
+    h->pool_b.put(xb);
+    h->pool_b.put(yb);
+    h->pool_b.put(zb);
+    return 0;
   } else {
     throw Error(-65, "nsk_time_op: unknown op");
   }

@@ -25,6 +25,10 @@ extern "C" {
  *   stream role: [0] before barrier A, [1] after A, [2] after the products, [3] after barrier B
  *   window role: [4] start of the run, [5] window copy and next-run loads issued, [6] after A, [7] results stored
  *   [8] threads that found a sentinel in the window and had to poll.
+ * CSR-halves kernels (default): per workgroup of the lower launch, then of the upper launch: [0] start, [1] matrix
+ * stream and first look at the gathered entries have landed, [2] wave 0 has all its entries (polls done), [3] all waves
+ * have, [4] results stored, [5] gathered entries that still held the sentinel, [6] XCC id, [7] rows, [8] non-zeros;
+ * *grid = -(workgroups of the lower launch).
  * Returns the number of runs of the list (0: this factor does not use the window format); *grid = workgroups of the
  * persistent launch (0: one launch per colour). */
 int nsk_debug_tri_trace(struct nsk_handle_s *h, int which, int64_t *out16, int max_runs, int *grid);

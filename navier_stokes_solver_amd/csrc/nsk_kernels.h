@@ -179,7 +179,7 @@ void vec_fill_sentinel(hipStream_t s, int n, double *y);
 void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int n_blocks, int lower, int kind, int run_nnz,
                          int wrong_order /* test hook */, const double *dinv, const int *perm, const double *rhs,
                          const double *own, double *w, double *reset /* gets the sentinel at the rows' positions */,
-                         int *err);
+                         int *err, long long *dbg = nullptr /* diagnostics: 16 int64 per workgroup */);
 void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int n_blocks, int lower, int kind, int permx,
                       int wrong_order /* test hook */, const double *intra, const int *permn, const double *rhs,
                       const double *own, double *w, double *out, double *reset, int *err);

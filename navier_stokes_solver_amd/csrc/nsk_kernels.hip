@@ -487,8 +487,14 @@ __global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, i
                                                             const double *__restrict__ dinv,
                                                             const int *__restrict__ perm,
                                                             const double *__restrict__ rhs,
-                                                            const double *ownv, double *w, double *reset, int *err) {
+                                                            const double *ownv, double *w, double *reset, int *err,
+                                                            long long *dbg) {
   __shared__ double prod[NNZ];
+  // diagnostics (dbg != null; nsk_internal.h: nsk_debug_tri_trace): time stamps of workgroup blockIdx.x
+  auto stamp = [&](int k) {
+    if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 16 + k] = (long long)__builtin_amdgcn_s_memrealtime();
+  };
+  stamp(0);
   // M.desc is in DISPATCH order (TriSolve::sf_dispatch_order): colours in dependency order, so producers
   // always sit in workgroups the dispatcher has started earlier; inside a colour (padded to a multiple of 8
   // with empty runs) the runs are dealt so that XCD k works on the k-th eighth of every colour.
@@ -522,13 +528,22 @@ __global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, i
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) g[u] = c[u] >= 0 ? sf_peek(w + c[u]) : 0ull;
+    if (dbg) {
+      int waiting = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) waiting += (c[u] >= 0 && g[u] == kSentinel) ? 1 : 0;   // (uses the loads: they have landed)
+      if (waiting) atomicAdd(reinterpret_cast<unsigned long long *>(dbg) + (size_t)blockIdx.x * 16 + 5, (unsigned long long)waiting);
+      stamp(1);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int k = k0 + (int)threadIdx.x + u * BLK;
       if (k < k1) prod[k - k0] = v[u] * sf_wait(w + c[u], g[u], err);
     }
   }
+  stamp(2);
   __syncthreads();
+  stamp(3);
   const double sum = row_sum_lds(prod, jb, je, lane);
   if (have && lane == 0) {
     double x;
@@ -539,6 +554,12 @@ __global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, i
     // upper half's result vector, the upper half re-arms the lower result it has just consumed (every other reader
     // of that entry ran in the lower launch, which has completed)
     reinterpret_cast<unsigned long long *>(reset)[i] = kSentinel;
+  }
+  stamp(4);
+  if (dbg && threadIdx.x == 0) {
+    dbg[(size_t)blockIdx.x * 16 + 6] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID
+    dbg[(size_t)blockIdx.x * 16 + 7] = r1 - r0;
+    dbg[(size_t)blockIdx.x * 16 + 8] = k1 - k0;
   }
 }
 
@@ -1393,9 +1414,9 @@ void vec_fill_sentinel(hipStream_t s, int n, double *y) {
 }
 void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int kind, int run_nnz, int wrong_order,
                          const double *dinv, const int *perm, const double *rhs, const double *own, double *w,
-                         double *reset, int *err) {
+                         double *reset, int *err, long long *dbg) {
   if (nb <= 0) return;
-#define NSK_SF(L, K, N) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, dinv, perm, rhs, own, w, reset, err)
+#define NSK_SF(L, K, N) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, dinv, perm, rhs, own, w, reset, err, dbg)
 #define NSK_SFN(L, K)                                      \
   do {                                                     \
     if (run_nnz <= 512) NSK_SF(L, K, 512);                 \

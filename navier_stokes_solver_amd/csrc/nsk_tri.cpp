@@ -630,8 +630,9 @@ void TriSolve::apply(const double *b, double *x) {
     const TriHalf L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
     // the lower half arms x for the upper half, the upper half re-arms y for the next call: no fill launches
     if (!sf_armed) { vec_fill_sentinel(s, n, y.p); sf_armed = true; }
-    tri_stream_syncfree(s, L, n_Lsf, 1, kind, kStreamNnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, x, sf_err.p);
-    tri_stream_syncfree(s, U, n_Usf, 0, kind, kStreamNnz, sf_fault ? 1 : 0, dinv.p, d_perm.p, nullptr, y.p, x, y.p, sf_err.p);
+    tri_stream_syncfree(s, L, n_Lsf, 1, kind, kStreamNnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, x, sf_err.p, win_dbg);
+    tri_stream_syncfree(s, U, n_Usf, 0, kind, kStreamNnz, sf_fault ? 1 : 0, dinv.p, d_perm.p, nullptr, y.p, x, y.p, sf_err.p,
+                        win_dbg ? win_dbg + (size_t)n_Lsf * 16 : nullptr);
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
     return;

@@ -29,7 +29,8 @@ t0 = time.time(); ls.setup_preconditioner(a.prec, 0, 0.5); t1 = time.time()
 ls.setup_preconditioner(a.prec, 0, 0.5); t2 = time.time()
 print(f"setup first {t1 - t0:.2f}s numeric {t2 - t1:.3f}s", ls.stats())
 names = {0: "spmv F", 1: "spmv Bt", 2: "spmv B", 3: "spmv Mp", 5: "spmv S", 10: "jacobian vmult", 20: "tri F apply",
-         21: "tri P apply", 30: "dot", 31: "axpy", 32: "add_and_dot"}
+         21: "tri P apply", 30: "dot", 31: "axpy", 32: "add_and_dot", 40: "host read of a scalar (wall)",
+         41: "dot + host read (wall)"}
 out = {}
 for op, nm in names.items():
     if op == 5 and a.prec != 2:
