@@ -23,7 +23,6 @@ CLASSES = [  # (label, substring(s) of the kernel name, launches per unit, op id
     ("tri_blk_sf_kernel upper, one ILU(F) apply", ["tri_blk_sf_kernel<0,"], 1, 20),
     ("tri_stream_sf_kernel lower, one ILU(S) apply", ["tri_stream_sf_kernel<1,"], 1, 21),
     ("tri_stream_sf_kernel upper, one ILU(S) apply", ["tri_stream_sf_kernel<0,"], 1, 21),
-    ("vec_fill_sentinel (two per single-launch apply; F and S applies pooled)", ["vec_fill_sentinel"], 2, None),
 ]
 
 
