@@ -3,7 +3,13 @@
 Reference: `NSSolverStationary::compute_lift_drag()`, `compute_lift_coeff()`, `compute_drag_coeff()`, `output()`
 (lab_new/src/NSSolverStationary.cpp:765-800, 802-897, 905-933) and the NSSolver twins (NSSolver.cpp:761-797,
 839-975).  These read the solution once per Newton pass / time step; they are not on the accelerated path and
-work on the owned vectors the drivers download with `nsk_state_get` (one rank).
+work on the vectors the drivers download with `nsk_state_get`.
+
+Several ranks (x-strips of whole cell columns, the generator's partition): every rank integrates / writes ITS cells —
+`lift_drag(..., rank, nranks)` returns the rank's share, which `sum_over_ranks` adds up as the reference's
+`Utilities::MPI::sum` does (.cpp:895-896; NSSolver.cpp:933-934); `write_vtu(..., rank, nranks)` writes the rank's
+piece and, on rank 0, the `.pvtu` record naming all pieces (`write_vtu_with_pvtu_record`, .cpp:793-796).  A rank only
+touches entries of its owned and ghost DoFs: `global_view` scatters them into global numbering (NaN elsewhere).
 
 The generated mesh is the nx x ny lattice over [0, 2.2] x [0, 0.41] without the cells whose centre is closer than
 0.05 to (0.2, 0.205) (`NSSolverStationary.cpp:13-63`); boundary id 10 (the obstacle) is every face between a kept
@@ -71,18 +77,49 @@ class Lattice:
         return un, pn
 
 
-def lift_drag(nx, ny, u, p, nu):
+def cell_columns(nx, nranks):
+    """First cell column of every rank's x-strip (+ end): the generator's rule (csrc/problem_gen.cpp)."""
+    return [r * nx // nranks for r in range(nranks + 1)]
+
+
+def global_view(n_global, begin, owned, ghost_ids, ghost):
+    """A rank's owned + ghost entries in GLOBAL numbering, NaN where the rank holds nothing (velocity: pass DoF ids)."""
+    g = np.full(n_global, np.nan)
+    g[begin:begin + len(owned)] = owned
+    g[np.asarray(ghost_ids, np.int64)] = ghost
+    return g
+
+
+def sum_over_ranks(values):
+    """`Utilities::MPI::sum` over the ranks of the running torch.distributed job (identity on one rank)."""
+    try:
+        import torch
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor(list(values), dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return tuple(float(v) for v in t)
+    except ImportError:
+        pass
+    return tuple(float(v) for v in values)
+
+
+def lift_drag(nx, ny, u, p, nu, rank=0, nranks=1):
     """(drag_force, lift_force): -sum over the obstacle faces of (nu (grad u + grad u^T) - p I) n JxW with the
-    fluid cell's outward normal, 4 Gauss points per face (NSSolverStationary.cpp:844-892)."""
+    fluid cell's outward normal, 4 Gauss points per face (NSSolverStationary.cpp:844-892).  With several ranks: the
+    share of the cells of this rank's strip (add the shares with `sum_over_ranks`)."""
     L = Lattice(nx, ny)
     u, p = np.asarray(u, float), np.asarray(p, float)
     if u.shape != (L.n_u,) or p.shape != (L.n_p,):
         raise ValueError("solution vectors do not match the mesh")
+    c0, c1 = cell_columns(nx, nranks)[rank:rank + 2]
     gx, gw = np.polynomial.legendre.leggauss(4)
     gx, gw = 0.5 * (gx + 1.0), 0.5 * gw
     drag = lift = 0.0
     faces = (((-1, 0), 0, 0.0), ((1, 0), 0, 1.0), ((0, -1), 1, 0.0), ((0, 1), 1, 1.0))   # neighbour, fixed axis, coordinate
     for i, j in zip(*np.nonzero(L.kept)):
+        if not c0 <= i < c1:
+            continue                          # another rank's cell
         for (di, dj), axis, fixed in faces:
             ni, nj = i + di, j + dj
             if not (0 <= ni < nx and 0 <= nj < ny) or L.kept[ni, nj]:
@@ -107,6 +144,8 @@ def lift_drag(nx, ny, u, p, nu):
                 f = -(s @ n) * jxw[q]
                 drag += f[0]
                 lift += f[1]
+    if not (np.isfinite(drag) and np.isfinite(lift)):
+        raise ValueError("lift/drag touched an entry this rank does not hold (owned + ghost DoFs)")
     return float(drag), float(lift)
 
 
@@ -116,12 +155,14 @@ def coefficients(drag_force, lift_force, inlet_u):
     return 2.0 * drag_force / (u_avg * u_avg * 0.1), 2.0 * lift_force / (u_avg * u_avg * 0.1)
 
 
-def write_vtu(directory, name, counter, nx, ny, u, p, n_digits=None, rank=0):
-    """`DataOut::write_vtu_with_pvtu_record` for one rank: `<name>_<counter>.<rank>.vtu` + `<name>_<counter>.pvtu`.
-    As deal.II's default `build_patches()` does, every cell is one patch with its own four vertices; point data
-    `velocity` (3 components, z = 0), `pressure`, `partitioning` (NSSolverStationary.cpp:769-796).  ASCII XML."""
+def write_vtu(directory, name, counter, nx, ny, u, p, n_digits=None, rank=0, nranks=1):
+    """`DataOut::write_vtu_with_pvtu_record`: this rank's piece `<name>_<counter>.<rank>.vtu` (its strip of cells)
+    and, on rank 0, the record `<name>_<counter>.pvtu` naming the pieces of all ranks.  As deal.II's default
+    `build_patches()` does, every cell is one patch with its own four vertices; point data `velocity` (3 components,
+    z = 0), `pressure`, `partitioning` (NSSolverStationary.cpp:769-796).  ASCII XML."""
     L = Lattice(nx, ny)
-    cells = np.argwhere(L.kept)
+    c0, c1 = cell_columns(nx, nranks)[rank:rank + 2]
+    cells = np.array([c for c in np.argwhere(L.kept) if c0 <= c[0] < c1]).reshape(-1, 2)
     pts, vel, prs = [], [], []
     for i, j in cells:
         for (a, b) in ((0, 0), (1, 0), (0, 1), (1, 1)):          # deal.II vertex order of a patch
@@ -130,6 +171,8 @@ def write_vtu(directory, name, counter, nx, ny, u, p, n_digits=None, rank=0):
             node = L.uid[3 * ix, 3 * iy]
             vel.append((u[2 * node], u[2 * node + 1], 0.0))
             prs.append(p[L.pid[2 * ix, 2 * iy]])
+    if not (np.isfinite(np.asarray(vel)).all() and np.isfinite(np.asarray(prs)).all()):
+        raise ValueError("VTU output touched an entry this rank does not hold (owned + ghost DoFs)")
     n_cells, n_pts = len(cells), len(pts)
     cnt = str(counter) if n_digits is None else str(counter).zfill(n_digits)
     piece = f"{name}_{cnt}.{rank}.vtu"
@@ -173,6 +216,9 @@ def write_vtu(directory, name, counter, nx, ny, u, p, n_digits=None, rank=0):
     os.makedirs(directory, exist_ok=True)
     with open(os.path.join(directory, piece), "w") as f:
         f.write(xml)
+    if rank != 0:
+        return os.path.join(directory, piece)
+    pieces = "\n".join(f'<Piece Source="{name}_{cnt}.{r}.vtu"/>' for r in range(nranks))
     pvtu = f"""<?xml version="1.0"?>
 <VTKFile type="PUnstructuredGrid" version="0.1" byte_order="LittleEndian">
 <PUnstructuredGrid GhostLevel="0">
@@ -184,7 +230,7 @@ def write_vtu(directory, name, counter, nx, ny, u, p, n_digits=None, rank=0):
 <PPoints>
 <PDataArray type="Float64" NumberOfComponents="3"/>
 </PPoints>
-<Piece Source="{piece}"/>
+{pieces}
 </PUnstructuredGrid>
 </VTKFile>
 """
