@@ -3,6 +3,7 @@
 set -u
 out=$1; shift
 repo=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $repo/$out
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "$@"; do

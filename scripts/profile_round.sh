@@ -13,7 +13,9 @@ echo "bench K20 done"
 timeout -k 10 500 python3 bench.py --no-cpu-baseline > $out/bench_line_default_K58.json 2> $out/bench_line_default_K58.err || echo "bench K58 failed"
 echo "bench K58 done"
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $repo/$out/kt --output-format csv -- python3 $repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $repo/$out/bench_line_under_rocprof_K20.json 2> $repo/$out/rocprof_kt.err) || echo "kernel trace failed"
+rm -f $out/kt/*/*_kernel_trace.csv   # (70 MB; the statistics file is what is kept)
 echo "kernel trace done"
+mkdir -p $out/pmc
 bash scripts/pmc_passes.sh $out/pmc "FETCH_SIZE" "WRITE_SIZE"
 f=$(ls $out/pmc/pass1/*/*counter_collection.csv 2>/dev/null | head -1)
 w=$(ls $out/pmc/pass2/*/*counter_collection.csv 2>/dev/null | head -1)
