@@ -62,7 +62,8 @@ class NoConvergence(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libnsk_hip.so")
+    # NSK_HIP_LIBRARY: another build of the same library (A/B measurements of compile-time variants)
+    return os.environ.get("NSK_HIP_LIBRARY") or os.path.join(_HERE, "libnsk_hip.so")
 
 
 def lib() -> C.CDLL:
