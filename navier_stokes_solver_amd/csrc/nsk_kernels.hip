@@ -157,8 +157,17 @@ __device__ __forceinline__ void stream_products(const int *__restrict__ col, con
 }
 
 __device__ __forceinline__ double row_sum_lds(const double *prod, int b, int e, int lane) {
+  // four LDS reads in flight per trip, added in the order of the plain loop (same bits, a quarter of the latency)
   double s = 0.0;
-  for (int j = b + lane; j < e; j += RG) s += prod[j];
+  int j = b + lane;
+  for (; j + 3 * RG < e; j += 4 * RG) {
+    const double a0 = prod[j], a1 = prod[j + RG], a2 = prod[j + 2 * RG], a3 = prod[j + 3 * RG];
+    s += a0;
+    s += a1;
+    s += a2;
+    s += a3;
+  }
+  for (; j < e; j += RG) s += prod[j];
   return subwave_sum<RG>(s);
 }
 
@@ -465,25 +474,28 @@ __device__ __forceinline__ void sf_store(double *p, double v) {
 __device__ __forceinline__ unsigned long long sf_peek(const double *p) {
   return (unsigned long long)__double_as_longlong(*p);
 }
-// re-poll until the producer's store is visible; bounded
+// One more round of polling allowed?  Bounded; once any wait has given up, nobody waits any more: the solve then
+// finishes quickly on garbage (NaNs end the Krylov loops) and the host reports the error, instead of timing out
+// again and again.  The error word is looked at every 1024 rounds only — a load of it in front of the first re-poll
+// would put a memory round trip on the critical path of every colour step.
+__device__ __forceinline__ bool sf_keep_polling(int &spins, int *err) {
+  if (++spins > kMaxSpins || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+  }
+  if (spins > 1) __builtin_amdgcn_s_sleep(1);
+  return true;
+}
+// re-poll one word until the producer's store is visible (window kernels)
 __device__ __forceinline__ double sf_wait(const double *p, unsigned long long first, int *err) {
   unsigned long long v = first;
   int spins = 0;
-  while (v == kSentinel) {
-    // once any wait has given up, nobody waits any more: the solve then finishes quickly on garbage (NaNs
-    // end the Krylov loops) and the host reports the error, instead of timing out again and again
-    if (++spins > kMaxSpins || ((spins & 1023) == 1 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
-    }
-    __builtin_amdgcn_s_sleep(1);
-    v = sf_load(p);
-  }
+  while (v == kSentinel && sf_keep_polling(spins, err)) v = sf_load(p);
   return __longlong_as_double((long long)v);
 }
 
 template <int LOWER, int KIND, int NNZ>
-__global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, int wrong_order,
+__global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, int nb, int wrong_order,
                                                             const double *__restrict__ dinv,
                                                             const int *__restrict__ perm,
                                                             const double *__restrict__ rhs,
@@ -507,38 +519,74 @@ __global__ __launch_bounds__(BLK) void tri_stream_sf_kernel(TriHalf M, int nb, i
   const bool have = r < r1;
   int jb = 0, je = 0, i = 0;
   double own = 0.0, dv = 1.0;
-  if (have) {
-    jb = M.rowptr[r] - k0;
-    je = M.rowptr[r + 1] - k0;
-    i = perm[r];
-    own = LOWER ? rhs[i] : ownv[i];
-    if (KIND == 1 || !LOWER) dv = dinv[r];
-  }
   {
     constexpr int U = NNZ / BLK;
-    int c[U];
-    double v[U];
-    unsigned long long g[U];
+    const bool any = k0 < k1;   // (uniform) false: rows without entries; every lane then reads valid stand-in words
+    const int kz = any ? k0 : 0;
+    const int *colp = any ? M.col : M.rowptr;
+    const double *valp = any ? M.val : w;
+    unsigned o[U];   // byte offset of the gathered entry (32 bits on top of the uniform base)
+    unsigned open = 0;   // bit u: entry u still shows the sentinel
+    const char *wb = reinterpret_cast<const char *>(w);
+    {
+      double v[U];
+      unsigned long long g[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = k0 + (int)threadIdx.x + u * BLK;
-      const bool ok = k < k1;
-      c[u] = ok ? __builtin_nontemporal_load(M.col + k) : -1;
-      v[u] = ok ? __builtin_nontemporal_load(M.val + k) : 0.0;
+      for (int u = 0; u < U; ++u) {
+        // loads without branches or arithmetic on their results: all 2 U stay in flight.  A tail lane re-reads the
+        // run's first entry and is masked out below
+        const int k = k0 + (int)threadIdx.x + u * BLK, kk = k < k1 ? k : kz;
+        o[u] = (unsigned)__builtin_nontemporal_load(colp + kk);
+        v[u] = __builtin_nontemporal_load(valp + kk);
+      }
+      // row bounds, perm and the row's own right-hand side (which hangs on perm[r]) are asked for AFTER the streaming
+      // loads have been issued, so that no wait stands between the descriptor and the stream: three dependent trips
+      // to memory (descriptor | stream, bounds, perm | gathers, own), not four
+      if (have) {
+        jb = M.rowptr[r] - k0;
+        je = M.rowptr[r + 1] - k0;
+        i = perm[r];
+        if (KIND == 1 || !LOWER) dv = dinv[r];
+        own = LOWER ? rhs[i] : ownv[i];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        o[u] <<= 3;
+        g[u] = sf_peek(reinterpret_cast<const double *>(wb + o[u]));
+      }
+      // first look done: the product of every entry whose value was there goes to LDS now; an open entry parks its
+      // matrix value in the same LDS word, so that only its offset stays in registers while it is polled
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = (int)threadIdx.x + u * BLK;
+        const bool op = g[u] == kSentinel && k < k1 - k0;
+        open |= op ? 1u << u : 0u;
+        if (k < k1 - k0) prod[k] = op ? v[u] : v[u] * __longlong_as_double((long long)g[u]);
+      }
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) g[u] = c[u] >= 0 ? sf_peek(w + c[u]) : 0ull;
     if (dbg) {
-      int waiting = 0;
-#pragma unroll
-      for (int u = 0; u < U; ++u) waiting += (c[u] >= 0 && g[u] == kSentinel) ? 1 : 0;   // (uses the loads: they have landed)
-      if (waiting) atomicAdd(reinterpret_cast<unsigned long long *>(dbg) + (size_t)blockIdx.x * 16 + 5, (unsigned long long)waiting);
+      if (open) atomicAdd(reinterpret_cast<unsigned long long *>(dbg) + (size_t)blockIdx.x * 16 + 5, (unsigned long long)__popc(open));
       stamp(1);
     }
+    // open entries: re-read at agent scope until the producers' stores are visible, ALL of a thread's open entries
+    // in flight together (one memory round trip per round, not one per entry)
+    for (int spins = 0; open != 0u;) {
+      if (!sf_keep_polling(spins, err)) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = k0 + (int)threadIdx.x + u * BLK;
-      if (k < k1) prod[k - k0] = v[u] * sf_wait(w + c[u], g[u], err);
+        for (int u = 0; u < U; ++u)
+          if (open >> u & 1u) prod[(int)threadIdx.x + u * BLK] = __longlong_as_double((long long)kSentinel);
+        break;
+      }
+      unsigned long long t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (open >> u & 1u) t[u] = sf_load(reinterpret_cast<const double *>(wb + o[u]));
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if ((open >> u & 1u) && t[u] != kSentinel) {
+          prod[(int)threadIdx.x + u * BLK] *= __longlong_as_double((long long)t[u]);
+          open &= ~(1u << u);
+        }
     }
   }
   stamp(2);
@@ -628,10 +676,7 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int w
     }
   }
   __syncthreads();
-  double s0 = 0.0, s1 = 0.0;
-  for (int j = jb + lane; j < je; j += RG) { s0 += p0[j]; s1 += p1[j]; }
-  s0 = subwave_sum<RG>(s0);
-  s1 = subwave_sum<RG>(s1);
+  const double s0 = row_sum_lds(p0, jb, je, lane), s1 = row_sum_lds(p1, jb, je, lane);
   if (have && lane == 0) {
     double v0, v1;
     if (LOWER) {
