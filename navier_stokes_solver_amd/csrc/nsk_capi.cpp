@@ -476,14 +476,21 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
   // unsteady aSIMPLE (NSSolver.hpp:294-350): ILU applies only
   tri_apply_sampled(tF, 20, su.own, du.own);
   halo(0, du);
-  vec_copy(s(), np, spv.own, tmp_p);
-  spmv_nohalo(B, du, tmp_p, 1);                          // tmp_p = src_p + B~ u   (vmult_add)
+  spmv_nohalo(B, du, tmp_p, 1, spv.own);                 // tmp_p = src_p + B~ u   (vmult_add)
   tri_apply_sampled(*tP, 21, tmp_p, dp.own);
-  vec_mul(s(), nu, D, du.own);                           // u .*= D
   vec_scale(s(), np, sref(1.0 / alpha), dp.own);         // p /= alpha
   halo(1, dp);
-  spmv_nohalo(Bt, dp, tmp_u, 0);
-  vec_sub_then_mul(s(), nu, tmp_u, Dinv, du.own);        // u = (u - B~^T p) .* D^-1
+  Csr &BT = Bt;
+  if (BT.blk_ok && use_stream && use_bsr && BT.blk_R == 2 && BT.blk_C == 1) {
+    // u .*= D ; u = (u - B~^T p) .* D^-1 in the epilogue of the B~^T product (same roundings, two passes fewer)
+    nsk::spmv_blk_stream(s(), BT.blk_view(), 2, 1, BT.blk_rowblk.p, BT.blk_nblk, dp.own, dp.ghost, du.own, D, Dinv);
+    ++ctx.st.spmv_calls;
+    ctx.st.spmv_bytes += (double)BT.spmv_bytes() + 24.0 * nu;
+  } else {
+    vec_mul(s(), nu, D, du.own);                         // u .*= D
+    spmv_nohalo(Bt, dp, tmp_u, 0);
+    vec_sub_then_mul(s(), nu, tmp_u, Dinv, du.own);      // u = (u - B~^T p) .* D^-1
+  }
 }
 
 int H::solve_once(int solver, double tol, int max_iter, int *iters, double *final_res) {
@@ -729,6 +736,7 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
       }
       break;
     case NSK_IOPT_TRI_WINDOW: h->tri_window = v != 0.0; break;
+    case NSK_IOPT_FUSED_MGS: h->ctx.fused_mgs = v != 0.0; break;
     case NSK_IOPT_TINY_BYTES: h->tF.tiny_bytes = h->tMp.tiny_bytes = h->tS.tiny_bytes = v; break;
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
     case NSK_OPT_VELOCITY_AMG: h->velocity_amg = v != 0.0; break;

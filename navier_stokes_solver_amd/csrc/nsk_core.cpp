@@ -299,6 +299,35 @@ void Ctx::multi_axpy(int n, double *w, double *const *v, int m, int coef_slot, i
   st.blas1_bytes += 8.0 * n * (m + 2);
 }
 
+bool Ctx::mgs_sweep(int n, double *w, double *const *v, int nv, int so) {
+  if (!fused_mgs || comm.active() || nv < 1 || nv > kMgsMaxVecs) return false;
+  const int G = std::min(n_cu, kMgsThreads);
+  if ((long)n > (long)G * kMgsThreads * 12) return false;   // 12 entries per thread: 3.1 M rows on 256 CUs
+  const size_t tab = (size_t)(kMgsMaxVecs + 1) * G;
+  if (mgs_grid != G) {
+    mgs_tables.alloc(2 * tab);
+    vec_fill_sentinel(stream, (int)(2 * tab), mgs_tables.p);
+    mgs_err.alloc(1);
+    NSK_HIP(hipMemsetAsync(mgs_err.p, 0, sizeof(int), stream));
+    mgs_grid = G;
+    mgs_parity = 0;
+  }
+  MgsArgs A{};
+  A.n = n;
+  A.nv = nv;
+  for (int k = 0; k < nv; ++k) A.v[k] = v[k];
+  A.aux = w;
+  A.table = mgs_tables.p + (size_t)mgs_parity * tab;
+  A.rearm = mgs_tables.p + (size_t)(1 - mgs_parity) * tab;
+  A.out = slot(so);
+  A.err = mgs_err.p;
+  if (!nsk::mgs_sweep(stream, A, G)) return false;
+  mgs_parity = 1 - mgs_parity;
+  st.reductions += nv + 1;
+  st.blas1_bytes += 8.0 * n * (nv + 2);
+  return true;
+}
+
 void Ctx::spmv(Csr &A, Space &colspace, const DVec &x, double *y, int mode, const double *z) {
   comm.halo_exchange(colspace, x, stream);
   if (A.stream_ok) nsk::spmv_stream(stream, A.view(), A.rowblk.p, A.nblk, A.even_rows, x.own, x.ghost, y, mode, z);

@@ -226,6 +226,14 @@ struct Ctx {
   void multi_axpy(int n, double *w, double *const *v, int m, int coef_slot, int norm_slot);
   void cg_update(int n, SRef a, const double *d, const double *h, double *x, double *g, int slot_out);
   void dot3(int n, const double *r, const double *u, const double *w, int slot_out);   // r.u, w.u, r.r: one pass, one all-reduce
+  // the whole modified Gram-Schmidt chain of one Arnoldi step in one launch (single rank, vector short enough to sit
+  // in registers): slots[so + i] = h_i, [so + nv] = |w|^2, [so + nv + 1] = |w|, [so + nv + 2] = 1 if it timed out.
+  // false: not applicable, nothing done — the caller runs the chain of dot / axpy_dot launches.
+  bool mgs_sweep(int n, double *w, double *const *v, int nv, int slot_out);
+  bool fused_mgs = true;   // NSK_IOPT_FUSED_MGS
+  DBuf<double> mgs_tables;
+  DBuf<int> mgs_err;
+  int mgs_parity = 0, mgs_grid = 0;
   void spmv(Csr &A, Space &colspace, const DVec &x, double *y, int mode = 0, const double *z = nullptr);
 };
 

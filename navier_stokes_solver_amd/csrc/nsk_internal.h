@@ -13,8 +13,10 @@ enum {
                                 // 1200x400: 0.256 vs 0.249 ms for S); 0 (default): CSR-stream kernel
   NSK_IOPT_TRI_WINDOW = 103,    // 1: scalar triangular factors (S, Mp) on the window format with ONE persistent launch for
                                 // both halves (measured slower than the CSR halves at 1200x400: DESIGN.md); default 0
-  NSK_IOPT_TINY_BYTES = 102     // triangular factors below this many bytes (default 4e6) are solved by ONE workgroup walking
+  NSK_IOPT_TINY_BYTES = 102,    // triangular factors below this many bytes (default 4e6) are solved by ONE workgroup walking
                                 // all levels; the tests set 0 to run the streamed kernels on small meshes
+  NSK_IOPT_FUSED_MGS = 106      // 1 (default): the modified Gram-Schmidt chain of an Arnoldi step in ONE launch when the
+                                // vector fits the registers of the co-resident grid (single rank); 0: one launch per link
 };
 
 #ifdef __cplusplus

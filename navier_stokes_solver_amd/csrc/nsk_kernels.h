@@ -64,9 +64,10 @@ struct BlkView {
   const double *val;    // R*C per block, row-major
 };
 constexpr int kBlkMax = 1024;  // blocks per workgroup (both matrices together in the fused kernel)
-// y = A x on an R x C blocked matrix (R, C in {1,2}); rowblk = runs of block rows
+// y = A x on an R x C blocked matrix (R, C in {1,2}); rowblk = runs of block rows.
+// epi_d != null (R x C = 2 x 1 only): y = ((y .* epi_d) - A x) .* epi_dinv instead (aSIMPLE's velocity correction)
 void spmv_blk_stream(hipStream_t s, const BlkView &A, int R, int C, const int *rowblk, int nblk, const double *x_own,
-                     const double *x_ghost, double *y);
+                     const double *x_ghost, double *y, const double *epi_d = nullptr, const double *epi_dinv = nullptr);
 // y = A xa + B xb with A 2x2-blocked and B 2x1-blocked over the same block rows (velocity block row of J)
 void spmv_blk_fused22_21(hipStream_t s, const BlkView &A, const double *xa_own, const double *xa_ghost,
                          const BlkView &B, const double *xb_own, const double *xb_ghost, const int *rowblk, int nblk,
@@ -105,6 +106,18 @@ struct VecPack {
 void vec_multi_dot(hipStream_t s, const ReduceWs &ws, int n, const double *w, const VecPack &P, int m, double *out);
 void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const VecPack &P, int m, const double *h,
                     double *norm_out);
+// One-launch modified Gram-Schmidt sweep (nsk_kernels.hip: mgs_sweep_kernel): out[i] = h_i (i < nv), out[nv] = |aux|^2,
+// out[nv+1] = |aux|, out[nv+2] = 1 if a wait gave up (sums invalid), else 0.  `table` / `rearm`: two tables of (kMgsMaxVecs + 1) x G words, the first holding the sentinel in
+// all rows (each sweep arms the other one for its successor).  Returns false (nothing launched) when the
+// vector is too long for G co-resident workgroups to keep in registers.
+constexpr int kMgsThreads = 1024, kMgsMaxVecs = 32;
+struct MgsArgs {
+  int n, nv;
+  const double *v[kMgsMaxVecs];
+  double *aux, *table, *rearm, *out;
+  int *err;
+};
+bool mgs_sweep(hipStream_t s, const MgsArgs &A, int G);
 // single-reduction (Chronopoulos-Gear) CG building blocks: see SolverCG::solve_fused
 void vec_dot3(hipStream_t s, const ReduceWs &ws, int n, const double *r, const double *u, const double *w, double *out);
 void cg_fused_scalars(hipStream_t s, double *sc7, int first);

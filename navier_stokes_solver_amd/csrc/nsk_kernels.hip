@@ -68,7 +68,7 @@ __global__ __launch_bounds__(BLK) void spmv_kernel(CsrView A, const double *__re
   s = subwave_sum<LPR>(s);
   if (lane == 0 && row < A.n_rows) {
     if (MODE == 0) y[row] = s;
-    else if (MODE == 1) y[row] += s;
+    else if (MODE == 1) y[row] = (z ? z[row] : y[row]) + s;   // vmult_add; z given: y = z + A x without a copy first
     else y[row] = z[row] - s;
   }
 }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(BLK) void spmv_stream_kernel(CsrView A, const int *
   if (have) {
     jb = A.rowptr[r] - k0;
     je = A.rowptr[r + 1] - k0;
-    if (MODE == 1) zv = y[r];
+    if (MODE == 1) zv = z ? z[r] : y[r];
     if (MODE == 2) zv = z[r];
   }
   stream_products<VEC>(A.col, A.val, k0, k1, A.n_own_cols, xo, xg, prod);
@@ -275,10 +275,13 @@ __device__ __forceinline__ void blk_products(const BlkView &A, int k0, int k1, c
   }
 }
 
-template <int R, int C>
+// EPI = 1 (aSIMPLE's velocity correction, NSSolver.hpp:343-349, in the kernel's epilogue instead of two more passes
+// over the vector): y = ((y .* d) - A x) .* dinv, with the products rounded one by one like the separate vector calls.
+template <int R, int C, int EPI>
 __global__ __launch_bounds__(BLK) void spmv_blk_kernel(BlkView A, const int *__restrict__ rowblk,
                                                        const double *__restrict__ xo, const double *__restrict__ xg,
-                                                       double *__restrict__ y) {
+                                                       double *__restrict__ y, const double *__restrict__ d,
+                                                       const double *__restrict__ dinv) {
   __shared__ double p0[kBlkMax];
   __shared__ double p1[R == 2 ? kBlkMax : 1];
   const int r0 = rowblk[blockIdx.x], r1 = rowblk[blockIdx.x + 1];
@@ -294,6 +297,13 @@ __global__ __launch_bounds__(BLK) void spmv_blk_kernel(BlkView A, const int *__r
   s0 = subwave_sum<RG>(s0);
   if (R == 2) s1 = subwave_sum<RG>(s1);
   if (have && lane == 0) {
+    if (EPI == 1 && R == 2) {
+      const double2 yo = *reinterpret_cast<const double2 *>(y + 2 * (size_t)r);
+      const double2 dd = *reinterpret_cast<const double2 *>(d + 2 * (size_t)r);
+      const double2 di = *reinterpret_cast<const double2 *>(dinv + 2 * (size_t)r);
+      s0 = __dmul_rn(__dsub_rn(__dmul_rn(yo.x, dd.x), s0), di.x);
+      s1 = __dmul_rn(__dsub_rn(__dmul_rn(yo.y, dd.y), s1), di.y);
+    }
     if (R == 2) *reinterpret_cast<double2 *>(y + 2 * (size_t)r) = make_double2(s0, s1);
     else y[r] = s0;
   }
@@ -774,7 +784,7 @@ __global__ __launch_bounds__(BLK) void spmv_win_kernel(WinView M, const double *
     if (lane == 0) {
       const int r = r0 + rho;
       if (MODE == 0) y[r] = sum;
-      else if (MODE == 1) y[r] += sum;
+      else if (MODE == 1) y[r] = (z ? z[r] : y[r]) + sum;
       else y[r] = z[r] - sum;
     }
   }
@@ -1354,9 +1364,13 @@ void tri_blk_level(hipStream_t s, const TriBlk &M, int b0, int b1, int lower, in
 }
 
 void spmv_blk_stream(hipStream_t s, const BlkView &A, int R, int C, const int *rowblk, int nblk, const double *xo,
-                     const double *xg, double *y) {
+                     const double *xg, double *y, const double *epi_d, const double *epi_dinv) {
   if (nblk <= 0) return;
-#define NSK_BK(RR, CC) hipLaunchKernelGGL((spmv_blk_kernel<RR, CC>), dim3(nblk), dim3(BLK), 0, s, A, rowblk, xo, xg, y)
+  if (epi_d) {   // only built for the (2 x 1) block shape of the (0,1) block
+    hipLaunchKernelGGL((spmv_blk_kernel<2, 1, 1>), dim3(nblk), dim3(BLK), 0, s, A, rowblk, xo, xg, y, epi_d, epi_dinv);
+    return;
+  }
+#define NSK_BK(RR, CC) hipLaunchKernelGGL((spmv_blk_kernel<RR, CC, 0>), dim3(nblk), dim3(BLK), 0, s, A, rowblk, xo, xg, y, nullptr, nullptr)
   if (R == 2 && C == 2) NSK_BK(2, 2);
   else if (R == 2 && C == 1) NSK_BK(2, 1);
   else if (R == 1 && C == 2) NSK_BK(1, 2);
@@ -1576,6 +1590,106 @@ void vec_cg_update(hipStream_t s, const ReduceWs &ws, int n, SRef a, const doubl
     g[i] = v;
     return v * v;
   });
+}
+
+// ------------------------------------------------------------------ one-launch modified Gram-Schmidt sweep
+// h_i = aux . v_i ; aux -= h_i v_i  (i = 0 .. nv-1, in this order) ; then |aux|.  deal.II's orthogonalisation
+// (SolverFGMRES / SolverGMRES) is a chain of nv + 1 dependent reductions: as separate launches each link reads
+// aux and two basis vectors again.  Here the whole chain is ONE launch of G co-resident workgroups: every thread
+// keeps its E entries of aux in registers for the whole sweep, reads each v_i exactly once (the next one is
+// fetched while the current link's sum is formed) and the grid-wide sums go through a table of data-tagged words
+// (one per link and workgroup, written once, polled by one thread each — the hand-off of the triangular solves),
+// summed in a fixed order by every workgroup: deterministic, and every workgroup holds the same h_i.
+// Bytes: (nv + 2) n x 8 instead of ~(4 nv + 3) n x 8; launches: 1 instead of nv + 1.
+template <int E>
+__global__ __launch_bounds__(kMgsThreads) void mgs_sweep_kernel(MgsArgs A) {
+  __shared__ double wsum[kMgsThreads / 64], gsum[kMgsThreads / 64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, G = (int)gridDim.x;
+  const unsigned stride = (unsigned)G * kMgsThreads, base = blockIdx.x * kMgsThreads + t, n = (unsigned)A.n;   // (n < 2^31)
+  constexpr bool PF = E <= 8;   // room in the register file to fetch v_{k+1} while link k is summed
+  double a[E], vi[E], vn[PF ? E : 1];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const unsigned i = base + e * stride;
+    a[e] = i < n ? A.aux[i] : 0.0;
+    vi[e] = (i < n && A.nv > 0) ? A.v[0][i] : 0.0;
+    if (PF) vn[e] = 0.0;
+  }
+  // arm the table the NEXT sweep will use (the one before the previous sweep has long been consumed)
+  if (t <= kMgsMaxVecs) reinterpret_cast<unsigned long long *>(A.rearm)[(size_t)t * G + blockIdx.x] = kSentinel;
+  bool dead = false;
+  for (int k = 0; k <= A.nv; ++k) {   // link nv: the norm of what is left
+    if (PF && k + 1 < A.nv) {
+      const double *nx = A.v[k + 1];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const unsigned i = base + e * stride;
+        vn[e] = i < n ? nx[i] : 0.0;
+      }
+    }
+    double p = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) p += a[e] * (k < A.nv ? vi[e] : a[e]);
+    p = subwave_sum<64>(p);
+    if (lane == 0) wsum[w] = p;
+    __syncthreads();
+    if (t == 0) {
+      double sblk = 0.0;
+      for (int q = 0; q < kMgsThreads / 64; ++q) sblk += wsum[q];
+      sf_store(A.table + (size_t)k * G + blockIdx.x, sblk);
+    }
+    double q = 0.0;
+    if (t < G && !dead) {
+      const double *src = A.table + (size_t)k * G + t;
+      unsigned long long v = sf_load(src);
+      for (int spins = 0; v == kSentinel;) {
+        if (!sf_keep_polling(spins, A.err)) { dead = true; break; }
+        v = sf_load(src);
+      }
+      q = __longlong_as_double((long long)v);
+    }
+    q = subwave_sum<64>(q);
+    if (lane == 0) gsum[w] = q;
+    __syncthreads();
+    double h = 0.0;
+    for (int qq = 0; qq < (G + 63) / 64; ++qq) h += gsum[qq];
+    if (k < A.nv) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) a[e] -= h * vi[e];
+      if (PF) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) vi[e] = vn[e];
+      } else if (k + 1 < A.nv) {
+        const double *nx = A.v[k + 1];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const unsigned i = base + e * stride;
+          vi[e] = i < n ? nx[i] : 0.0;
+        }
+      }
+      if (blockIdx.x == 0 && t == 0) A.out[k] = h;
+    } else if (blockIdx.x == 0 && t == 0) {
+      A.out[A.nv] = h;
+      A.out[A.nv + 1] = sqrt(fabs(h));
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const unsigned i = base + e * stride;
+    if (i < n) A.aux[i] = a[e];
+  }
+  // a wait that gave up (workgroup 0 polls every other workgroup's word, so it notices): the caller must not use the sums
+  const int gave_up = __syncthreads_or(dead ? 1 : 0);
+  if (blockIdx.x == 0 && t == 0) A.out[A.nv + 2] = gave_up ? 1.0 : 0.0;
+}
+
+bool mgs_sweep(hipStream_t s, const MgsArgs &A, int G) {
+  const long per = ((long)A.n + (long)G * kMgsThreads - 1) / ((long)G * kMgsThreads);
+  if (G < 1 || G > kMgsThreads || A.nv > kMgsMaxVecs || per > 12) return false;
+  if (per <= 4) hipLaunchKernelGGL((mgs_sweep_kernel<4>), dim3(G), dim3(kMgsThreads), 0, s, A);
+  else if (per <= 8) hipLaunchKernelGGL((mgs_sweep_kernel<8>), dim3(G), dim3(kMgsThreads), 0, s, A);
+  else hipLaunchKernelGGL((mgs_sweep_kernel<12>), dim3(G), dim3(kMgsThreads), 0, s, A);
+  return true;
 }
 
 // out[0] = r.u, out[1] = w.u, out[2] = r.r in ONE pass (single-reduction CG)

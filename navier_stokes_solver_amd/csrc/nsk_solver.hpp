@@ -231,6 +231,7 @@ struct SolverFGMRES : SolverBase {
         if (!v[j]) v[j] = pool.get(false);
         if (!z[j]) z[j] = pool.get(true);  // zero on first use, stale (previous cycle) afterwards
         DVec vj = pool.view(v[j]), zj = pool.view(z[j]);
+        int mgs_flag = -1;
         if (a != 0.0 && std::isfinite(1.0 / a)) vec_equ(s(), n, sref(1.0, nullptr, ctx.slot(a_slot)), aux.own, vj.own);
         else vec_set(s(), n, vj.own, 0.0);
         P(zj, vj);
@@ -242,6 +243,9 @@ struct SolverFGMRES : SolverBase {
           for (int i0 = 0; i0 <= j; i0 += 8) ctx.multi_dot(n, aux.own, &v[i0], std::min(8, j + 1 - i0), HS + i0);
           for (int i0 = 0; i0 <= j; i0 += 8)
             ctx.multi_axpy(n, aux.own, &v[i0], std::min(8, j + 1 - i0), HS + i0, i0 + 8 > j ? HS + j + 1 : -1);
+        } else if (ctx.mgs_sweep(n, aux.own, v.data(), j + 1, HS)) {
+          // modified Gram-Schmidt, the whole chain in one launch (Ctx::mgs_sweep)
+          mgs_flag = HS + j + 3;
         } else {
           // modified Gram-Schmidt with add_and_dot; all coefficients stay on the device
           ctx.dot(n, aux.own, v[0], HS);
@@ -249,7 +253,8 @@ struct SolverFGMRES : SolverBase {
             ctx.axpy_dot(n, sref(-1.0, ctx.slot(HS + i - 1)), v[i - 1], aux.own, v[i], HS + i);
           ctx.axpy_norm2(n, sref(-1.0, ctx.slot(HS + j)), v[j], aux.own, HS + j + 1);
         }
-        const double *h = ctx.read_slots(HS, j + 3);
+        const double *h = ctx.read_slots(HS, j + 4);
+        if (mgs_flag >= 0 && h[j + 3] != 0.0) throw Error(-71, "one-launch Gram-Schmidt sweep timed out (workgroups not co-resident?)");
         for (int i = 0; i <= j; ++i) H[i * kBasis + j] = h[i];
         H[(j + 1) * kBasis + j] = a = h[j + 2];
         a_slot = HS + j + 2;
@@ -308,19 +313,27 @@ struct SolverGMRES : SolverBase {
         dim = inner + 1;
         const bool consider = !re_orth && (inner % 5 == 4);
         if (consider) ctx.norm2(n, vv.own, NS);
-        ctx.dot(n, vv.own, tmp[0], HS);
-        for (int i = 1; i < dim; ++i) ctx.axpy_dot(n, sref(-1.0, ctx.slot(HS + i - 1)), tmp[i - 1], vv.own, tmp[i], HS + i);
-        ctx.axpy_norm2(n, sref(-1.0, ctx.slot(HS + dim - 1)), tmp[dim - 1], vv.own, HS + dim);
-        const double *hh = ctx.read_slots(NS, 2 + dim + 2);
+        const bool one_launch = ctx.mgs_sweep(n, vv.own, tmp.data(), dim, HS);
+        if (!one_launch) {
+          ctx.dot(n, vv.own, tmp[0], HS);
+          for (int i = 1; i < dim; ++i) ctx.axpy_dot(n, sref(-1.0, ctx.slot(HS + i - 1)), tmp[i - 1], vv.own, tmp[i], HS + i);
+          ctx.axpy_norm2(n, sref(-1.0, ctx.slot(HS + dim - 1)), tmp[dim - 1], vv.own, HS + dim);
+        }
+        const double *hh = ctx.read_slots(NS, 2 + dim + 3);
+        if (one_launch && hh[2 + dim + 2] != 0.0) throw Error(-71, "one-launch Gram-Schmidt sweep timed out (workgroups not co-resident?)");
         const double norm_start = hh[1];
         for (int i = 0; i < dim; ++i) h[i] = hh[2 + i];
         double snorm = hh[2 + dim + 1];
         if (consider && !(snorm > 10.0 * norm_start * std::sqrt(std::numeric_limits<double>::epsilon()))) re_orth = true;
         if (re_orth) {
-          ctx.dot(n, vv.own, tmp[0], HS);
-          for (int i = 1; i < dim; ++i) ctx.axpy_dot(n, sref(-1.0, ctx.slot(HS + i - 1)), tmp[i - 1], vv.own, tmp[i], HS + i);
-          ctx.axpy_norm2(n, sref(-1.0, ctx.slot(HS + dim - 1)), tmp[dim - 1], vv.own, HS + dim);
-          const double *h2 = ctx.read_slots(HS, dim + 2);
+          const bool again = ctx.mgs_sweep(n, vv.own, tmp.data(), dim, HS);
+          if (!again) {
+            ctx.dot(n, vv.own, tmp[0], HS);
+            for (int i = 1; i < dim; ++i) ctx.axpy_dot(n, sref(-1.0, ctx.slot(HS + i - 1)), tmp[i - 1], vv.own, tmp[i], HS + i);
+            ctx.axpy_norm2(n, sref(-1.0, ctx.slot(HS + dim - 1)), tmp[dim - 1], vv.own, HS + dim);
+          }
+          const double *h2 = ctx.read_slots(HS, dim + 3);
+          if (again && h2[dim + 2] != 0.0) throw Error(-71, "one-launch Gram-Schmidt sweep timed out (workgroups not co-resident?)");
           for (int i = 0; i < dim; ++i) h[i] += h2[i];
           snorm = h2[dim + 1];
         }

@@ -614,3 +614,31 @@ def test_one_rocm_stack_per_process():
     hip = {p for p in libs if os.path.basename(p).startswith("libamdhip64.so")}
     rccl = {p for p in libs if os.path.basename(p).startswith("librccl.so")}
     assert len(hip) == 1 and len(rccl) <= 1, (hip, rccl)
+
+
+@pytest.mark.parametrize("mesh,solver", [((60, 20), 1), ((60, 20), 0), ((400, 130), 1), ((600, 200), 1)])
+def test_one_launch_gram_schmidt_matches_the_chain_of_launches(mesh, solver):
+    """The modified Gram-Schmidt chain of an Arnoldi step (deal.II SolverFGMRES / SolverGMRES: h_i = w.v_i, w -= h_i v_i,
+    one after the other) runs as ONE launch when the vector fits the registers of the co-resident grid (4, 8 or 12
+    entries per thread: the three meshes), otherwise as one launch per link.  Both do the same arithmetic up to the
+    summation order inside a dot product: the residuals SolverControl sees over the first 24 steps agree to 1e-9, and
+    so does the solution after them (unsteady aSIMPLE: ILU applies only, no inner iterations that could amplify)."""
+    S = _S()
+    from navier_stokes_solver_amd import problem as P
+    pr = P.generate(mesh[0], mesh[1], nu=1.0 / 91.0, mode=1, state=1, inv_dt=100.0, U=0.3)
+    out = []
+    for fused in (1, 0):
+        ls = S.LinearSolver()
+        try:
+            ls.set_option(S.OPT_TRI_ORDERING, 1)
+            ls.set_option(S.IOPT_FUSED_MGS, fused)
+            ls.set_problem(pr)
+            ls.setup_preconditioner(S.ASIMPLE, S.UNSTEADY, 0.5)
+            xu, xp, _, _, _ = ls.solve(solver, 0.0, 24, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+            out.append((np.concatenate([xu, xp]), ls.history()))
+        finally:
+            ls.close()
+    (x1, h1), (x0, h0) = out
+    assert len(h1) == len(h0) >= 24
+    assert np.abs(h1 - h0).max() <= 1e-9 * np.abs(h0).max()
+    assert rel_err(x1, x0) <= 1e-9
