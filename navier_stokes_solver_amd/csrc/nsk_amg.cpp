@@ -2,6 +2,8 @@
 #include "nsk_amg.hpp"
 
 #include <omp.h>
+#include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
 #include <chrono>
@@ -254,9 +256,40 @@ double now_ms() {
 
 }  // namespace
 
+// lambda = kEigBoost x ||(D^-1 A)^k x0|| / ||(D^-1 A)^(k-1) x0|| after kEigIts steps, x0(i) = start_entry(i), on the device
+double Amg::estimate_lambda_device(AmgLevel &L) {
+  const int n = L.n;
+  hipStream_t st = ctx->stream;
+  std::vector<double> x((size_t)n);
+  double nrm = 0.0;
+  for (int i = 0; i < n; ++i) { x[i] = start_entry(i); nrm += x[i] * x[i]; }
+  nrm = std::sqrt(nrm);
+  if (!(nrm > 0.0)) return 1.0 * kEigBoost;
+  for (int i = 0; i < n; ++i) x[i] /= nrm;
+  NSK_HIP(hipMemcpyAsync(L.r.p, x.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+  const int sl = ctx->alloc_slots(2);
+  for (int it = 0; it < kEigIts; ++it) {
+    mv(*L.A, L.r.p, L.w.p);
+    vec_mul(st, n, L.dinv.p, L.w.p);                                         // y = D^-1 A x
+    vec_dot(st, ctx->ws, n, L.w.p, L.w.p, ctx->slot(sl), 1);                  // rank-local: no all-reduce
+    vec_equ(st, n, sref(1.0, nullptr, ctx->slot(sl + 1)), L.w.p, L.r.p);      // x = y / ||y||
+  }
+  const double lam = ctx->read_slots(sl + 1, 1)[0];   // (also keeps the host staging vector alive until the copy is done)
+  ctx->slot_top = sl;
+  return kEigBoost * lam;
+}
+
 void Amg::build(AmgHierarchy &H, HostCsr &&A0, Csr *alias) {
   hipStream_t s = ctx->stream;
   HostCsr A = std::move(A0);
+  const bool timing = std::getenv("NSK_AMG_TIMING") != nullptr;   // phase times of the set-up on stderr
+  double tp = now_ms();
+  auto lap = [&](int l, const char *what) {
+    if (!timing) return;
+    const double t = now_ms();
+    std::fprintf(stderr, "amg set-up: level %d %-22s %9.1f ms\n", l, what, t - tp);
+    tp = t;
+  };
   for (int l = 0;; ++l) {
     auto L = std::make_unique<AmgLevel>();
     const int n = A.n_rows;
@@ -269,16 +302,23 @@ void Amg::build(AmgHierarchy &H, HostCsr &&A0, Csr *alias) {
         if (A.col[k] == i) d = A.val[k];
       dinv[i] = d != 0.0 ? 1.0 / d : 1.0;
     }
-    L->lam = estimate_lambda(A, dinv);
+    lap(l, "diagonal");
     if (l == 0 && alias) L->A = alias;
     else { upload_csr(ctx, A, L->own_A); L->A = &L->own_A; }
     L->dinv.upload(dinv, s);
     L->r.alloc((size_t)n);
     L->w.alloc((size_t)n);
+    lap(l, "upload");
+    // the ten power iterations run on the device copy of the level (same start vector and recurrence as the host
+    // routine, which stays as the fallback should the device value not be finite)
+    L->lam = estimate_lambda_device(*L);
+    if (!(L->lam > 0.0) || !std::isfinite(L->lam)) L->lam = estimate_lambda(A, dinv);
+    lap(l, "lambda (power its)");
     if (l > 0) { L->x.alloc((size_t)n); L->b.alloc((size_t)n); }
     int nc = 0;
     std::vector<int> agg;
     if (n > kCoarseMax && l + 1 < kMaxLevels) nc = aggregate(A, agg);
+    lap(l, "aggregation");
     if (nc <= 0 || nc >= n) {
       if (n <= kDenseLimit) L->inv.upload(dense_inverse(A), s);
       ctx->sync();
@@ -286,9 +326,13 @@ void Amg::build(AmgHierarchy &H, HostCsr &&A0, Csr *alias) {
       break;
     }
     HostCsr P = smoothed_prolongator(A, agg, nc, dinv, L->lam);
+    lap(l, "smoothed prolongator");
     HostCsr R = transpose(P);
+    lap(l, "transpose");
     HostCsr AP = spgemm(A, P);
+    lap(l, "A P");
     HostCsr Ac = spgemm(R, AP);
+    lap(l, "R (A P)");
     upload_csr(ctx, P, L->P);
     upload_csr(ctx, R, L->R);
     L->has_coarse = true;
@@ -316,11 +360,13 @@ void Amg::setup(Ctx *c, Csr &F, const std::vector<int> &shard_off) {
     HostCsr B;
     B.n_rows = B.n_cols = r1 - r0;
     B.rp.assign((size_t)(r1 - r0) + 1, 0);
+#pragma omp parallel for schedule(static)
     for (int i = r0; i < r1; ++i) {
       int cnt = 0;
       for (int k = F.h_rowptr[i]; k < F.h_rowptr[i + 1]; ++k) cnt += F.h_col[k] >= r0 && F.h_col[k] < r1;
-      B.rp[i - r0 + 1] = B.rp[i - r0] + cnt;
+      B.rp[i - r0 + 1] = cnt;
     }
+    for (int i = 0; i < r1 - r0; ++i) B.rp[i + 1] += B.rp[i];
     B.col.resize((size_t)B.rp[r1 - r0]);
     B.val.resize((size_t)B.rp[r1 - r0]);
 #pragma omp parallel for schedule(static)

@@ -59,6 +59,7 @@ struct Amg {
 
  private:
   void build(AmgHierarchy &H, HostCsr &&A0, Csr *alias);
+  double estimate_lambda_device(AmgLevel &L);
   void cheby(AmgLevel &L, const double *b, double *x, bool zero_init);
   void vcycle(AmgHierarchy &H, int l, const double *b, double *x);
   void mv(Csr &A, const double *x, double *y, int mode = 0, const double *z = nullptr);

@@ -172,6 +172,9 @@ def test_rccl_transport_self_test():
     pr = problem("ns16")
     ref = S.LinearSolver()
     ref.set_option(S.OPT_TRI_ORDERING, 1)
+    # with a communicator every Gram-Schmidt link is its own launch + all-reduce; the one-launch sweep of the
+    # communicator-free handle sums in another order (thousands of iterations amplify that into the count)
+    ref.set_option(S.IOPT_FUSED_MGS, 0)
     ref.set_problem(pr)
     ref.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
     xr = ref.solve(S.FGMRES, 1e-10, 20000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
