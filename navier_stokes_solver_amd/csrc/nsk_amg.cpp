@@ -279,9 +279,10 @@ double Amg::estimate_lambda_device(AmgLevel &L) {
   return kEigBoost * lam;
 }
 
-void Amg::build(AmgHierarchy &H, HostCsr &&A0, Csr *alias) {
+void Amg::build(AmgHierarchy &H, const HostCsr &A0, Csr *alias) {
   hipStream_t s = ctx->stream;
-  HostCsr A = std::move(A0);
+  HostCsr coarse;               // the current level's operator from level 1 on
+  const HostCsr *cur = &A0;     // level 0 stays with the caller (kept across set-ups: no 5 GB of page faults each time)
   const bool timing = std::getenv("NSK_AMG_TIMING") != nullptr;   // phase times of the set-up on stderr
   double tp = now_ms();
   auto lap = [&](int l, const char *what) {
@@ -292,6 +293,7 @@ void Amg::build(AmgHierarchy &H, HostCsr &&A0, Csr *alias) {
   };
   for (int l = 0;; ++l) {
     auto L = std::make_unique<AmgLevel>();
+    const HostCsr &A = *cur;
     const int n = A.n_rows;
     L->n = n;
     std::vector<double> dinv((size_t)n, 1.0);
@@ -311,7 +313,8 @@ void Amg::build(AmgHierarchy &H, HostCsr &&A0, Csr *alias) {
     lap(l, "upload");
     // the ten power iterations run on the device copy of the level (same start vector and recurrence as the host
     // routine, which stays as the fallback should the device value not be finite)
-    L->lam = estimate_lambda_device(*L);
+    static const bool host_lambda = std::getenv("NSK_AMG_HOST_LAMBDA") != nullptr;   // A/B switch for measurements
+    L->lam = host_lambda ? -1.0 : estimate_lambda_device(*L);
     if (!(L->lam > 0.0) || !std::isfinite(L->lam)) L->lam = estimate_lambda(A, dinv);
     lap(l, "lambda (power its)");
     if (l > 0) { L->x.alloc((size_t)n); L->b.alloc((size_t)n); }
@@ -338,7 +341,8 @@ void Amg::build(AmgHierarchy &H, HostCsr &&A0, Csr *alias) {
     L->has_coarse = true;
     ctx->sync();  // host staging copies die below
     H.lev.push_back(std::move(L));
-    A = std::move(Ac);
+    coarse = std::move(Ac);
+    cur = &coarse;
   }
 }
 
@@ -347,38 +351,68 @@ void Amg::setup(Ctx *c, Csr &F, const std::vector<int> &shard_off) {
   const double t0 = now_ms();
   shards.clear();
   if (F.n_rows <= 0) return;
-  // values live on the device (nsk_update_values): bring them back once for the host set-up
-  std::vector<double> val((size_t)F.nnz);
-  NSK_HIP(hipMemcpyAsync(val.data(), F.val.p, sizeof(double) * (size_t)F.nnz, hipMemcpyDeviceToHost, ctx->stream));
-  ctx->sync();
   std::vector<int> off = shard_off;
   if (off.size() < 2) off = {0, F.n_rows};
   const bool single_full = off.size() == 2 && F.n_cols == F.n_own_cols && F.n_cols == F.n_rows;
   shards.resize(off.size() - 1);
+  // The host copies of the shards' level-0 operators live across set-ups (the pattern of a block is fixed for the run,
+  // NSSolverStationary.cpp:304): only the values are fetched again, straight into their place.
+  const bool reuse = host0.size() == shards.size() && host0_key == &F && host0_nnz == F.nnz && host0_off == off;
+  if (!reuse) {
+    host0.clear();
+    host0.resize(shards.size());
+    host0_key = &F;
+    host0_nnz = F.nnz;
+    host0_off = off;
+  }
+  std::vector<double> val;   // staging for the general case only (ghost columns dropped / several shards)
+  if (single_full) {
+    HostCsr &B = host0[0];
+    if (!reuse) {
+      B.n_rows = B.n_cols = F.n_rows;
+      B.rp.assign(F.h_rowptr.begin(), F.h_rowptr.end());
+      B.col.resize((size_t)F.nnz);
+      B.val.resize((size_t)F.nnz);
+#pragma omp parallel for schedule(static)
+      for (int64_t k = 0; k < F.nnz; ++k) B.col[k] = F.h_col[k];
+    }
+    NSK_HIP(hipMemcpyAsync(B.val.data(), F.val.p, sizeof(double) * (size_t)F.nnz, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+  } else {
+    // values live on the device (nsk_update_values): bring them back once for the host set-up
+    val.resize((size_t)F.nnz);
+    NSK_HIP(hipMemcpyAsync(val.data(), F.val.p, sizeof(double) * (size_t)F.nnz, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+  }
   for (size_t sidx = 0; sidx + 1 < off.size(); ++sidx) {
     const int r0 = off[sidx], r1 = off[sidx + 1];
-    HostCsr B;
-    B.n_rows = B.n_cols = r1 - r0;
-    B.rp.assign((size_t)(r1 - r0) + 1, 0);
+    HostCsr &B = host0[sidx];
+    if (!single_full) {
+      if (!reuse) {
+        B.n_rows = B.n_cols = r1 - r0;
+        B.rp.assign((size_t)(r1 - r0) + 1, 0);
 #pragma omp parallel for schedule(static)
-    for (int i = r0; i < r1; ++i) {
-      int cnt = 0;
-      for (int k = F.h_rowptr[i]; k < F.h_rowptr[i + 1]; ++k) cnt += F.h_col[k] >= r0 && F.h_col[k] < r1;
-      B.rp[i - r0 + 1] = cnt;
-    }
-    for (int i = 0; i < r1 - r0; ++i) B.rp[i + 1] += B.rp[i];
-    B.col.resize((size_t)B.rp[r1 - r0]);
-    B.val.resize((size_t)B.rp[r1 - r0]);
+        for (int i = r0; i < r1; ++i) {
+          int cnt = 0;
+          for (int k = F.h_rowptr[i]; k < F.h_rowptr[i + 1]; ++k) cnt += F.h_col[k] >= r0 && F.h_col[k] < r1;
+          B.rp[i - r0 + 1] = cnt;
+        }
+        for (int i = 0; i < r1 - r0; ++i) B.rp[i + 1] += B.rp[i];
+        B.col.resize((size_t)B.rp[r1 - r0]);
+        B.val.resize((size_t)B.rp[r1 - r0]);
+      }
 #pragma omp parallel for schedule(static)
-    for (int i = r0; i < r1; ++i) {
-      int w = B.rp[i - r0];
-      for (int k = F.h_rowptr[i]; k < F.h_rowptr[i + 1]; ++k)
-        if (F.h_col[k] >= r0 && F.h_col[k] < r1) { B.col[w] = F.h_col[k] - r0; B.val[w] = val[k]; ++w; }
+      for (int i = r0; i < r1; ++i) {
+        int w = B.rp[i - r0];
+        for (int k = F.h_rowptr[i]; k < F.h_rowptr[i + 1]; ++k)
+          if (F.h_col[k] >= r0 && F.h_col[k] < r1) { B.col[w] = F.h_col[k] - r0; B.val[w] = val[k]; ++w; }
+      }
     }
     shards[sidx].offset = r0;
-    build(shards[sidx], std::move(B), single_full ? &F : nullptr);
+    build(shards[sidx], B, single_full ? &F : nullptr);
   }
   setup_host_ms = now_ms() - t0;
+  if (std::getenv("NSK_AMG_TIMING")) std::fprintf(stderr, "amg set-up: total %.1f ms\n", setup_host_ms);
 }
 
 void Amg::mv(Csr &A, const double *x, double *y, int mode, const double *z) {

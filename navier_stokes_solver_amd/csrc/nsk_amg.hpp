@@ -50,7 +50,7 @@ struct Amg {
   // F: device block with host pattern; shard_off: empty = one shard
   void setup(Ctx *ctx, Csr &F, const std::vector<int> &shard_off);
   void apply(const double *b, double *x);
-  void clear() { shards.clear(); }
+  void clear() { shards.clear(); }   // (the host copy of level 0 stays: see host0)
   int n_levels(int shard = 0) const { return shards.empty() ? 0 : (int)shards[shard].lev.size(); }
   int level_rows(int shard, int l) const { return shards[shard].lev[l]->n; }
   int64_t level_nnz(int shard, int l) const { return shards[shard].lev[l]->A->nnz; }
@@ -58,7 +58,12 @@ struct Amg {
   size_t apply_bytes() const;  // algorithmic bytes of one V-cycle (SURVEY 8d formulas)
 
  private:
-  void build(AmgHierarchy &H, HostCsr &&A0, Csr *alias);
+  void build(AmgHierarchy &H, const HostCsr &A0, Csr *alias);
+  // host copies of the shards' level-0 operators, kept across set-ups (pattern fixed, values refreshed)
+  std::vector<HostCsr> host0;
+  const void *host0_key = nullptr;
+  int64_t host0_nnz = 0;
+  std::vector<int> host0_off;
   double estimate_lambda_device(AmgLevel &L);
   void cheby(AmgLevel &L, const double *b, double *x, bool zero_init);
   void vcycle(AmgHierarchy &H, int l, const double *b, double *x);

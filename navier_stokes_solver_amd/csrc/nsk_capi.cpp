@@ -97,6 +97,17 @@ struct nsk_handle_s {
   Amg amgF;                 // velocity AMG of the stationary block-triangular preconditioner
   int velocity_amg = 1;     // NSK_OPT_VELOCITY_AMG
   bool amg_active = false;  // the current setup preconditions F with amgF instead of tF
+  // The hierarchy is built on first use: PreconditionAMG::initialize is called before every solve (NSSolverStationary.hpp:231),
+  // also before the many solves of a Newton run that stop at step 0 without ever applying the preconditioner; building it
+  // when the first vmult arrives (or before the block's values change) gives the same results without those set-ups.
+  bool amg_pending = false;
+  void amg_ready() {
+    if (!amg_pending) return;
+    amg_pending = false;
+    const double t0 = wall_ms();
+    amgF.setup(&ctx, blk[NSK_BLK_F], sub_offsets(0));
+    setup_ms += wall_ms() - t0;
+  }
   bool tF_ok = false, tMp_ok = false, tS_ok = false, s_symbolic = false;
   int tF_key = -1, tMp_key = -1, tS_key = -1;
   TriSolve *tP = nullptr;
@@ -339,8 +350,10 @@ void H::setup(int type, int variant_, double alpha_) {
   const int kindP = (type == 0 && variant == 0) ? 1 : 0;
   // PreconditionBlockTriangular, stationary: preconditioner_velocity is an AMG (NSSolverStationary.hpp:225,231)
   amg_active = type == 1 && variant == 0 && velocity_amg != 0;
+  amg_pending = false;
   if (amg_active) {
-    amgF.setup(&ctx, F, sub_offsets(0));
+    amgF.clear();
+    amg_pending = true;
   } else {
     amgF.clear();
     if (!tF_ok || tF_key != key) {
@@ -399,7 +412,7 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
   const int nu = n_u(), np = n_p();
   MatVec A_F = [&](const DVec &x, double *y) { halo(0, x); spmv_nohalo(F, x, y); };
   PrecVmult P_F = [&](DVec &d, const DVec &r) {
-    if (amg_active) amgF.apply(r.own, d.own);
+    if (amg_active) { amg_ready(); amgF.apply(r.own, d.own); }
     else tri_apply_sampled(tF, 20, r.own, d.own);
   };
   PrecVmult P_P = [&](DVec &d, const DVec &r) { tri_apply_sampled(*tP, 21, r.own, d.own); };
@@ -700,6 +713,7 @@ int nsk_update_values(nsk_handle h, int b, const double *val) {
   NSK_TRY(h)
   if (b < 0 || b > NSK_BLK_BT_GHOST || !h->blk[b].present) throw Error(-60, "nsk_update_values: block not set");
   (void)hipSetDevice(h->ctx.device);
+  if (b == NSK_BLK_F) h->amg_ready();   // a pending hierarchy belongs to the values it was requested for
   Csr &A = h->blk[b];
   NSK_HIP(hipMemcpyAsync(A.val.p, val, sizeof(double) * (size_t)A.nnz, hipMemcpyHostToDevice, h->s()));
   A.refresh_blocked(h->s());
@@ -1081,6 +1095,8 @@ int nsk_assemble(nsk_handle h, int stokes, double nu, double inv_dt, double p_ou
   auto &A = h->asmd;
   if (!A.ready || !A.dirichlet_set || !A.state_set) throw Error(-66, "nsk_assemble needs cells, Dirichlet flags and a state");
   if (!(nu > 0.0)) throw Error(-60, "nsk_assemble: nu must be positive");
+  // (a hierarchy still pending here was requested for a solve that never applied it: it is NOT built from the old
+  //  values now; should a solve follow without a new nsk_setup_preconditioner, it is built from the new ones)
   if (inhomogeneous_bc && !A.have_bc) throw Error(-60, "nsk_assemble: no boundary values were given");
   Csr &F = h->blk[NSK_BLK_F];
   hipStream_t s = h->s();
@@ -1110,6 +1126,7 @@ int nsk_scale_values(nsk_handle h, int blk, double factor) {
   NSK_TRY(h)
   (void)hipSetDevice(h->ctx.device);
   if (blk < 0 || blk > NSK_BLK_S || !h->blk[blk].present) throw Error(-52, "nsk_scale_values: no such block");
+  if (blk == NSK_BLK_F) h->amg_ready();
   Csr &A = h->blk[blk];
   vec_scale(h->s(), (int)A.nnz, sref(factor), A.val.p);
   A.refresh_blocked(h->s());
@@ -1172,7 +1189,7 @@ int nsk_tri_apply(nsk_handle h, int which, const double *b, double *x) {
   VecPool &p = which == NSK_TRI_VELOCITY ? h->pool_u : h->pool_p;
   double *bv = p.get(true), *xv = p.get(true);
   NSK_HIP(hipMemcpyAsync(bv, b, sizeof(double) * (size_t)p.n, hipMemcpyHostToDevice, h->s()));
-  if (which == NSK_TRI_VELOCITY && h->amg_active) h->amgF.apply(bv, xv);  // the velocity preconditioner is the AMG
+  if (which == NSK_TRI_VELOCITY && h->amg_active) { h->amg_ready(); h->amgF.apply(bv, xv); }  // the velocity preconditioner is the AMG
   else T->apply(bv, xv);
   NSK_HIP(hipMemcpyAsync(x, xv, sizeof(double) * (size_t)p.n, hipMemcpyDeviceToHost, h->s()));
   h->ctx.sync();
@@ -1215,6 +1232,7 @@ int nsk_debug_tri_trace(nsk_handle h, int which, int64_t *out16, int max_runs, i
 
 int nsk_amg_info(nsk_handle h, int shard, int level, int64_t *rows, int64_t *nnz, double *lambda_max) {
   NSK_TRY(h)
+  if (h->amg_active) h->amg_ready();
   if (!h->amg_active || shard < 0 || shard >= (int)h->amgF.shards.size()) return 0;
   const int nl = h->amgF.n_levels(shard);
   if (level >= 0 && level < nl) {
@@ -1419,6 +1437,7 @@ int nsk_time_op(nsk_handle h, int op, int reps, double *avg_ms, double *bytes) {
     if (h->prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
     TriSolve *T = op == 20 ? &h->tF : h->tP;
     if (op == 20 && h->amg_active) {  // the velocity preconditioner of this setup is the AMG V-cycle
+      h->amg_ready();
       by = (double)h->amgF.apply_bytes();
       f = [=]() { h->amgF.apply(xb, yb); };
     } else {

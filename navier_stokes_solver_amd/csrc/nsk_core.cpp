@@ -279,13 +279,19 @@ void Ctx::dot3(int n, const double *r, const double *u, const double *w, int so)
   ++st.reductions;
   st.blas1_bytes += 24.0 * n;
 }
-void Ctx::multi_dot(int n, const double *w, double *const *v, int m, int so) {
+void Ctx::multi_dot(int n, const double *w, double *const *v, int m, int so, bool defer) {
   VecPack P{};
   for (int k = 0; k < m; ++k) P.v[k] = v[k];
   vec_multi_dot(stream, ws, n, w, P, m, slot(so));
-  comm.allreduce_sum(slot(so), m, stream);
-  ++st.reductions;
+  if (!defer) {
+    comm.allreduce_sum(slot(so), m, stream);
+    ++st.reductions;
+  }
   st.blas1_bytes += 8.0 * n * (m + 1);
+}
+void Ctx::allreduce_slots(int first, int count) {
+  comm.allreduce_sum(slot(first), count, stream);
+  ++st.reductions;
 }
 void Ctx::multi_axpy(int n, double *w, double *const *v, int m, int coef_slot, int norm_slot) {
   VecPack P{};

@@ -222,7 +222,9 @@ struct Ctx {
   void axpy_dot(int n, SRef a, const double *x, double *y, const double *w, int slot_out);
   void axpy_norm2(int n, SRef a, const double *x, double *y, int slot_out);
   // fused classical Gram-Schmidt: slots[so..so+m) = w . v[k] ; w -= sum slot[coef+k] v[k] (+ norm)
-  void multi_dot(int n, const double *w, double *const *v, int m, int slot_out);
+  // defer: leave the cross-rank sum to ONE allreduce_slots over all the passes of a Gram-Schmidt column
+  void multi_dot(int n, const double *w, double *const *v, int m, int slot_out, bool defer = false);
+  void allreduce_slots(int first, int count);
   void multi_axpy(int n, double *w, double *const *v, int m, int coef_slot, int norm_slot);
   void cg_update(int n, SRef a, const double *d, const double *h, double *x, double *g, int slot_out);
   void dot3(int n, const double *r, const double *u, const double *w, int slot_out);   // r.u, w.u, r.r: one pass, one all-reduce

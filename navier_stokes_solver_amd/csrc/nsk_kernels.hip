@@ -505,7 +505,7 @@ __device__ __forceinline__ double sf_wait(const double *p, unsigned long long fi
 }
 
 template <int LOWER, int KIND, int NNZ>
-__global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, int nb, int wrong_order,
+__global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const int4 *__restrict__ desc, int nb, int wrong_order,
                                                             const double *__restrict__ dinv,
                                                             const int *__restrict__ perm,
                                                             const double *__restrict__ rhs,
@@ -522,7 +522,8 @@ __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, int nb
   // with empty runs) the runs are dealt so that XCD k works on the k-th eighth of every colour.
   // wrong_order (test hook): walk the list backwards, i.e. consumers before their producers, to exercise
   // the bounded-spin / fallback path
-  const int4 d = M.desc[wrong_order ? nb - 1 - (int)blockIdx.x : (int)blockIdx.x];
+  // (desc == M.desc, handed over as a read-only pointer of its own: the uniform load becomes a scalar load)
+  const int4 d = desc[wrong_order ? nb - 1 - (int)blockIdx.x : (int)blockIdx.x];
   const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
   if (r0 == r1) return;  // padding run
   const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
@@ -1475,7 +1476,7 @@ void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int
                          const double *dinv, const int *perm, const double *rhs, const double *own, double *w,
                          double *reset, int *err, long long *dbg) {
   if (nb <= 0) return;
-#define NSK_SF(L, K, N) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, dinv, perm, rhs, own, w, reset, err, dbg)
+#define NSK_SF(L, K, N) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N>), dim3(nb), dim3(BLK), 0, s, M, M.desc, nb, wrong_order, dinv, perm, rhs, own, w, reset, err, dbg)
 #define NSK_SFN(L, K)                                      \
   do {                                                     \
     if (run_nnz <= 512) NSK_SF(L, K, 512);                 \

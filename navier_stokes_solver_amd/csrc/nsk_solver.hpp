@@ -240,7 +240,9 @@ struct SolverFGMRES : SolverBase {
           // classical Gram-Schmidt in two fused sweeps: all h(i,j) from one read of aux (8 basis vectors
           // per pass), then aux -= sum h(i,j) v_i and ||aux||.  Same Arnoldi relation as deal.II's
           // modified Gram-Schmidt in exact arithmetic; ~2.5x fewer bytes and 4 launches instead of j+2.
-          for (int i0 = 0; i0 <= j; i0 += 8) ctx.multi_dot(n, aux.own, &v[i0], std::min(8, j + 1 - i0), HS + i0);
+          // (the passes' partial sums land in consecutive slots: one all-reduce for the whole column)
+          for (int i0 = 0; i0 <= j; i0 += 8) ctx.multi_dot(n, aux.own, &v[i0], std::min(8, j + 1 - i0), HS + i0, true);
+          ctx.allreduce_slots(HS, j + 1);
           for (int i0 = 0; i0 <= j; i0 += 8)
             ctx.multi_axpy(n, aux.own, &v[i0], std::min(8, j + 1 - i0), HS + i0, i0 + 8 > j ? HS + j + 1 : -1);
         } else if (ctx.mgs_sweep(n, aux.own, v.data(), j + 1, HS)) {
