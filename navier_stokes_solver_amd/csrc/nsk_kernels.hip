@@ -526,6 +526,7 @@ __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const 
   const int4 d = desc[wrong_order ? nb - 1 - (int)blockIdx.x : (int)blockIdx.x];
   const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
   if (r0 == r1) return;  // padding run
+  if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 16 + 9] = (long long)__builtin_amdgcn_s_memrealtime() + (r0 & 0);   // descriptor has arrived
   const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
   const bool have = r < r1;
   int jb = 0, je = 0, i = 0;

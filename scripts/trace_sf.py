@@ -28,7 +28,7 @@ for name, sl in (("lower", slice(0, nL)), ("upper", slice(nL, n))):
     t0 = t[:, 0].min()
     print(f"{name}: workgroups {len(b)} (non-empty {int(live.sum())}), span {t[:, 4].max() - t0:.1f} us, "
           f"entries/wg {d[:, 8].mean():.0f}, waiting entries/wg mean {d[:, 5].mean():.1f} ({100 * d[:, 5].sum() / d[:, 8].sum():.1f}% of all)")
-    for nm, v in (("start -> loads landed", t[:, 1] - t[:, 0]), ("polling (wave 0)", t[:, 2] - t[:, 1]),
+    for nm, v in (("start -> descriptor", d[:, 9] * 0.01 - t[:, 0]), ("start -> loads landed", t[:, 1] - t[:, 0]), ("polling (wave 0)", t[:, 2] - t[:, 1]),
                   ("other waves' polls", t[:, 3] - t[:, 2]), ("row sums + store", t[:, 4] - t[:, 3]), ("lifetime", t[:, 4] - t[:, 0])):
         print(f"   {nm:26s} mean {v.mean():7.2f} us  p50 {np.percentile(v, 50):7.2f}  p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f}")
     # concurrency: workgroups alive over time
