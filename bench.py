@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--sync-free", type=int, default=2, help="0 per-colour launches, 1 single-launch S/Mp solves, 2 also F")
     ap.add_argument("--cg-single-reduction", type=int, default=-1,
                     help="inner CG with one fused all-reduce per iteration (NSK_OPT_CG_SINGLE_REDUCTION); default: on for N > 1")
+    ap.add_argument("--inner-gs", type=int, default=-1,
+                    help="Gram-Schmidt of the inner FGMRES: 0 modified, 1 fused classical (default on one GPU), 2 fused classical "
+                         "with one reduction per iteration (default for N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mesh", type=str, default="300,100")
     ap.add_argument("--cpu-steps", type=int, default=12)
@@ -88,6 +91,7 @@ def make_solver(S, PT, P, dist, args, nx, ny, nu, inv_dt, world, rank, local_ran
     ls.set_option(S.OPT_SUBDOMAINS, args.subdomains)
     ls.set_option(S.OPT_TRI_SYNC_FREE, args.sync_free)
     ls.set_option(S.OPT_CG_SINGLE_REDUCTION, int(args.cg_single_reduction if args.cg_single_reduction >= 0 else world > 1))
+    ls.set_option(S.OPT_INNER_FUSED_GS, int(args.inner_gs if args.inner_gs >= 0 else (2 if world > 1 else 1)))
     t0 = time.time()
     ls.set_problem(pr, plan)
     return ls, pr, n_global, t_gen, time.time() - t0
@@ -359,6 +363,8 @@ def main():
                 "residual_after_K": res,
                 "inner_cg": "single-reduction (Chronopoulos-Gear)" if (args.cg_single_reduction if args.cg_single_reduction >= 0
                                                                       else world > 1) else "deal.II recurrence",
+                "inner_gram_schmidt": ["modified", "fused classical", "fused classical, one reduction per iteration"][
+                    int(args.inner_gs if args.inner_gs >= 0 else (2 if world > 1 else 1))],
             },
             "roofline": {
                 "bound": "hbm", "kernel": D["kernel"], "time_share": D["time_share"],

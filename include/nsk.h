@@ -70,7 +70,10 @@ enum {
   NSK_OPT_FUSE_BLOCK_ROW = 2, /* 1 (default): F x_u + Bt x_p in one kernel */
   NSK_OPT_STREAM_KERNELS = 3, /* 1 (default): LDS-staged CSR-stream kernels; 0: CSR-vector kernels */
   NSK_OPT_INNER_FUSED_GS = 4, /* 1 (default): inner FGMRES (on F) orthogonalises with fused classical Gram-Schmidt
-                                 (two sweeps, 8 vectors per pass); 0: deal.II's modified Gram-Schmidt (add_and_dot) */
+                                 (two sweeps, 8 vectors per pass); 0: deal.II's modified Gram-Schmidt (add_and_dot);
+                                 2: as 1 with the norm of the new vector from |w|^2 - sum h_i^2 — one cross-rank
+                                 reduction per inner iteration instead of two (made for several GPUs; the inner solve
+                                 only has to reach 1e-1 relative) */
   NSK_OPT_OUTER_FUSED_GS = 5, /* same for the outer FGMRES; default 0 (modified Gram-Schmidt, as deal.II) */
   NSK_OPT_CG_SINGLE_REDUCTION = 11, /* 0 (default): inner CG (on S / Mp) with deal.II's recurrence — three reductions per
                                  iteration; 1: Chronopoulos-Gear form, ONE fused reduction (one all-reduce) per iteration:

@@ -79,7 +79,8 @@ struct nsk_handle_s {
   VecPool pool_u, pool_p, pool_b;
   bool pools_ready = false;
   int tri_ordering = ORDER_MULTICOLOR, subdomains = 1, fuse_block_row = 1, use_stream = 1;
-  bool inner_fused_gs = true, outer_fused_gs = false, cg_fused = false;
+  int inner_fused_gs = 1;
+  bool outer_fused_gs = false, cg_fused = false;
   int use_bsr = 1;
   int sync_free_fallbacks = 0;
   int x_layout_mode = 2;   // NSK_IOPT_TRI_X_LAYOUT
@@ -521,7 +522,7 @@ int H::solve_once(int solver, double tol, int max_iter, int *iters, double *fina
   const int slot_mark = ctx.slot_top;
   try {
     if (solver == 0) { SolverGMRES sv(ctx, pool_b, control); sv.solve(A, x, b, P); }
-    else if (solver == 1) { SolverFGMRES sv(ctx, pool_b, control); sv.fused_gs = outer_fused_gs; sv.solve(A, x, b, P); }
+    else if (solver == 1) { SolverFGMRES sv(ctx, pool_b, control); sv.fused_gs = outer_fused_gs ? 1 : 0; sv.solve(A, x, b, P); }
     else { SolverBicgstab sv(ctx, pool_b, control); sv.solve(A, x, b, P); }
   } catch (NoConvergence &e) {
     rc = e.code;
@@ -758,7 +759,10 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
       h->x_layout_mode = v == 0.0 ? 0 : 2;
       h->tF_ok = false;
       break;
-    case NSK_OPT_INNER_FUSED_GS: h->inner_fused_gs = v != 0.0; break;
+    case NSK_OPT_INNER_FUSED_GS:
+      if (v != 0.0 && v != 1.0 && v != 2.0) throw Error(-61, "NSK_OPT_INNER_FUSED_GS: 0, 1 or 2");
+      h->inner_fused_gs = (int)v;
+      break;
     case NSK_OPT_OUTER_FUSED_GS: h->outer_fused_gs = v != 0.0; break;
     case NSK_OPT_CG_SINGLE_REDUCTION: h->cg_fused = v != 0.0; break;
     default: throw Error(-61, "nsk_set_option: unknown option");

@@ -104,6 +104,7 @@ struct VecPack {
   const double *v[8];
 };
 void vec_multi_dot(hipStream_t s, const ReduceWs &ws, int n, const double *w, const VecPack &P, int m, double *out);
+void gs_pythagoras(hipStream_t s, double *h, int m);   // h[m] = w.w  ->  h[m] = w.w - sum h_i^2, h[m+1] = sqrt
 void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const VecPack &P, int m, const double *h,
                     double *norm_out);
 // One-launch modified Gram-Schmidt sweep (nsk_kernels.hip: mgs_sweep_kernel): out[i] = h_i (i < nv), out[nv] = |aux|^2,

@@ -1469,6 +1469,18 @@ void scalar_sqrt(hipStream_t s, const double *in, double *out) {
   const int n = 1;
   NSK_EW(n, [=] __device__(int) { out[0] = sqrt(fabs(in[0])); });
 }
+// h[0..m) Gram-Schmidt coefficients, h[m] = w.w before the update: h[m] <- |w - sum h_i v_i|^2 = w.w - sum h_i^2 (the
+// basis is orthonormal), h[m+1] <- its root.  One thread.
+void gs_pythagoras(hipStream_t s, double *h, int m) {
+  const int n = 1;
+  NSK_EW(n, [=] __device__(int) {
+    double q = h[m];
+    for (int i = 0; i < m; ++i) q -= h[i] * h[i];
+    q = q > 0.0 ? q : 0.0;
+    h[m] = q;
+    h[m + 1] = sqrt(q);
+  });
+}
 void vec_fill_sentinel(hipStream_t s, int n, double *y) {
   unsigned long long *p = reinterpret_cast<unsigned long long *>(y);
   NSK_EW(n, [=] __device__(int i) { p[i] = kSentinel; });

@@ -195,7 +195,9 @@ struct SolverFGMRES : SolverBase {
   using SolverBase::SolverBase;
   static constexpr int kBasis = 30;
   int iterations = 0;
-  bool fused_gs = false;  // inner solves: fused classical Gram-Schmidt instead of modified
+  int fused_gs = 0;  // inner solves: 1 fused classical Gram-Schmidt instead of modified; 2 the same with the new
+                     // vector's norm from |w|^2 - sum h_i^2 (w.w rides in the coefficient pass): ONE cross-rank
+                     // reduction per iteration instead of two (NSK_OPT_INNER_FUSED_GS = 2, for several GPUs)
   void solve(const MatVec &A, DVec &x, const DVec &b, const PrecVmult &P) {
     std::vector<double *> v(kBasis, nullptr), z(kBasis, nullptr);
     double *auxp = pool.get(false);
@@ -241,10 +243,16 @@ struct SolverFGMRES : SolverBase {
           // per pass), then aux -= sum h(i,j) v_i and ||aux||.  Same Arnoldi relation as deal.II's
           // modified Gram-Schmidt in exact arithmetic; ~2.5x fewer bytes and 4 launches instead of j+2.
           // (the passes' partial sums land in consecutive slots: one all-reduce for the whole column)
-          for (int i0 = 0; i0 <= j; i0 += 8) ctx.multi_dot(n, aux.own, &v[i0], std::min(8, j + 1 - i0), HS + i0, true);
-          ctx.allreduce_slots(HS, j + 1);
+          const bool one_red = fused_gs == 2;
+          double *vv[kBasis + 1];
+          for (int i = 0; i <= j; ++i) vv[i] = v[i];
+          vv[j + 1] = aux.own;   // one_red: w.w as one more "coefficient" of the same pass
+          const int m = j + 1 + (one_red ? 1 : 0);
+          for (int i0 = 0; i0 < m; i0 += 8) ctx.multi_dot(n, aux.own, &vv[i0], std::min(8, m - i0), HS + i0, true);
+          ctx.allreduce_slots(HS, m);
+          if (one_red) gs_pythagoras(s(), ctx.slot(HS), j + 1);
           for (int i0 = 0; i0 <= j; i0 += 8)
-            ctx.multi_axpy(n, aux.own, &v[i0], std::min(8, j + 1 - i0), HS + i0, i0 + 8 > j ? HS + j + 1 : -1);
+            ctx.multi_axpy(n, aux.own, &v[i0], std::min(8, j + 1 - i0), HS + i0, (!one_red && i0 + 8 > j) ? HS + j + 1 : -1);
         } else if (ctx.mgs_sweep(n, aux.own, v.data(), j + 1, HS)) {
           // modified Gram-Schmidt, the whole chain in one launch (Ctx::mgs_sweep)
           mgs_flag = HS + j + 3;

@@ -93,6 +93,7 @@ def test_multi_rank_path_over_gloo(world):
     (2, 2, 1, 0, "unsteady16"), (3, 2, 1, 1, "unsteady16"), (2, 2, 0, 1, "ns16"), (2, 0, 0, 0, "ns16"), (2, 1, 0, 1, "ns16"),
     (2, 2, 0, 1, "ns16_re200"),     # north_star / BASELINE configs[3]: FGMRES + aSIMPLE at nu = 1/190, row-partitioned
     (2, 2, 0, 1, "ns16+cg1"),       # the same with the single-reduction inner CG (NSK_OPT_CG_SINGLE_REDUCTION)
+    (2, 2, 0, 1, "ns16_re200+cg1+gs2"),   # what bench.py --gpus N runs: plus one reduction per inner FGMRES iteration
 ])
 def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name):
     """N rank threads on one GPU: ghost import, global reductions, D^-1 halo, SpGEMM with imported
@@ -100,7 +101,8 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name
     import scipy.sparse.linalg as spl
     from navier_stokes_solver_amd import solver as S
     from oracle import oracle as O
-    cg_fused = name.endswith("+cg1")
+    cg_fused = "+cg1" in name
+    inner_gs = 2 if "+gs2" in name else 1
     name = name.split("+")[0]
     case = CASES[name]
     pr = problem(name)
@@ -118,6 +120,7 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name
             p = parts[r]
             ls.set_option(S.OPT_TRI_ORDERING, ordering)
             ls.set_option(S.OPT_CG_SINGLE_REDUCTION, int(cg_fused))
+            ls.set_option(S.OPT_INNER_FUSED_GS, inner_gs)
             ls.set_problem(p, plans[r])
             ur, prg = p.u_ranges, p.p_ranges
             yu, yp = ls.jacobian_vmult(xu[ur[r]:ur[r + 1]], xp[prg[r]:prg[r + 1]])
