@@ -383,6 +383,7 @@ def main():
                 "host_syncs": st["host_syncs"], "reductions": st["reductions"],
                 "host_syncs_per_step": st["host_syncs"] / args.steps, "reductions_per_step": st["reductions"] / args.steps,
                 "sync_free_fallbacks": st["sync_free_fallbacks"],
+                "spmvs_overlapped_with_halo_per_step": st["overlapped_spmvs"] / args.steps,
                 "dof_iters_per_s_incl_setup": n_global * args.steps / (dt + t_setup),
             },
         }

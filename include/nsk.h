@@ -100,6 +100,7 @@ typedef struct {
   int64_t sync_free_fallbacks; /* times a solve fell back to per-colour launches (NSK_OPT_TRI_SYNC_FREE) */
   int64_t cur_outer_iters;     /* progress of the running / last outer solve: iterations done ... */
   double cur_residual;         /* ... and the residual SolverControl saw last (readable from another thread) */
+  int64_t overlapped_spmvs;    /* SpMVs whose interior rows ran while the halo exchange was in flight (nranks > 1) */
 } nsk_stats;
 
 /* 128-byte RCCL unique id, produced on rank 0 and distributed by the caller (e.g. MPI_Bcast). */

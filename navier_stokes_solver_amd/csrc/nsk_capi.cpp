@@ -177,6 +177,43 @@ struct nsk_handle_s {
     ++ctx.st.spmv_calls;
     ctx.st.spmv_bytes += (double)A.spmv_bytes() + (mode == 1 ? 8.0 * A.n_rows : 0.0);
   }
+  // y = A x including the ghost import of x.  Several ranks: the rows without ghost columns (all but the first and last
+  // lattice columns of the strip) are computed on a second stream while the halo exchange occupies the main one; the
+  // boundary rows follow it.  Row-run plans are cut at the interior range (Csr::find_interior), so the three launches
+  // are sub-ranges of the same plan.
+  bool overlap_halo = true;   // NSK_IOPT_OVERLAP_HALO
+  long overlapped_spmvs = 0;
+  void spmv_halo(Csr &A, int space, const DVec &x, double *y) {
+    const bool blocked = A.blk_ok && use_stream && use_bsr;
+    const bool streamed = !blocked && A.stream_ok && use_stream && !(A.win_ok && use_win_spmv);
+    const int b0 = blocked ? A.blk_int_b0 : A.int_b0, b1 = blocked ? A.blk_int_b1 : A.int_b1;
+    const int nb = blocked ? A.blk_nblk : A.nblk;
+    EventSampler::Slot *smp = sampler.find((int)(&A - blk));
+    const bool sampling = smp && smp->used < smp->cap;   // (a launch that is being timed stays one launch)
+    if (!overlap_halo || ctx.comm.nranks <= 1 || !(blocked || streamed) || b1 <= b0 || sampling) {
+      halo(space, x);
+      spmv_nohalo(A, x, y);
+      return;
+    }
+    if (smp) ++smp->seen;
+    ++overlapped_spmvs;
+    ctx.ensure_stream2();
+    auto part = [&](hipStream_t st, int c0, int c1) {
+      if (c1 <= c0) return;
+      if (blocked) nsk::spmv_blk_stream(st, A.blk_view(), A.blk_R, A.blk_C, A.blk_rowblk.p + c0, c1 - c0, x.own, x.ghost, y);
+      else nsk::spmv_stream(st, A.view(), A.rowblk.p + c0, c1 - c0, A.even_rows, x.own, x.ghost, y, 0, nullptr);
+    };
+    NSK_HIP(hipEventRecord(ctx.ev_fork, s()));                 // x is complete here
+    NSK_HIP(hipStreamWaitEvent(ctx.stream2, ctx.ev_fork, 0));
+    part(ctx.stream2, b0, b1);                                 // interior rows: owned entries of x only
+    NSK_HIP(hipEventRecord(ctx.ev_join, ctx.stream2));
+    halo(space, x);                                            // pack + grouped send/recv into x's ghost tail
+    part(s(), 0, b0);
+    part(s(), b1, nb);
+    NSK_HIP(hipStreamWaitEvent(s(), ctx.ev_join, 0));
+    ++ctx.st.spmv_calls;
+    ctx.st.spmv_bytes += (double)A.spmv_bytes();
+  }
   // BlockSparseMatrix::vmult on jacobian_matrix: y_u = F x_u + Bt x_p ; y_p = B x_u (+ 0 x_p)
   void jacobian_vmult(const DVec &xb, double *yb) {
     const DVec xu = ub(xb.own), xp = pb(xb.own);
@@ -411,7 +448,7 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
   DVec du = ub(dst.own), dp = pb(dst.own);
   const DVec su = ub(src.own), spv = pb(src.own);
   const int nu = n_u(), np = n_p();
-  MatVec A_F = [&](const DVec &x, double *y) { halo(0, x); spmv_nohalo(F, x, y); };
+  MatVec A_F = [&](const DVec &x, double *y) { spmv_halo(F, 0, x, y); };
   PrecVmult P_F = [&](DVec &d, const DVec &r) {
     if (amg_active) { amg_ready(); amgF.apply(r.own, d.own); }
     else tri_apply_sampled(tF, 20, r.own, d.own);
@@ -423,7 +460,7 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
 
   if (prec_type == 0 || prec_type == 1) {
     Csr &Mp = blk[NSK_BLK_MP];
-    MatVec A_M = [&](const DVec &x, double *y) { halo(1, x); spmv_nohalo(Mp, x, y); };
+    MatVec A_M = [&](const DVec &x, double *y) { spmv_halo(Mp, 1, x, y); };
     int max_u, max_p;
     double tol_u, tol_p;
     if (prec_type == 0) {
@@ -461,7 +498,7 @@ void H::prec_vmult(DVec &dst, const DVec &src) {
   if (variant == 0) {
     // stationary aSIMPLE (NSSolverStationary.hpp:282-311)
     Csr &S = blk[NSK_BLK_S];
-    MatVec A_S = [&](const DVec &x, double *y) { halo(1, x); spmv_nohalo(S, x, y); };
+    MatVec A_S = [&](const DVec &x, double *y) { spmv_halo(S, 1, x, y); };
     try {
       SolverControl cF(100000, 1e-1 * norm_of(su.own, nu));
       SolverFGMRES sF(ctx, pool_u, cF);
@@ -752,6 +789,7 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
       break;
     case NSK_IOPT_TRI_WINDOW: h->tri_window = v != 0.0; break;
     case NSK_IOPT_FUSED_MGS: h->ctx.fused_mgs = v != 0.0; break;
+    case NSK_IOPT_OVERLAP_HALO: h->overlap_halo = v != 0.0; break;
     case NSK_IOPT_TINY_BYTES: h->tF.tiny_bytes = h->tMp.tiny_bytes = h->tS.tiny_bytes = v; break;
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
     case NSK_OPT_VELOCITY_AMG: h->velocity_amg = v != 0.0; break;
@@ -1331,6 +1369,7 @@ int nsk_get_stats(nsk_handle h, nsk_stats *o) {
   o->sync_free_fallbacks = h->sync_free_fallbacks;
   o->cur_outer_iters = h->progress_step;
   o->cur_residual = h->progress_value;
+  o->overlapped_spmvs = h->overlapped_spmvs;
   return 0;
   NSK_CATCH(h)
 }
@@ -1353,6 +1392,7 @@ int nsk_reset_stats(nsk_handle h) {
   NSK_TRY(h)
   h->ctx.st = Stats{};
   h->inner_u = h->inner_p = h->prec_applies = h->outer_iters = 0;
+  h->overlapped_spmvs = 0;
   return 0;
   NSK_CATCH(h)
 }

@@ -213,8 +213,20 @@ void Ctx::init(int device_id) {
   NSK_HIP(hipStreamSynchronize(stream));
 }
 
+void Ctx::ensure_stream2() {
+  if (stream2) return;
+  NSK_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+  NSK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  NSK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+}
+
 void Ctx::destroy() {
   comm.destroy();
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
+  if (ev_join) (void)hipEventDestroy(ev_join);
+  if (stream2) (void)hipStreamDestroy(stream2);
+  ev_fork = ev_join = nullptr;
+  stream2 = nullptr;
   if (h_scal) (void)hipHostFree(h_scal);
   h_scal = nullptr;
   ws_partials.release();
@@ -361,11 +373,48 @@ bool build_rowblocks(const int *ra, const int *rb, int n_rows, int max_nnz, cons
   return true;
 }
 
+// longest run of rows without ghost columns
+void Csr::find_interior() {
+  int_r0 = int_r1 = 0;
+  if (n_cols == n_own_cols) { int_r1 = n_rows; return; }
+  std::vector<char> ghost((size_t)n_rows, 0);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n_rows; ++i) {
+    char g = 0;
+    for (int k = h_rowptr[i]; k < h_rowptr[i + 1]; ++k) g |= h_col[k] >= n_own_cols;
+    ghost[i] = g;
+  }
+  int best0 = 0, best1 = 0, start = 0;
+  for (int i = 0; i <= n_rows; ++i) {
+    if (i == n_rows || ghost[i]) {
+      if (i - start > best1 - best0) { best0 = start; best1 = i; }
+      start = i + 1;
+    }
+  }
+  int_r0 = best0;
+  int_r1 = best1;
+}
+
+static void interior_runs(const std::vector<int> &rb, int r0, int r1, int &b0, int &b1) {
+  b0 = b1 = 0;
+  const int nb = (int)rb.size() - 1;
+  for (int b = 0; b < nb; ++b)
+    if (rb[b] >= r0 && rb[b + 1] <= r1) {
+      if (b1 == b0) b0 = b;
+      b1 = b + 1;
+    }
+}
+
 void Csr::build_stream_plan(hipStream_t s) {
   std::vector<int> rb;
-  stream_ok = n_rows > 0 && build_rowblocks(h_rowptr.data(), nullptr, n_rows, kStreamNnz, nullptr, rb);
+  find_interior();
+  std::vector<int> cuts;
+  if (int_r0 > 0) cuts.push_back(int_r0);
+  if (int_r1 < n_rows && int_r1 > int_r0) cuts.push_back(int_r1);
+  stream_ok = n_rows > 0 && build_rowblocks(h_rowptr.data(), nullptr, n_rows, kStreamNnz, cuts.empty() ? nullptr : &cuts, rb);
   if (!stream_ok) { nblk = 0; return; }
   nblk = (int)rb.size() - 1;
+  interior_runs(rb, int_r0, int_r1, int_b0, int_b1);
   even_rows = true;
   for (int i = 0; i <= n_rows; ++i)
     if (h_rowptr[i] & 1) { even_rows = false; break; }
@@ -405,7 +454,14 @@ void Csr::build_blocked(int R, int C, hipStream_t s) {
       for (int q = 0; q < R; ++q)
         for (int t = 0; t < C; ++t) bsrc[(b * R + q) * C + t] = h_rowptr[R * r + q] + C * k + t;
     }
-  if (!build_rowblocks(rp.data(), nullptr, nr, kBlkMax, nullptr, rb)) return;
+  // cuts at the interior range in block rows (rounded inwards to whole block rows)
+  find_interior();
+  const int ib0 = (int_r0 + R - 1) / R, ib1 = int_r1 / R;
+  std::vector<int> cuts;
+  if (ib0 > 0 && ib0 < nr) cuts.push_back(ib0);
+  if (ib1 < nr && ib1 > ib0) cuts.push_back(ib1);
+  if (!build_rowblocks(rp.data(), nullptr, nr, kBlkMax, cuts.empty() ? nullptr : &cuts, rb)) return;
+  interior_runs(rb, ib0, ib1, blk_int_b0, blk_int_b1);
   blk_R = R;
   blk_C = C;
   blk_rows = nr;

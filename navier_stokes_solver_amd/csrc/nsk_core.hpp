@@ -101,6 +101,11 @@ struct Csr {  // device CSR block with host copy of the pattern
   int nblk = 0;
   bool stream_ok = false, even_rows = false;
   void build_stream_plan(hipStream_t s);
+  // Rows without ghost columns ("interior": everything but the first and last lattice columns of an x-strip, contiguous
+  // in the x-major numbering) form [int_r0, int_r1); the row-run plans are cut there, and [*_int_b0, *_int_b1) are the
+  // runs of the interior — what an SpMV can compute while the halo exchange is still in flight.
+  int int_r0 = 0, int_r1 = 0, int_b0 = 0, int_b1 = 0, blk_int_b0 = 0, blk_int_b1 = 0;
+  void find_interior();
   // R x C blocked copy (F: 2x2, (0,1): 2x1, (1,0): 1x2), built when the pattern has that structure
   bool blk_ok = false;
   int blk_R = 1, blk_C = 1, blk_rows = 0, blk_nblk = 0;
@@ -190,6 +195,10 @@ struct Stats {
 
 struct Ctx {
   hipStream_t stream = nullptr;
+  // second stream + two events: interior rows of an SpMV run there while the halo exchange occupies `stream`
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  void ensure_stream2();
   int device = 0;
   int n_cu = 256;   // compute units of the device
   Comm comm;

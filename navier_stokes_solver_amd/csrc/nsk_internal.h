@@ -15,6 +15,8 @@ enum {
                                 // both halves (measured slower than the CSR halves at 1200x400: DESIGN.md); default 0
   NSK_IOPT_TINY_BYTES = 102,    // triangular factors below this many bytes (default 4e6) are solved by ONE workgroup walking
                                 // all levels; the tests set 0 to run the streamed kernels on small meshes
+  NSK_IOPT_OVERLAP_HALO = 107,  // 1 (default): several ranks — interior rows of the inner solvers' SpMVs (F, S, Mp) run on a
+                                // second stream while the halo exchange is in flight; 0: exchange first, then one launch
   NSK_IOPT_FUSED_MGS = 106      // 1 (default): the modified Gram-Schmidt chain of an Arnoldi step in ONE launch when the
                                 // vector fits the registers of the co-resident grid (single rank); 0: one launch per link
 };

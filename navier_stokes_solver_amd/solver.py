@@ -30,7 +30,7 @@ OPT_VELOCITY_AMG = 10
 OPT_CG_SINGLE_REDUCTION = 11
 # not part of the public ABI (csrc/nsk_internal.h): study switches and the fault-injection hook of the tests
 IOPT_TRI_X_LAYOUT, IOPT_FAULT_INJECT, IOPT_WINDOW_SPMV, IOPT_TINY_BYTES, IOPT_TRI_WINDOW = 6, 100, 101, 102, 103
-IOPT_FUSED_MGS = 106
+IOPT_FUSED_MGS, IOPT_OVERLAP_HALO = 106, 107
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
 
 EXPORTS = [
@@ -51,7 +51,7 @@ class Stats(C.Structure):
                 ("spmv_bytes", C.c_double), ("tri_bytes", C.c_double), ("blas1_bytes", C.c_double),
                 ("n_colors_u", C.c_int32), ("n_levels_u", C.c_int32), ("n_colors_p", C.c_int32),
                 ("n_levels_p", C.c_int32), ("nnz_s", C.c_int64), ("sync_free_fallbacks", C.c_int64),
-                ("cur_outer_iters", C.c_int64), ("cur_residual", C.c_double)]
+                ("cur_outer_iters", C.c_int64), ("cur_residual", C.c_double), ("overlapped_spmvs", C.c_int64)]
 
 
 class NoConvergence(RuntimeError):

@@ -94,6 +94,7 @@ def test_multi_rank_path_over_gloo(world):
     (2, 2, 0, 1, "ns16_re200"),     # north_star / BASELINE configs[3]: FGMRES + aSIMPLE at nu = 1/190, row-partitioned
     (2, 2, 0, 1, "ns16+cg1"),       # the same with the single-reduction inner CG (NSK_OPT_CG_SINGLE_REDUCTION)
     (2, 2, 0, 1, "ns16_re200+cg1+gs2"),   # what bench.py --gpus N runs: plus one reduction per inner FGMRES iteration
+    (2, 2, 0, 1, "ns16+noovl"),     # halo exchange first, then one SpMV launch (default: interior rows overlap the exchange)
 ])
 def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name):
     """N rank threads on one GPU: ghost import, global reductions, D^-1 halo, SpGEMM with imported
@@ -103,6 +104,7 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name
     from oracle import oracle as O
     cg_fused = "+cg1" in name
     inner_gs = 2 if "+gs2" in name else 1
+    overlap = "+noovl" not in name
     name = name.split("+")[0]
     case = CASES[name]
     pr = problem(name)
@@ -121,6 +123,7 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name
             ls.set_option(S.OPT_TRI_ORDERING, ordering)
             ls.set_option(S.OPT_CG_SINGLE_REDUCTION, int(cg_fused))
             ls.set_option(S.OPT_INNER_FUSED_GS, inner_gs)
+            ls.set_option(S.IOPT_OVERLAP_HALO, int(overlap))
             ls.set_problem(p, plans[r])
             ur, prg = p.u_ranges, p.p_ranges
             yu, yp = ls.jacobian_vmult(xu[ur[r]:ur[r + 1]], xp[prg[r]:prg[r + 1]])
@@ -129,7 +132,8 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name
             du, dp, rc = ls.precond_vmult(xu[ur[r]:ur[r + 1]], xp[prg[r]:prg[r + 1]])
             ls.setup_preconditioner(prec, variant, 0.5)
             su, spp, its, fres, src = ls.solve(S.FGMRES, 1e-12, 100000, p.rhs_u, p.rhs_p, p.x0_u, p.x0_p)
-            res[r] = dict(yu=yu, yp=yp, du=du, dp=dp, rc=rc, su=su, sp=spp, its=its, src=src, perm_u=perm_u, perm_p=perm_p)
+            res[r] = dict(yu=yu, yp=yp, du=du, dp=dp, rc=rc, su=su, sp=spp, its=its, src=src, perm_u=perm_u, perm_p=perm_p,
+                          overlapped=ls.stats()["overlapped_spmvs"])
             ls.close()
         except Exception as e:  # noqa: BLE001
             errs.append((r, repr(e)))
@@ -159,6 +163,8 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name
     b = np.concatenate([pr.rhs_u, pr.rhs_p])
     x = np.concatenate([cat("su"), cat("sp")])
     assert all(r["src"] == 0 for r in res) and len({r["its"] for r in res}) == 1
+    if variant == 0:   # the stationary preconditioners run inner Krylov solvers, whose SpMVs overlap the halo exchange
+        assert all((r["overlapped"] > 0) == overlap for r in res), [r["overlapped"] for r in res]
     assert np.linalg.norm(b - J @ x) <= 1.05e-12
     assert rel_err(x, spl.splu(J).solve(b)) <= 1e-7
     xo, info = op.solve(b, np.concatenate([pr.x0_u, pr.x0_p]), solver=1, prec=prec, variant=variant, tol=1e-12,
