@@ -10,11 +10,13 @@ level the reference would visit (`NSSolverStationary.cpp:662-665`, `NSSolver.cpp
 `StationaryNSSolver` runs the reference's whole `solve_newton()` (continuation, Stokes phase, Newton iterations
 with backtracking) with assembly, linear solves and vector updates resident on the GPU (`newton.py`);
 `NSSolver` runs the reference's time loop (`NSSolver::solve()`, one `solve_newton()` per step with the mass term
-and the `solution_old` term in the device assembly).  `-M` (gmsh meshes) is rejected.
+and the `solution_old` term in the device assembly).  `-M FILE` (stationary driver): P2/P1 on a gmsh triangle mesh, host
+assembly (`simplex.py`) + the same GPU solves.
 """
 from __future__ import annotations
 
 import getopt
+import os
 import sys
 import time
 
@@ -53,7 +55,7 @@ def parse(argv, unsteady: bool):
                 return None, 1
             cfg["T"], cfg["dt"] = (float(v) for v in a.split(",", 1))
         elif o in ("-M", "--read-mesh-from-file"):
-            cfg["read_mesh"] = True
+            cfg["read_mesh"] = a if (o == "-M" and a) else True    # -M swallows the next token: taken as the mesh file
         elif o in ("-m", "--mesh-size"):
             if "," not in a:
                 sys.stderr.write("Error: mesh-size requires two values separated by comma\n")
@@ -115,12 +117,59 @@ def _report(backend, nx, ny, nu, inlet_u, name, counter, n_digits):
     print(f"===============================================\nDrag coefficient: {cd:g}")
 
 
+def run_gmsh(cfg, unsteady: bool) -> int:
+    """`-M FILE`: P2/P1 on a gmsh triangle mesh (NSSolverStationary.cpp:144-206).  The reference reads a hard-coded
+    path (testStationary.cpp:127) and its getopt string lets -M swallow the next token: here that token names the file."""
+    from . import gmsh as G
+    from . import newton as N
+    from . import simplex as SX
+    from . import solver as S
+    if unsteady:
+        sys.stderr.write("-M is built for the stationary driver only\n")
+        return 1
+    if cfg["prec"] not in PRECS:
+        raise ValueError("Invalid preconditioner type. Use 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE.")
+    path = cfg["read_mesh"] if isinstance(cfg["read_mesh"], str) else ""
+    print("Initializing the mesh")
+    print(f"Mesh file name = {path}")
+    space = SX.build_space(G.read_msh(path))
+    print(f"  Number of elements = {len(space.cell_u)}")
+    print("Initializing the finite element space\n  Velocity degree:           = 2\n  Pressure degree:           = 1\n"
+          "  DoFs per cell              = 15\n  Quadrature points per cell = 7\n  Quadrature points per face = 3")
+    print("-----------------------------------------------\nInitializing the DoF handler\n  Number of DoFs: ")
+    print(f"    velocity = {space.n_u}\n    pressure = {space.n_p}\n    total    = {space.n_u + space.n_p}")
+    print("-----------------------------------------------")
+    ls = S.LinearSolver()
+    ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
+    backend = N.SimplexBackend(ls, space, cfg["solver"], cfg["prec"], cfg["tol"])
+    t0 = time.time()
+    try:
+        N.solve_newton(backend, cfg["Re"])
+        u, p = backend.solution()
+        out = os.path.join(os.environ.get("NSK_OUTPUT_DIR", "./"), "output-stokes_0.vtu")
+        SX.write_vtu(out, space, u, p)
+        print("===============================================\nOutput written to output-stokes")
+        nu = 1.0 / max(_levels(10.0, 20.0, cfg["Re"]))
+        print("===============================================\n===============================================\nComputing lift and drag forces")
+        from . import postprocess as PP
+        drag, lift = SX.lift_drag(space, u, p, nu)
+        cd, cl = PP.coefficients(drag, lift, 1.0)
+        print(f"===============================================\nLift coefficient: {cl:g}")
+        print(f"===============================================\nDrag coefficient: {cd:g}")
+    finally:
+        dt = time.time() - t0
+        its = backend.total_linear_iterations
+        print(f"[nsk] {backend.assemblies} assemblies (host, P2/P1), {its} outer iterations of solve_system() on the GPU, "
+              f"{dt:.3f} s in solve_newton")
+        ls.close()
+    return 0
+
+
 def run(cfg, unsteady: bool) -> int:
     from . import problem as P
     from . import solver as S
     if cfg["read_mesh"]:
-        sys.stderr.write("-M (gmsh P2/P1 mesh from file) is outside the accelerated path; generated meshes only\n")
-        return 1
+        return run_gmsh(cfg, unsteady)
     if cfg["prec"] not in PRECS:
         raise ValueError("Invalid preconditioner type. Use 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE.")
     nx, ny = cfg["mx"], cfg["my"]

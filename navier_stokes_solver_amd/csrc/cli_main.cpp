@@ -262,7 +262,7 @@ int main(int argc, char *argv[]) {
   std::cout << "-----------------------------------------------\n";
 
   if (read_mesh_from_file) {
-    std::cerr << "-M (gmsh P2/P1 mesh from file) is outside the accelerated path; generated meshes only\n";
+    std::cerr << "-M (gmsh P2/P1 mesh from file): host assembly lives in the Python driver — python -m navier_stokes_solver_amd.cli StationaryNSSolver -M FILE ...\n";
     return 1;
   }
   nsk_handle h = nullptr;

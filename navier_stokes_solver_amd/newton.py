@@ -230,3 +230,72 @@ class DeviceBackend:
 
     def solution(self):
         return self.ls.state_get()
+
+
+class SimplexBackend:
+    """The `-M` path (gmsh triangles, P2/P1): the system is assembled on the host (`simplex.assemble`, the caller's side
+    of the hand-off, as deal.II does it for the reference) and every `solve_system()` runs on the GPU through the same C
+    ABI — first hand-off with the pattern, then `nsk_update_values` + `nsk_upload_system` per assembly.  `linear` may be
+    replaced by a host sparse-direct solver (tests: the yardstick driver)."""
+
+    def __init__(self, ls, space, solver, preconditioner, tolerance, max_iter=20000, alpha=0.5, U=0.1, p_out=1.0,
+                 direct=False):
+        import numpy as np
+        from . import solver as S
+        self.S, self.ls, self.space, self.np = S, ls, space, np
+        self.solver, self.prec, self.tol, self.max_iter, self.alpha = solver, preconditioner, tolerance, max_iter, alpha
+        self.U, self.p_out, self.direct = U, p_out, direct
+        self.sol_u, self.sol_p = np.zeros(space.n_u), np.zeros(space.n_p)      # solution = 0 (setup(), .cpp:308-311)
+        self.eval_u, self.eval_p = self.sol_u.copy(), self.sol_p.copy()
+        self.delta_u, self.delta_p = np.zeros(space.n_u), np.zeros(space.n_p)
+        self.pr = None
+        self.handed_over = False
+        self.total_linear_iterations = 0
+        self.assemblies = 0
+
+    def assemble(self, first, stokes, nu):
+        from . import simplex as SX
+        np, S = self.np, self.S
+        pr = SX.assemble(self.space, nu, mode=0 if stokes else 1, state=(self.sol_u, self.sol_p), inlet_bc=int(bool(first)),
+                         U=self.U, p_out=self.p_out)
+        self.pr = pr
+        self.assemblies += 1
+        if not self.direct:
+            if not self.handed_over:
+                self.ls.set_problem(pr)
+                self.handed_over = True
+            else:
+                for blk, A in ((S.BLK_F, pr.F), (S.BLK_BT, pr.Bt), (S.BLK_B, pr.B), (S.BLK_MP, pr.Mp)):
+                    self.ls.update_values(blk, A.val)
+            self.ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+        return float(np.sqrt(pr.rhs_u @ pr.rhs_u + pr.rhs_p @ pr.rhs_p))
+
+    def solve(self):
+        np = self.np
+        if self.direct:
+            import scipy.sparse.linalg as spl
+            J, b = self.pr.jacobian_scipy().tocsc(), np.concatenate([self.pr.rhs_u, self.pr.rhs_p])
+            x0 = np.concatenate([self.pr.x0_u, self.pr.x0_p])
+            if np.linalg.norm(b - J @ x0) <= self.tol:      # what an iterative solver reports as 0 iterations
+                x, its = x0, 0
+            else:
+                x, its = spl.splu(J).solve(b), 1
+            self.delta_u, self.delta_p = x[:self.space.n_u], x[self.space.n_u:]
+        else:
+            self.ls.setup_preconditioner(self.prec, self.S.STATIONARY, self.alpha)     # a fresh preconditioner per solve_system()
+            its, res, rc = self.ls.solve_resident(self.solver, self.tol, self.max_iter)
+            if rc != 0:
+                raise RuntimeError(f"solve_system: no convergence (status {rc}) after {its} iterations, residual {res:g}")
+            self.delta_u, self.delta_p = self.ls.download_solution()
+        self.total_linear_iterations += its
+        return its
+
+    def save(self):
+        self.eval_u, self.eval_p = self.sol_u.copy(), self.sol_p.copy()
+
+    def update(self, alpha):
+        self.sol_u = self.eval_u + alpha * self.delta_u
+        self.sol_p = self.eval_p + alpha * self.delta_p
+
+    def solution(self):
+        return self.sol_u, self.sol_p

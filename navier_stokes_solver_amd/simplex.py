@@ -1,0 +1,243 @@
+"""Taylor-Hood P2/P1 hand-off producer for gmsh triangle meshes: the caller side of the reference's `-M` path
+(`FE_SimplexP(2)^2 x FE_SimplexP(1)`, `QGaussSimplex(3)`, lab_new/src/NSSolverStationary.cpp:144-206) with the
+same weak forms, outlet term and Dirichlet rows as the generated-mesh path (`.cpp:377-576`): what deal.II would
+hand to `solve_system()`.  Host NumPy (vectorised over the triangles); the accelerated path — every linear solve —
+is the same `libnsk_hip.so` (the library never sees the mesh, only the block CSR hand-off).
+
+DoF numbering: velocity nodes = vertices, then edge midpoints; DoF 2*node + component (the two components of a node
+adjacent, as deal.II's FESystem numbering and the library's 2x2 node blocks expect); pressure = vertices.
+Boundary ids as in the reference: 7 inlet (parabolic profile, `InletVelocity`), 6 and 10 no-slip, 8 outlet
+(natural condition with `p_out`)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import problem as P
+from .gmsh import TriMesh
+
+H_CHANNEL = 0.41     # InletVelocity: 4 U y (H - y) / H^2 (NSSolverStationary.hpp:60-93)
+
+# degree-5 rule on the triangle (7 points; QGaussSimplex(3) is exact to the same degree), barycentric points
+_a1, _a2 = (6.0 - np.sqrt(15.0)) / 21.0, (6.0 + np.sqrt(15.0)) / 21.0
+_w1, _w2 = (155.0 - np.sqrt(15.0)) / 1200.0, (155.0 + np.sqrt(15.0)) / 1200.0
+QL = np.array([[1 / 3, 1 / 3, 1 / 3],
+               [1 - 2 * _a1, _a1, _a1], [_a1, 1 - 2 * _a1, _a1], [_a1, _a1, 1 - 2 * _a1],
+               [1 - 2 * _a2, _a2, _a2], [_a2, 1 - 2 * _a2, _a2], [_a2, _a2, 1 - 2 * _a2]])
+QW = np.array([9 / 40, _w1, _w1, _w1, _w2, _w2, _w2])
+EDGES = ((0, 1), (1, 2), (2, 0))     # local edge k carries local node 3 + k
+
+
+def _p2(lam):
+    """phi[n, q] and dphi/dlambda[n, q, 3] of the six P2 functions at barycentric points lam[q, 3]."""
+    nq = len(lam)
+    phi = np.zeros((6, nq))
+    dl = np.zeros((6, nq, 3))
+    for i in range(3):
+        phi[i] = lam[:, i] * (2 * lam[:, i] - 1)
+        dl[i, :, i] = 4 * lam[:, i] - 1
+    for k, (i, j) in enumerate(EDGES):
+        phi[3 + k] = 4 * lam[:, i] * lam[:, j]
+        dl[3 + k, :, i] = 4 * lam[:, j]
+        dl[3 + k, :, j] = 4 * lam[:, i]
+    return phi, dl
+
+
+@dataclass
+class SimplexSpace:
+    mesh: TriMesh
+    cell_u: np.ndarray        # (T, 6) velocity node ids
+    cell_p: np.ndarray        # (T, 3) pressure DoF ids (= vertex ids)
+    xy_u: np.ndarray          # (n_un, 2) coordinates of the velocity nodes
+    dirichlet: np.ndarray     # (n_un,) bit 0: no-slip or inlet node, bit 1: inlet node
+    grad_lam: np.ndarray      # (T, 3, 2)
+    area: np.ndarray          # (T,)
+    outlet: tuple             # (a, m, b, n_x, n_y, length): vertex, midpoint, vertex, outward normal of the id-8 edges
+    obstacle: tuple           # the same for the id-10 edges, plus the triangle each belongs to
+    n_un: int
+    n_p: int
+
+    @property
+    def n_u(self):
+        return 2 * self.n_un
+
+
+def build_space(mesh: TriMesh) -> SimplexSpace:
+    tri = mesh.tris
+    nv = len(mesh.nodes)
+    e = np.sort(np.stack([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]], axis=1).reshape(-1, 2), axis=1)
+    uniq, inv = np.unique(e, axis=0, return_inverse=True)
+    inv = np.asarray(inv).reshape(-1)
+    cell_u = np.concatenate([tri, nv + inv.reshape(-1, 3)], axis=1)
+    xy = np.concatenate([mesh.nodes, 0.5 * (mesh.nodes[uniq[:, 0]] + mesh.nodes[uniq[:, 1]])])
+    n_un = len(xy)
+    edge_id = {(int(a), int(b)): k for k, (a, b) in enumerate(uniq)}
+    p = mesh.nodes[tri]
+    J = np.stack([p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]], axis=2)          # columns x1-x0, x2-x0
+    det = J[:, 0, 0] * J[:, 1, 1] - J[:, 0, 1] * J[:, 1, 0]
+    Jinv = np.stack([np.stack([J[:, 1, 1], -J[:, 0, 1]], 1), np.stack([-J[:, 1, 0], J[:, 0, 0]], 1)], 1) / det[:, None, None]
+    g12 = Jinv                                                            # row 0: grad lam_1, row 1: grad lam_2
+    grad_lam = np.stack([-(g12[:, 0] + g12[:, 1]), g12[:, 0], g12[:, 1]], axis=1)
+    # boundary segments: owner triangle (for the outward normal), flags
+    owner = {}
+    for t, (a, b, c) in enumerate(tri):
+        for i, j, k in ((a, b, c), (b, c, a), (c, a, b)):
+            owner[(min(int(i), int(j)), max(int(i), int(j)))] = (t, int(k))
+    dirichlet = np.zeros(n_un, np.int64)
+    segs = {8: [], 10: []}
+    for (a, b), pid in zip(mesh.lines, mesh.line_ids):
+        key = (min(int(a), int(b)), max(int(a), int(b)))
+        m = nv + edge_id[key]
+        if pid == 7:
+            dirichlet[[a, b, m]] |= 3
+        elif pid in (6, 10):
+            dirichlet[[a, b, m]] |= 1
+        if pid in (8, 10):
+            t, k = owner[key]
+            tang = mesh.nodes[b] - mesh.nodes[a]
+            length = float(np.hypot(*tang))
+            nrm = np.array([tang[1], -tang[0]]) / length
+            if np.dot(nrm, mesh.nodes[k] - mesh.nodes[a]) > 0:             # must point away from the third vertex
+                nrm = -nrm
+            segs[pid].append((int(a), int(m), int(b), nrm[0], nrm[1], length, t))
+    pack = lambda L: tuple(np.array(c) for c in zip(*L)) if L else tuple(np.zeros(0) for _ in range(7))   # noqa: E731
+    return SimplexSpace(mesh, cell_u, tri.copy(), xy, dirichlet, grad_lam, 0.5 * np.abs(det), pack(segs[8]), pack(segs[10]),
+                        n_un, nv)
+
+
+def inlet_profile(y, U):
+    return 4.0 * U * y * (H_CHANNEL - y) / H_CHANNEL ** 2
+
+
+def assemble(sp_: SimplexSpace, nu, mode=1, state=None, inlet_bc=0, inv_dt=0.0, U=0.1, p_out=1.0, state_old=None):
+    """The hand-off of one `assemble_system()` (`.cpp:317-577`): mode 0 = Stokes phase (no convection, block (1,0) =
+    -B, zero residual but boundary data), mode 1 = Newton system about `state` = (u, p) (None: zero)."""
+    T = len(sp_.cell_u)
+    n_un, n_u, n_p = sp_.n_un, sp_.n_u, sp_.n_p
+    phi, dl = _p2(QL)                                           # (6, q), (6, q, 3)
+    psi = QL.T.copy()                                           # P1: psi_j = lambda_j, (3, q)
+    jxw = sp_.area[:, None] * QW[None, :]                        # (T, q)
+    dphi = np.einsum("nql,tld->tnqd", dl, sp_.grad_lam)          # (T, 6, q, 2)
+    cu, cp = sp_.cell_u, sp_.cell_p
+    if state is None:
+        su, spv = np.zeros(n_u), np.zeros(n_p)
+    else:
+        su, spv = np.asarray(state[0], float), np.asarray(state[1], float)
+    Un = np.stack([su[2 * cu], su[2 * cu + 1]], axis=1)          # (T, 2, 6)
+    u = np.einsum("tcn,nq->tcq", Un, phi)                        # (T, 2, q)
+    g = np.einsum("tcn,tnqd->tcdq", Un, dphi)                    # (T, c, d, q): d_d u_c
+    Kv = np.einsum("tq,tnqd,tmqd->tnm", jxw, dphi, dphi)
+    M = np.einsum("tq,nq,mq->tnm", jxw, phi, phi)
+    G = np.einsum("tq,tnqd,jq->tdnj", jxw, dphi, psi)            # (T, d, 6, 3)
+    Fe = np.zeros((T, 6, 2, 6, 2))
+    base = nu * Kv + inv_dt * M
+    if mode == 1:
+        adv = np.einsum("tdq,tmqd->tmq", u, dphi)                # (u . grad) phi_m
+        base = base + np.einsum("tq,nq,tmq->tnm", jxw, phi, adv)
+        Fe += np.einsum("tq,nq,tcdq,mq->tncmd", jxw, phi, g, phi)
+    for c in range(2):
+        Fe[:, :, c, :, c] += base
+    # global indices
+    ru = (2 * cu[:, :, None] + np.arange(2)[None, None, :]).reshape(T, 12)
+    Frow = np.repeat(ru[:, :, None], 12, axis=2).ravel()
+    Fcol = np.repeat(ru[:, None, :], 12, axis=1).ravel()
+    F = sp.coo_matrix((Fe.reshape(T, 12, 12).ravel(), (Frow, Fcol)), shape=(n_u, n_u)).tocsr()
+    Bt_e = -np.transpose(G, (0, 2, 1, 3)).reshape(T, 12, 3)       # rows (n, c), cols j: - int d_c phi_n psi_j
+    Bt = sp.coo_matrix((Bt_e.ravel(), (np.repeat(ru[:, :, None], 3, 2).ravel(), np.repeat(cp[:, None, :], 12, 1).ravel())),
+                       shape=(n_u, n_p)).tocsr()
+    sign = 1.0 if mode == 1 else -1.0
+    B_e = sign * np.transpose(G, (0, 3, 2, 1)).reshape(T, 3, 12)   # rows j, cols (n, c)
+    B = sp.coo_matrix((B_e.ravel(), (np.repeat(cp[:, :, None], 12, 2).ravel(), np.repeat(ru[:, None, :], 3, 1).ravel())),
+                      shape=(n_p, n_u)).tocsr()
+    Mp_e = np.einsum("tq,iq,jq->tij", jxw, psi, psi) / nu
+    Mp = sp.coo_matrix((Mp_e.ravel(), (np.repeat(cp[:, :, None], 3, 2).ravel(), np.repeat(cp[:, None, :], 3, 1).ravel())),
+                       shape=(n_p, n_p)).tocsr()
+    for A in (F, Bt, B, Mp):
+        A.sort_indices()
+    rhs_u, rhs_p = np.zeros(n_u), np.zeros(n_p)
+    if mode == 1:
+        pq = np.einsum("tj,jq->tq", spv[cp], psi)
+        re = -nu * np.einsum("tq,tcdq,tnqd->tnc", jxw, g, dphi) - np.einsum("tq,tdq,tcdq,nq->tnc", jxw, u, g, phi)
+        re += np.einsum("tq,tnqc->tnc", jxw * pq, dphi)                                    # + b(v, p)
+        if state_old is not None and inv_dt != 0.0:
+            so = np.asarray(state_old, float)
+            du = np.einsum("tcn,nq->tcq", Un - np.stack([so[2 * cu], so[2 * cu + 1]], axis=1), phi)
+            re -= inv_dt * np.einsum("tq,tcq,nq->tnc", jxw, du, phi)
+        np.add.at(rhs_u, ru.ravel(), re.reshape(T, 12).ravel())
+        np.add.at(rhs_p, cp.ravel(), np.einsum("tq,tq,jq->tj", jxw, g[:, 0, 0] + g[:, 1, 1], psi).ravel())
+    a, m, b, nx_, ny_, ln = sp_.outlet[:6]
+    if len(a):                                                   # - p_out int phi . n over the id-8 edges (Simpson: exact for P2)
+        for node, w in ((a, 1 / 6), (m, 4 / 6), (b, 1 / 6)):
+            np.add.at(rhs_u, 2 * node.astype(int), -p_out * w * ln * nx_)
+            np.add.at(rhs_u, 2 * node.astype(int) + 1, -p_out * w * ln * ny_)
+    # Dirichlet rows: cleared, diagonal = |first diagonal entry| (MatrixTools::apply_boundary_values), rhs = diag * value
+    d0 = abs(F[0, 0])
+    is_dir = np.repeat(sp_.dirichlet != 0, 2)
+    x0_u = np.zeros(n_u)
+    if inlet_bc:
+        inl = np.nonzero(sp_.dirichlet & 2)[0]
+        x0_u[2 * inl] = inlet_profile(sp_.xy_u[inl, 1], U)
+    rows_of = np.repeat(np.arange(n_u), np.diff(F.indptr))
+    F.data[is_dir[rows_of]] = 0.0
+    F.data[(rows_of == F.indices) & is_dir[rows_of]] = d0
+    Bt.data[is_dir[np.repeat(np.arange(n_u), np.diff(Bt.indptr))]] = 0.0
+    rhs_u[is_dir] = d0 * x0_u[is_dir]
+
+    def blk(A):
+        return P.CsrBlock(A.shape[0], A.shape[1], A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(float))
+    info = dict(nx=0, ny=0, nranks=1, rank=0, n_cells=T, n_removed=0, n_u_global=n_u, n_p_global=n_p,
+                u_begin=0, u_end=n_u, p_begin=0, p_end=n_p, n_ghost_u=0, n_ghost_p=0)
+    empty = P.CsrBlock(0, n_p, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    z32 = np.zeros(0, np.int32)
+    return P.LocalProblem(info, blk(F), blk(Bt), blk(B), blk(Mp), empty, rhs_u, rhs_p, x0_u, np.zeros(n_p), z32, z32,
+                          is_dir.astype(np.uint8), np.array([0, n_u]), np.array([0, n_p]),
+                          params=dict(mode=mode, nu=nu, inv_dt=inv_dt, U=U, p_out=p_out, inlet_bc=inlet_bc))
+
+
+def lift_drag(sp_: SimplexSpace, u, p, nu):
+    """Forces on the id-10 boundary (`compute_lift_drag`, `.cpp:836-897`): - int (nu (grad u + grad u^T) - p I) n ds with
+    the fluid cell's outward normal, two Gauss points per edge (the integrand is at most quadratic there)."""
+    a, m, b, nx_, ny_, ln, tt = sp_.obstacle
+    drag = lift = 0.0
+    gp = 0.5 + np.array([-0.5, 0.5]) / np.sqrt(3.0)
+    for k in range(len(a)):
+        t = int(tt[k])
+        verts = sp_.cell_u[t, :3]
+        for s in gp:
+            x = (1 - s) * sp_.mesh.nodes[int(a[k])] + s * sp_.mesh.nodes[int(b[k])]
+            lam = np.array([[1.0, x[0], x[1]]]) @ np.linalg.inv(np.column_stack([np.ones(3), sp_.mesh.nodes[verts]]).T).T
+            phi, dl = _p2(lam.reshape(1, 3))
+            dphi = np.einsum("nl,ld->nd", dl[:, 0, :], sp_.grad_lam[t])
+            cu = sp_.cell_u[t]
+            gu = np.array([[u[2 * cu + c] @ dphi[:, d] for d in range(2)] for c in range(2)])
+            pv = p[sp_.cell_p[t]] @ lam.ravel()
+            n = np.array([nx_[k], ny_[k]])
+            f = -(nu * (gu + gu.T) - pv * np.eye(2)) @ n
+            drag += 0.5 * ln[k] * f[0]
+            lift += 0.5 * ln[k] * f[1]
+    return drag, lift
+
+
+def write_vtu(path, sp_: SimplexSpace, u, p):
+    """One-piece ASCII VTU of the solution on the mesh's vertices (linear triangles; the midside values are dropped)."""
+    nv = sp_.n_p
+    with open(path, "w") as f:
+        f.write('<?xml version="1.0"?>\n<VTKFile type="UnstructuredGrid" version="0.1" byte_order="LittleEndian">\n<UnstructuredGrid>\n')
+        f.write(f'<Piece NumberOfPoints="{nv}" NumberOfCells="{len(sp_.cell_p)}">\n<Points>\n<DataArray type="Float64" NumberOfComponents="3" format="ascii">\n')
+        for x, y in sp_.mesh.nodes:
+            f.write(f"{x:.16g} {y:.16g} 0\n")
+        f.write('</DataArray>\n</Points>\n<Cells>\n<DataArray type="Int32" Name="connectivity" format="ascii">\n')
+        for t in sp_.cell_p:
+            f.write(f"{t[0]} {t[1]} {t[2]}\n")
+        f.write('</DataArray>\n<DataArray type="Int32" Name="offsets" format="ascii">\n')
+        f.write(" ".join(str(3 * (k + 1)) for k in range(len(sp_.cell_p))))
+        f.write('\n</DataArray>\n<DataArray type="UInt8" Name="types" format="ascii">\n' + " ".join(["5"] * len(sp_.cell_p)))
+        f.write('\n</DataArray>\n</Cells>\n<PointData Vectors="velocity" Scalars="pressure">\n')
+        f.write('<DataArray type="Float64" Name="velocity" NumberOfComponents="3" format="ascii">\n')
+        for k in range(nv):
+            f.write(f"{u[2 * k]:.16g} {u[2 * k + 1]:.16g} 0\n")
+        f.write('</DataArray>\n<DataArray type="Float64" Name="pressure" format="ascii">\n')
+        f.write("\n".join(f"{v:.16g}" for v in p[:nv]))
+        f.write('\n</DataArray>\n</PointData>\n</Piece>\n</UnstructuredGrid>\n</VTKFile>\n')

@@ -1,0 +1,77 @@
+"""`-M` path on the GPU: the P2/P1 hand-off of a gmsh triangle mesh (host producer, tests/test_simplex.py) through the
+same C ABI as the generated meshes — linear solves against a sparse-direct solution, and the reference's Newton driver
+with GPU solves against the same driver with sparse-direct solves."""
+import os
+
+import numpy as np
+import pytest
+
+from navier_stokes_solver_amd import gmsh as G
+from navier_stokes_solver_amd import newton as N
+from navier_stokes_solver_amd import simplex as SX
+from tests.test_simplex import REF_MESH, channel_mesh
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2])
+def test_linear_solves_on_the_reference_gmsh_mesh(prec):
+    import scipy.sparse.linalg as spl
+    from navier_stokes_solver_amd import solver as S
+    s = SX.build_space(G.read_msh(REF_MESH))
+    rng = np.random.default_rng(5)
+    free = np.repeat(s.dirichlet == 0, 2)
+    state = (0.05 * rng.uniform(-1, 1, s.n_u) * free, np.zeros(s.n_p))
+    pr = SX.assemble(s, 1.0 / 30.0, mode=1, state=state)
+    J = pr.jacobian_scipy()
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    ls = S.LinearSolver()
+    try:
+        ls.set_option(S.OPT_TRI_ORDERING, 1)
+        ls.set_option(S.IOPT_TINY_BYTES, 0)            # small factors through the streamed / single-launch kernels too
+        ls.set_problem(pr)
+        yu, yp = ls.jacobian_vmult(pr.rhs_u, pr.rhs_p)
+        assert rel_err(np.concatenate([yu, yp]), J @ b) <= 1e-13
+        ls.setup_preconditioner(prec, S.STATIONARY, 0.5)
+        xu, xp, its, res, rc = ls.solve(S.FGMRES, 1e-10, 20000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+        assert rc == 0 and its > 0
+        x = np.concatenate([xu, xp])
+        assert np.linalg.norm(b - J @ x) <= 1.05e-10
+        assert rel_err(x, spl.splu(J.tocsc()).solve(b)) <= 1e-7
+    finally:
+        ls.close()
+
+
+def test_newton_on_a_gmsh_mesh_matches_the_direct_driver(tmp_path):
+    from navier_stokes_solver_amd import solver as S
+    path = channel_mesh(str(tmp_path / "c.msh"), 24, 8, jitter=0.2)
+    s = SX.build_space(G.read_msh(path))
+    ref = N.SimplexBackend(None, s, 1, 2, 1e-11, direct=True)
+    h_ref = N.solve_newton(ref, 30.0, log=lambda *_: None)
+    ls = S.LinearSolver()
+    try:
+        ls.set_option(S.OPT_TRI_ORDERING, 1)
+        gpu = N.SimplexBackend(ls, s, S.FGMRES, S.ASIMPLE, 1e-11)
+        h_gpu = N.solve_newton(gpu, 30.0, log=lambda *_: None)
+    finally:
+        ls.close()
+    ns_ref = [h for h in h_ref if h[0] == 30.0 and h[5] is not None]
+    ns_gpu = [h for h in h_gpu if h[0] == 30.0 and h[5] is not None]
+    assert len(ns_ref) == len(ns_gpu) and ns_gpu[-1][6] < 1e-9
+    (ur, prr), (ug, pg) = ref.solution(), gpu.solution()
+    assert rel_err(ug, ur) <= 1e-7 and rel_err(pg, prr) <= 1e-6
+    # the flow is Poiseuille (empty channel): both reproduce it
+    assert np.abs(ug[0::2] - SX.inlet_profile(s.xy_u[:, 1], 0.1)).max() <= 1e-7
+
+
+def test_cli_reads_a_mesh_file(tmp_path):
+    import subprocess
+    import sys
+    env = dict(os.environ, NSK_OUTPUT_DIR=str(tmp_path))
+    out = subprocess.run([sys.executable, "-m", "navier_stokes_solver_amd.cli", "StationaryNSSolver", "-M", REF_MESH, "-r", "30",
+                          "-s", "1", "-p", "2", "-t", "1e-8"], capture_output=True, text=True, env=env, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Number of elements = 122" in out.stdout and "velocity = 568" in out.stdout and "Drag coefficient" in out.stdout
+    assert os.path.exists(tmp_path / "output-stokes_0.vtu")

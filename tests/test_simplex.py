@@ -1,0 +1,113 @@
+"""`-M` path: gmsh reader and the P2/P1 Taylor-Hood hand-off producer (host side), checked without a
+GPU against facts that do not depend on this code: mesh areas, the exact Poiseuille solution (which P2/P1 holds on any
+triangulation of the channel), and Newton's quadratic convergence with a sparse-direct linear solver."""
+import os
+
+import numpy as np
+import pytest
+
+from navier_stokes_solver_amd import gmsh as G
+from navier_stokes_solver_amd import newton as N
+from navier_stokes_solver_amd import simplex as SX
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_MESH = os.path.join(HERE, "golden", "reference_gmsh41_2dMeshReallyCoarse.msh")   # the reference's own asset (data)
+
+
+def channel_mesh(path, nx=8, ny=4, L=2.2, H=0.41, jitter=0.0, seed=0):
+    """Structured triangulation of the empty channel with the reference's boundary ids (6 walls, 7 inlet, 8 outlet),
+    written as MSH 2.2; interior vertices optionally moved so that the triangles are not congruent."""
+    rng = np.random.default_rng(seed)
+    xs, ys = np.linspace(0, L, nx + 1), np.linspace(0, H, ny + 1)
+    nodes = np.array([[x, y] for x in xs for y in ys])
+    idx = lambda i, j: i * (ny + 1) + j    # noqa: E731
+    for i in range(1, nx):
+        for j in range(1, ny):
+            nodes[idx(i, j)] += jitter * rng.uniform(-1, 1, 2) * np.array([L / nx, H / ny])
+    tris, lines, ids = [], [], []
+    for i in range(nx):
+        for j in range(ny):
+            a, b, c, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
+            tris += [(a, b, c), (a, c, d)] if (i + j) % 2 == 0 else [(a, b, d), (b, c, d)]
+    for i in range(nx):
+        lines += [(idx(i, 0), idx(i + 1, 0)), (idx(i, ny), idx(i + 1, ny))]; ids += [6, 6]
+    for j in range(ny):
+        lines += [(idx(0, j), idx(0, j + 1)), (idx(nx, j), idx(nx, j + 1))]; ids += [7, 8]
+    G.write_msh2(path, nodes, tris, lines, ids)
+    return path
+
+
+def test_reader_msh41_reference_asset():
+    m = G.read_msh(REF_MESH)
+    assert m.nodes.shape == (81, 2) and m.tris.shape == (122, 3) and len(m.lines) == 40
+    assert dict(zip(*np.unique(m.line_ids, return_counts=True))) == {6: 32, 7: 4, 8: 4}
+    s = SX.build_space(m)
+    # channel minus the polygon inscribed in the obstacle circle (radius 0.05): between the two areas
+    assert 2.2 * 0.41 - np.pi * 0.05 ** 2 < s.area.sum() < 2.2 * 0.41 - 0.9 * np.pi * 0.05 ** 2
+    assert s.n_un == 81 + (81 + 122 - 0) and s.n_p == 81            # Euler: V - E + T = 0 for one hole -> E = V + T
+    inlet = np.nonzero(s.dirichlet & 2)[0]
+    assert len(inlet) == 9 and np.allclose(s.xy_u[inlet, 0], 0.0)
+
+
+def test_reader_msh22_round_trip(tmp_path):
+    m = G.read_msh(channel_mesh(str(tmp_path / "c.msh"), 6, 3, jitter=0.2))
+    assert m.tris.shape == (36, 3) and len(m.lines) == 18
+    s = SX.build_space(m)
+    assert abs(s.area.sum() - 2.2 * 0.41) < 1e-14 and np.all(s.area > 0)
+    assert np.allclose(s.grad_lam.sum(axis=1), 0.0)
+    assert len(s.outlet[0]) == 3 and np.allclose(s.outlet[3], 1.0) and np.allclose(s.outlet[4], 0.0)   # outward normal +x
+
+
+@pytest.mark.parametrize("jitter", [0.0, 0.25])
+def test_stokes_poiseuille_is_reproduced_exactly(tmp_path, jitter):
+    """u = (4 U y (H - y) / H^2, 0), p = p_out + 8 nu U (L - x) / H^2 solves the Stokes problem with the reference's
+    boundary conditions and lies in P2 x P1 on any triangulation: the discrete solution must be that field."""
+    import scipy.sparse.linalg as spl
+    s = SX.build_space(G.read_msh(channel_mesh(str(tmp_path / "c.msh"), 8, 4, jitter=jitter)))
+    nu, U, p_out = 0.1, 0.1, 1.0
+    pr = SX.assemble(s, nu, mode=0, inlet_bc=1, U=U, p_out=p_out)
+    J = pr.jacobian_scipy()
+    x = spl.splu(J.tocsc()).solve(np.concatenate([pr.rhs_u, pr.rhs_p]))
+    u, p = x[:s.n_u], x[s.n_u:]
+    assert np.abs(u[0::2] - SX.inlet_profile(s.xy_u[:, 1], U)).max() <= 1e-12
+    assert np.abs(u[1::2]).max() <= 1e-12
+    assert np.abs(p - (p_out + 8 * nu * U * (2.2 - s.mesh.nodes[:, 0]) / 0.41 ** 2)).max() <= 1e-10
+    # node-block structure the library's 2x2 / 2x1 / 1x2 formats rely on
+    F = pr.F.to_scipy()
+    assert np.array_equal(F[0::2].indices, F[1::2].indices) and np.all(F.indices.reshape(-1, 2)[:, 0] % 2 == 0)
+
+
+def test_newton_system_is_the_derivative_of_the_residual(tmp_path):
+    """J(state) dx = r(state + dx) - r(state) to second order: the assembled Newton matrix is the linearisation of
+    the assembled residual (the reference assembles both in one loop, .cpp:408-526)."""
+    s = SX.build_space(G.read_msh(channel_mesh(str(tmp_path / "c.msh"), 5, 3, jitter=0.2)))
+    rng = np.random.default_rng(1)
+    free = np.repeat(s.dirichlet == 0, 2)
+    u0, p0 = rng.uniform(-1, 1, s.n_u) * free, rng.uniform(-1, 1, s.n_p)
+    du, dp = rng.uniform(-1, 1, s.n_u) * free, rng.uniform(-1, 1, s.n_p)
+    nu = 0.05
+    pr0 = SX.assemble(s, nu, mode=1, state=(u0, p0))
+    J = pr0.jacobian_scipy()
+    errs = []
+    for eps in (1e-2, 1e-3):
+        pr1 = SX.assemble(s, nu, mode=1, state=(u0 + eps * du, p0 + eps * dp))
+        dr = np.concatenate([pr1.rhs_u - pr0.rhs_u, pr1.rhs_p - pr0.rhs_p])
+        lin = -(J @ np.concatenate([eps * du, eps * dp]))          # r = -F(x): dr = -J dx
+        # continuity: the reference assembles +b(u,q) against +B, so that block's sign is flipped
+        lin[s.n_u:] *= -1.0
+        errs.append(np.abs((dr - lin)[np.concatenate([free, np.ones(s.n_p, bool)])]).max())
+    assert errs[1] <= 0.02 * errs[0] + 1e-13     # second order in eps
+
+
+def test_newton_driver_with_direct_solves_converges_on_the_reference_mesh():
+    """The reference's solve_newton() control flow over the P2/P1 hand-off with sparse-direct linear solves: the yardstick
+    the GPU run is compared with (tests/test_gpu_simplex.py)."""
+    s = SX.build_space(G.read_msh(REF_MESH))
+    backend = N.SimplexBackend(None, s, 1, 2, 1e-10, direct=True)
+    hist = N.solve_newton(backend, 30.0, log=lambda *_: None)     # level Re 10: the Stokes passes; level Re 30: Newton on NS
+    ns = [h for h in hist if h[0] == 30.0 and h[5] is not None]
+    assert ns and ns[-1][6] < 1e-9
+    assert all(b[6] < 0.1 * a[6] for a, b in zip(ns, ns[1:]) if a[6] > 1e-8)        # contracts fast from the Stokes solution
+    u, p = backend.solution()
+    assert np.abs(u[0::2][(s.dirichlet & 2) != 0] - SX.inlet_profile(s.xy_u[(s.dirichlet & 2) != 0, 1], 0.1)).max() < 1e-12
+    assert np.isfinite(SX.lift_drag(s, u, p, 0.1)).all()
