@@ -45,7 +45,7 @@ def _p2(lam):
     return phi, dl
 
 
-@dataclass
+@dataclass(eq=False)
 class SimplexSpace:
     mesh: TriMesh
     cell_u: np.ndarray        # (T, 6) velocity node ids
@@ -107,6 +107,45 @@ def build_space(mesh: TriMesh) -> SimplexSpace:
                         n_un, nv)
 
 
+def _static(sp_: SimplexSpace):
+    """State-independent element data and the COO -> CSR scatter maps of the four blocks (the pattern is fixed for the
+    run, as `jacobian_matrix.reinit(sparsity)` happens once, .cpp:304), computed on first use."""
+    if getattr(sp_, "_st", None) is not None:
+        return sp_._st
+    T = len(sp_.cell_u)
+    n_u, n_p = sp_.n_u, sp_.n_p
+    phi, dl = _p2(QL)
+    psi = QL.T.copy()
+    jxw = sp_.area[:, None] * QW[None, :]
+    dphi = np.einsum("nql,tld->tnqd", dl, sp_.grad_lam)
+    cu, cp = sp_.cell_u, sp_.cell_p
+    ru = (2 * cu[:, :, None] + np.arange(2)[None, None, :]).reshape(T, 12)
+
+    def pattern(rows, cols, shape):
+        key = rows.astype(np.int64) * shape[1] + cols
+        uniq, inv = np.unique(key, return_inverse=True)
+        r, c = uniq // shape[1], uniq % shape[1]
+        indptr = np.zeros(shape[0] + 1, np.int32)
+        np.add.at(indptr, r + 1, 1)
+        return np.cumsum(indptr).astype(np.int32), c.astype(np.int32), np.asarray(inv).reshape(-1), r
+
+    st = dict(phi=phi, psi=psi, jxw=jxw, dphi=dphi, ru=ru,
+              Kv=np.einsum("tq,tnqd,tmqd->tnm", jxw, dphi, dphi), M=np.einsum("tq,nq,mq->tnm", jxw, phi, phi),
+              G=np.einsum("tq,tnqd,jq->tdnj", jxw, dphi, psi), Mp=np.einsum("tq,iq,jq->tij", jxw, psi, psi),
+              F=pattern(np.repeat(ru[:, :, None], 12, axis=2).ravel(), np.repeat(ru[:, None, :], 12, axis=1).ravel(), (n_u, n_u)),
+              Bt=pattern(np.repeat(ru[:, :, None], 3, 2).ravel(), np.repeat(cp[:, None, :], 12, 1).ravel(), (n_u, n_p)),
+              B=pattern(np.repeat(cp[:, :, None], 12, 2).ravel(), np.repeat(ru[:, None, :], 3, 1).ravel(), (n_p, n_u)),
+              MpP=pattern(np.repeat(cp[:, :, None], 3, 2).ravel(), np.repeat(cp[:, None, :], 3, 1).ravel(), (n_p, n_p)))
+    sp_._st = st
+    return st
+
+
+def _csr(pat, vals, shape):
+    indptr, indices, inv, _ = pat
+    data = np.bincount(inv, weights=vals.ravel(), minlength=len(indices))
+    return sp.csr_matrix((data, indices, indptr), shape=shape)
+
+
 def inlet_profile(y, U):
     return 4.0 * U * y * (H_CHANNEL - y) / H_CHANNEL ** 2
 
@@ -116,10 +155,8 @@ def assemble(sp_: SimplexSpace, nu, mode=1, state=None, inlet_bc=0, inv_dt=0.0, 
     -B, zero residual but boundary data), mode 1 = Newton system about `state` = (u, p) (None: zero)."""
     T = len(sp_.cell_u)
     n_un, n_u, n_p = sp_.n_un, sp_.n_u, sp_.n_p
-    phi, dl = _p2(QL)                                           # (6, q), (6, q, 3)
-    psi = QL.T.copy()                                           # P1: psi_j = lambda_j, (3, q)
-    jxw = sp_.area[:, None] * QW[None, :]                        # (T, q)
-    dphi = np.einsum("nql,tld->tnqd", dl, sp_.grad_lam)          # (T, 6, q, 2)
+    st = _static(sp_)
+    phi, psi, jxw, dphi, ru = st["phi"], st["psi"], st["jxw"], st["dphi"], st["ru"]
     cu, cp = sp_.cell_u, sp_.cell_p
     if state is None:
         su, spv = np.zeros(n_u), np.zeros(n_p)
@@ -128,34 +165,20 @@ def assemble(sp_: SimplexSpace, nu, mode=1, state=None, inlet_bc=0, inv_dt=0.0, 
     Un = np.stack([su[2 * cu], su[2 * cu + 1]], axis=1)          # (T, 2, 6)
     u = np.einsum("tcn,nq->tcq", Un, phi)                        # (T, 2, q)
     g = np.einsum("tcn,tnqd->tcdq", Un, dphi)                    # (T, c, d, q): d_d u_c
-    Kv = np.einsum("tq,tnqd,tmqd->tnm", jxw, dphi, dphi)
-    M = np.einsum("tq,nq,mq->tnm", jxw, phi, phi)
-    G = np.einsum("tq,tnqd,jq->tdnj", jxw, dphi, psi)            # (T, d, 6, 3)
+    G = st["G"]                                                  # (T, d, 6, 3): int d_d phi_n psi_j
     Fe = np.zeros((T, 6, 2, 6, 2))
-    base = nu * Kv + inv_dt * M
+    base = nu * st["Kv"] + inv_dt * st["M"]
     if mode == 1:
         adv = np.einsum("tdq,tmqd->tmq", u, dphi)                # (u . grad) phi_m
         base = base + np.einsum("tq,nq,tmq->tnm", jxw, phi, adv)
         Fe += np.einsum("tq,nq,tcdq,mq->tncmd", jxw, phi, g, phi)
     for c in range(2):
         Fe[:, :, c, :, c] += base
-    # global indices
-    ru = (2 * cu[:, :, None] + np.arange(2)[None, None, :]).reshape(T, 12)
-    Frow = np.repeat(ru[:, :, None], 12, axis=2).ravel()
-    Fcol = np.repeat(ru[:, None, :], 12, axis=1).ravel()
-    F = sp.coo_matrix((Fe.reshape(T, 12, 12).ravel(), (Frow, Fcol)), shape=(n_u, n_u)).tocsr()
-    Bt_e = -np.transpose(G, (0, 2, 1, 3)).reshape(T, 12, 3)       # rows (n, c), cols j: - int d_c phi_n psi_j
-    Bt = sp.coo_matrix((Bt_e.ravel(), (np.repeat(ru[:, :, None], 3, 2).ravel(), np.repeat(cp[:, None, :], 12, 1).ravel())),
-                       shape=(n_u, n_p)).tocsr()
+    F = _csr(st["F"], Fe, (n_u, n_u))
+    Bt = _csr(st["Bt"], -np.transpose(G, (0, 2, 1, 3)), (n_u, n_p))            # rows (n, c), cols j: - int d_c phi_n psi_j
     sign = 1.0 if mode == 1 else -1.0
-    B_e = sign * np.transpose(G, (0, 3, 2, 1)).reshape(T, 3, 12)   # rows j, cols (n, c)
-    B = sp.coo_matrix((B_e.ravel(), (np.repeat(cp[:, :, None], 12, 2).ravel(), np.repeat(ru[:, None, :], 3, 1).ravel())),
-                      shape=(n_p, n_u)).tocsr()
-    Mp_e = np.einsum("tq,iq,jq->tij", jxw, psi, psi) / nu
-    Mp = sp.coo_matrix((Mp_e.ravel(), (np.repeat(cp[:, :, None], 3, 2).ravel(), np.repeat(cp[:, None, :], 3, 1).ravel())),
-                       shape=(n_p, n_p)).tocsr()
-    for A in (F, Bt, B, Mp):
-        A.sort_indices()
+    B = _csr(st["B"], sign * np.transpose(G, (0, 3, 2, 1)), (n_p, n_u))         # rows j, cols (n, c)
+    Mp = _csr(st["MpP"], st["Mp"] / nu, (n_p, n_p))
     rhs_u, rhs_p = np.zeros(n_u), np.zeros(n_p)
     if mode == 1:
         pq = np.einsum("tj,jq->tq", spv[cp], psi)
