@@ -45,7 +45,7 @@ def test_linear_solves_on_the_reference_gmsh_mesh(prec):
 
 def test_newton_on_a_gmsh_mesh_matches_the_direct_driver(tmp_path):
     from navier_stokes_solver_amd import solver as S
-    path = channel_mesh(str(tmp_path / "c.msh"), 24, 8, jitter=0.2)
+    path = channel_mesh(str(tmp_path / "c.msh"), 16, 6, jitter=0.2)
     s = SX.build_space(G.read_msh(path))
     ref = N.SimplexBackend(None, s, 1, 2, 1e-11, direct=True)
     h_ref = N.solve_newton(ref, 30.0, log=lambda *_: None)
