@@ -87,7 +87,6 @@ struct nsk_handle_s {
   int sync_free_mode = 2;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
   int fault_inject = 0;    // NSK_IOPT_FAULT_INJECT
   int use_win_spmv = 0;    // NSK_IOPT_WINDOW_SPMV
-  int tri_window = 0;      // NSK_IOPT_TRI_WINDOW
   DBuf<int> jrow_blk, jblk_blk;  // row runs of the fused (F | Bt) block row: CSR and blocked variants
   int jrow_nblk = 0, jblk_nblk = 0;
   bool jrow_ok = false, jblk_ok = false;
@@ -288,7 +287,6 @@ struct nsk_handle_s {
         NSK_HIP(hipMemcpy(&ei, T->sf_err.p, sizeof(int), hipMemcpyDeviceToHost));
         if (ei) {
           NSK_HIP(hipMemsetAsync(T->sf_err.p, 0, sizeof(int), s()));
-          T->win_dirty = true;   // the working vectors of the abandoned solve are garbage
           T->sf_armed = false;
         }
         e |= ei;
@@ -368,11 +366,8 @@ void H::setup(int type, int variant_, double alpha_) {
   ensure_pools();
   tMp.sync_free = tS.sync_free = sync_free_mode >= 1;
   tF.sync_free = sync_free_mode == 2;
-  tMp.win_fault = tS.win_fault = (fault_inject & 1) ? 1 : 0;
   tMp.sf_fault = tS.sf_fault = (fault_inject & 1) != 0;
   tF.sf_fault = (fault_inject & 2) != 0;
-  if (tMp.use_window != (tri_window != 0)) { tMp.use_window = tri_window != 0; tMp_ok = false; }
-  if (tS.use_window != (tri_window != 0)) { tS.use_window = tri_window != 0; tS_ok = false; }
   // working-vector layout of the blocked velocity factor: colour-ordered whenever it runs single-launch (its
   // per-level kernels only know the caller's order).  The scalar factors always solve on colour-ordered vectors.
   const int f_layout = (x_layout_mode != 0 && sync_free_mode == 2) ? 1 : 0;
@@ -776,7 +771,6 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
       break;
     case NSK_IOPT_FAULT_INJECT:
       h->fault_inject = (int)v;
-      h->tMp.win_fault = h->tS.win_fault = (h->fault_inject & 1) ? 1 : 0;
       h->tMp.sf_fault = h->tS.sf_fault = (h->fault_inject & 1) != 0;
       h->tF.sf_fault = (h->fault_inject & 2) != 0;
       break;
@@ -787,7 +781,6 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
         if (h->blk[NSK_BLK_S].present && !h->blk[NSK_BLK_S].win_ok) { h->blk[NSK_BLK_S].build_win(h->s()); h->ctx.sync(); }
       }
       break;
-    case NSK_IOPT_TRI_WINDOW: h->tri_window = v != 0.0; break;
     case NSK_IOPT_FUSED_MGS: h->ctx.fused_mgs = v != 0.0; break;
     case NSK_IOPT_OVERLAP_HALO: h->overlap_halo = v != 0.0; break;
     case NSK_IOPT_TINY_BYTES: h->tF.tiny_bytes = h->tMp.tiny_bytes = h->tS.tiny_bytes = v; break;
@@ -1248,9 +1241,8 @@ int nsk_debug_tri_trace(nsk_handle h, int which, int64_t *out16, int max_runs, i
   (void)hipSetDevice(h->ctx.device);
   if (h->prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
   TriSolve *T = which == NSK_TRI_VELOCITY ? &h->tF : h->tP;
-  const bool window = T->win_ready;
-  if (!window && !(T->stream_ready && T->sync_free)) return 0;
-  const int n_wg = window ? T->win_nruns : T->n_Lsf + T->n_Usf;
+  if (!(T->stream_ready && T->sync_free)) return 0;   // only the scalar single-launch kernels carry the stamps
+  const int n_wg = T->n_Lsf + T->n_Usf;
   VecPool &p = which == NSK_TRI_VELOCITY ? h->pool_u : h->pool_p;
   double *bv = p.get(true), *xv = p.get(true);
   vec_set(h->s(), p.n, bv, 1.0);
@@ -1258,15 +1250,15 @@ int nsk_debug_tri_trace(nsk_handle h, int which, int64_t *out16, int max_runs, i
   DBuf<long long> dbg;
   dbg.alloc((size_t)n_wg * 16);
   NSK_HIP(hipMemsetAsync(dbg.p, 0, sizeof(long long) * dbg.n, h->s()));
-  T->win_dbg = dbg.p;
+  T->sf_dbg = dbg.p;
   T->apply(bv, xv);
-  T->win_dbg = nullptr;
+  T->sf_dbg = nullptr;
   const int n = std::min(max_runs, n_wg);
   NSK_HIP(hipMemcpyAsync(out16, dbg.p, sizeof(long long) * (size_t)n * 16, hipMemcpyDeviceToHost, h->s()));
   h->ctx.sync();
   p.put(bv);
   p.put(xv);
-  if (grid) *grid = window ? (T->sync_free ? std::min(T->win_grid, T->win_nruns) : 0) : -T->n_Lsf;
+  if (grid) *grid = -T->n_Lsf;
   h->check_sync_free();
   return n_wg;
   NSK_CATCH(h)

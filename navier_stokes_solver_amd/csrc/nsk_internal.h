@@ -6,13 +6,11 @@
 enum {
   NSK_IOPT_TRI_X_LAYOUT = 6,    // blocked velocity factor: 2 (default) colour-ordered working vector when it runs
                                 // single-launch, 0 the caller's order
-  NSK_IOPT_FAULT_INJECT = 100,  // bit 0: the scalar triangular solves walk their upper half (window variant: the whole run list) backwards,
+  NSK_IOPT_FAULT_INJECT = 100,  // bit 0: the scalar triangular solves walk their upper half backwards,
                                 // bit 1: the blocked velocity solve walks its upper half backwards — consumers before
                                 // producers, so the bounded spins give up and the fallback has to take over
   NSK_IOPT_WINDOW_SPMV = 101,   // 1: SpMV with S / Mp on the window format (measured on par with the CSR-stream kernel at
                                 // 1200x400: 0.256 vs 0.249 ms for S); 0 (default): CSR-stream kernel
-  NSK_IOPT_TRI_WINDOW = 103,    // 1: scalar triangular factors (S, Mp) on the window format with ONE persistent launch for
-                                // both halves (measured slower than the CSR halves at 1200x400: DESIGN.md); default 0
   NSK_IOPT_TINY_BYTES = 102,    // triangular factors below this many bytes (default 4e6) are solved by ONE workgroup walking
                                 // all levels; the tests set 0 to run the streamed kernels on small meshes
   NSK_IOPT_OVERLAP_HALO = 107,  // 1 (default): several ranks — interior rows of the inner solvers' SpMVs (F, S, Mp) run on a
@@ -24,17 +22,13 @@ enum {
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* Diagnostics: one apply of the scalar (window-format) triangular preconditioner `which` with in-kernel time stamps
- * (s_memrealtime, 10 ns ticks).  out16 receives 16 int64 per run of the dispatch-ordered list:
- *   stream role: [0] before barrier A, [1] after A, [2] after the products, [3] after barrier B
- *   window role: [4] start of the run, [5] window copy and next-run loads issued, [6] after A, [7] results stored
- *   [8] threads that found a sentinel in the window and had to poll.
- * CSR-halves kernels (default): per workgroup of the lower launch, then of the upper launch: [0] start, [1] matrix
- * stream and first look at the gathered entries have landed, [2] wave 0 has all its entries (polls done), [3] all waves
- * have, [4] results stored, [5] gathered entries that still held the sentinel, [6] XCC id, [7] rows, [8] non-zeros;
- * *grid = -(workgroups of the lower launch).
- * Returns the number of runs of the list (0: this factor does not use the window format); *grid = workgroups of the
- * persistent launch (0: one launch per colour). */
+/* Diagnostics: one apply of the scalar single-launch triangular preconditioner `which` with in-kernel time stamps
+ * (s_memrealtime, 10 ns ticks).  out16 receives 16 int64 per workgroup of the lower launch, then of the upper launch:
+ *   [0] start, [1] matrix stream and first look at the gathered entries have landed (products in LDS), [2] wave 0 has
+ *   all its entries (polls done), [3] all waves have, [4] results stored, [5] gathered entries that still held the
+ *   sentinel at first look, [6] XCC id, [7] rows, [8] non-zeros, [9] descriptor arrived.
+ * Returns the number of workgroups (0: this factor does not run the scalar single-launch kernels); *grid = -(workgroups
+ * of the lower launch). */
 int nsk_debug_tri_trace(struct nsk_handle_s *h, int which, int64_t *out16, int max_runs, int *grid);
 #ifdef __cplusplus
 }

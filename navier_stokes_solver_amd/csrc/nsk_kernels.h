@@ -211,29 +211,6 @@ void spmv_win(hipStream_t s, const WinView &A, int n_runs, const double *x, doub
 // y[i] = idx[i] >= 0 ? x[idx[i]] : 0   (values of the padded window slots)
 void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, double *y);
 
-// Triangular solve on the window format, both halves in ONE run list in dispatch order (lower colours ascending,
-// then upper colours descending).  Working vectors are in COLOUR order and 128-byte aligned:
-//   Y   lower result; every entry holds the sentinel on entry, and again on exit (the upper run of a row resets it)
-//   X   upper result of this call (sentinel on entry);  Xnext: the buffer of the NEXT call, reset here
-// rhs / out are in the caller's order (gathered / scattered through perm).  Runs [i0, i1) of the list are solved by
-// `grid` workgroups, workgroup g taking runs i0 + g, i0 + g + grid, ...: with grid <= the number of co-resident
-// workgroups this needs no assumption on the dispatch order (every wait is on a run a resident workgroup owns);
-// with grid = i1 - i0 and launches cut at colour boundaries it is the plain level-by-level schedule.
-struct WinTriArgs {
-  const double *dinv;   // per row (colour order): 1 / diagonal
-  const int *perm;      // colour order -> caller's order
-  const double *rhs;    // caller's order
-  double *Y, *X, *Xnext, *out;
-  int *err;
-  long long *dbg = nullptr;   // diagnostics: 16 int64 per run of the list (nsk_internal.h: nsk_debug_tri_trace)
-};
-void tri_win_solve(hipStream_t s, const WinView &M, int i0, int i1, int grid, int kind, int reverse /* test hook */,
-                   const WinTriArgs &a);
-int tri_win_max_resident_per_cu();   // occupancy API's answer for the kernel above (workgroups per CU)
-// census launch of `grid` workgroups of that kernel: afterwards two_ints[1] == 0 iff they were all resident together
-// (two_ints must be zeroed before the launch)
-void tri_win_census(hipStream_t s, int grid, int kind, int *two_ints);
-
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,
                        const int *col, double *val, int max_row_nnz);

@@ -792,232 +792,6 @@ __global__ __launch_bounds__(BLK) void spmv_win_kernel(WinView M, const double *
   }
 }
 
-constexpr int TWB = 2 * BLK;
-constexpr int RGW = 4;   // lanes per row in the row sums
-
-struct WinTriK {   // kernel arguments of the triangular window solve
-  WinView M;
-  int i0, i1, reverse;
-  const double *dinv;
-  const int *perm;
-  const double *rhs;
-  double *Y, *X, *Xnext, *out;
-  int *err;
-  long long *dbg;   // diagnostics (null in production): 16 time stamps / counters per run, see nsk_internal.h
-};
-__device__ __forceinline__ void win_stamp(const WinTriK &a, int run, int k) {
-  if (a.dbg) a.dbg[(size_t)run * 16 + k] = (long long)__builtin_amdgcn_s_memrealtime();
-}
-// reverse (test hook): walk the list backwards, i.e. consumers before their producers, to exercise the bounded
-// spins and the fallback
-__device__ __forceinline__ int win_at(const WinTriK &a, int k) { return a.reverse ? a.i1 - 1 - (k - a.i0) : k; }
-
-// stream role (waves 0-3): values and window positions of the NEXT run in registers, products into LDS
-__device__ __forceinline__ void tri_win_stream_role(const WinTriK &a, int t, const double *win, double *prod,
-                                                    const int *s_lines) {
-  const WinView &M = a.M;
-  int i = a.i0 + (int)blockIdx.x;
-  int4 d0 = M.runs[2 * win_at(a, i)], d1 = M.runs[2 * win_at(a, i) + 1];
-  WinRegs R;
-  for (bool first = true;; first = false) {
-    int4 n0 = d0, n1 = d1;
-    int inext = i;
-    if (!first) {
-      const int nrows = d0.y, q2 = d1.y;
-      double *W = (d1.w & 1) ? a.X : a.Y;
-      if (nrows > 0) {   // (padding runs of the dispatch order are empty)
-        if (t == 0) win_stamp(a, win_at(a, i), 0);
-        __syncthreads();   // A: the window of this run is in LDS
-        if (t == 0) win_stamp(a, win_at(a, i), 1);
-        const int e0 = t * 2 * q2, N = (d1.w >> 1) & 0xfff;   // entries of the run
-        bool missing = false;   // a window entry this thread needs still holds the sentinel
-#pragma unroll
-        for (int j = 0; j < WQ; ++j)
-          if (j < q2) {
-            const double xa = win[R.c[j] & 0xffffu], xb = win[R.c[j] >> 16];
-            missing |= (e0 + 2 * j < N && (unsigned long long)__double_as_longlong(xa) == kSentinel) ||
-                       (e0 + 2 * j + 1 < N && (unsigned long long)__double_as_longlong(xb) == kSentinel);
-            prod[e0 + 2 * j] = R.v[j].x * xa;
-            prod[e0 + 2 * j + 1] = R.v[j].y * xb;
-          }
-        if (a.dbg && missing) atomicAdd(reinterpret_cast<unsigned long long *>(a.dbg) + (size_t)win_at(a, i) * 16 + 8, 1ull);
-        if (missing) {   // rare: a producer's store had not landed when the window was copied — poll those entries
-          // (re-reads its slots from memory instead of keeping the register copy alive through the loop)
-          const unsigned short *pos16 = reinterpret_cast<const unsigned short *>(M.pos);
-#pragma unroll 1
-          for (int e = e0; e < min(N, e0 + 2 * q2); ++e) {
-            const size_t slot = 2 * ((size_t)d1.x + (size_t)((e - e0) >> 1) * BLK + (size_t)t) + (size_t)((e - e0) & 1);
-            const unsigned p = pos16[slot];
-            if ((unsigned long long)__double_as_longlong(win[p]) == kSentinel)
-              prod[e] = M.val[slot] * sf_wait(W + (size_t)s_lines[p >> 4] * 16 + (p & 15u), kSentinel, a.err);
-          }
-        }
-      }
-      if (t == 0 && nrows > 0) win_stamp(a, win_at(a, i), 2);
-    }
-    if (!first && d0.y > 0) {
-      __syncthreads();   // B: the products of this run are in LDS
-      if (t == 0) win_stamp(a, win_at(a, i), 3);
-    }
-    if (!first) {
-      inext = i + (int)gridDim.x;
-      n0 = n1 = make_int4(0, 0, 0, 0);   // no next run: an empty one (its loads are all masked off)
-      if (inext < a.i1) { n0 = M.runs[2 * win_at(a, inext)]; n1 = M.runs[2 * win_at(a, inext) + 1]; }
-    }
-    // the (next) run's matrix stream: in flight during the whole step before it is used (issued behind barrier B so
-    // that the window role starts the row sums as early as possible)
-#pragma unroll
-    for (int j = 0; j < WQ; ++j) {
-      const bool ok = j < n1.y;   // uniform in the workgroup
-      const size_t pi = (size_t)n1.x + (size_t)(ok ? j : 0) * BLK + (size_t)t;
-      R.v[j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const dvec2 *>(M.val) + pi) : dvec2{0.0, 0.0};
-      R.c[j] = ok ? __builtin_nontemporal_load(M.pos + pi) : 0u;
-    }
-    i = inext;
-    d0 = n0;
-    d1 = n1;
-    if (i >= a.i1) break;
-  }
-}
-
-// window role (waves 4-7): window lines into LDS, then the row sums and the results
-template <int KIND>
-__device__ __forceinline__ void tri_win_window_role(const WinTriK &a, int t, double *win, const double *prod,
-                                                    int *s_lines) {
-  const WinView &M = a.M;
-  int i = a.i0 + (int)blockIdx.x;
-  int4 d0 = M.runs[2 * win_at(a, i)], d1 = M.runs[2 * win_at(a, i) + 1];
-  int ln[WLD];                   // line ids of this thread's 16-byte window chunks
-  int jb = 0, je = 0, ip = 0;    // row data of the first reduce pass (row t / RGW of the run)
-  double dv = 1.0;
-  for (bool first = true;; first = false) {
-    int4 n0 = d0, n1 = d1;
-    int inext = i;
-    const int cjb = jb, cje = je, cip = ip;
-    const double cdv = dv;
-    unsigned long long ownb = 0ull;
-    const int r0 = d0.x, nrows = d0.y, roff0 = d1.z;
-    const bool upper = d1.w & 1, work = !first && nrows > 0;
-    double *W = upper ? a.X : a.Y;
-    if (!first) {
-      if (work) {
-        if (t == 0) win_stamp(a, win_at(a, i), 4);
-        // window lines -> LDS by LDS-DMA (16 B per lane, a wave writes 1 KB of contiguous LDS per instruction: no
-        // staging registers); the row's own value rides along (lower: rhs through perm, upper: the lower result)
-        const int wbase = __builtin_amdgcn_readfirstlane(t & ~63);
-#pragma unroll
-        for (int u = 0; u < WLD; ++u)
-          if (ln[u] >= 0)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(W + (size_t)ln[u] * 16 + (size_t)((t + u * BLK) & 7) * 2),
-                (__attribute__((address_space(3))) void *)(win + 2 * (u * BLK + wbase)), 16, 0, 0);
-        if (t / RGW < nrows)
-          ownb = upper ? sf_peek(a.Y + r0 + t / RGW) : (unsigned long long)__double_as_longlong(a.rhs[cip]);
-#pragma unroll
-        for (int u = 0; u < WLD; ++u) {
-          const int k = t + u * BLK;
-          if (ln[u] >= 0 && (k & 7) == 0) s_lines[k >> 3] = ln[u];
-        }
-      }
-    }
-    if (work) {
-      if (t == 0) win_stamp(a, win_at(a, i), 5);
-      __syncthreads();   // A: the window is in LDS
-      if (t == 0) win_stamp(a, win_at(a, i), 6);
-    }
-    if (!first) {
-      inext = i + (int)gridDim.x;
-      n0 = n1 = make_int4(0, 0, 0, 0);
-      if (inext < a.i1) { n0 = M.runs[2 * win_at(a, inext)]; n1 = M.runs[2 * win_at(a, inext) + 1]; }
-    }
-    // line ids and row data of the (next) run, a step ahead — issued while the stream role multiplies
-#pragma unroll
-    for (int u = 0; u < WLD; ++u) {
-      const int k = t + u * BLK;
-      ln[u] = k < n0.w * 8 ? M.lines[n0.z + (k >> 3)] : -1;
-    }
-    jb = je = 0;
-    if (t / RGW < n0.y) {
-      jb = M.roff[n1.z + t / RGW];
-      je = M.roff[n1.z + t / RGW + 1];
-      ip = a.perm[n0.x + t / RGW];
-      if (KIND == 1 || (n1.w & 1)) dv = a.dinv[n0.x + t / RGW];
-    }
-    if (work) {
-      __syncthreads();   // B: the products are in LDS
-      for (int rho = t / RGW; rho < nrows; rho += BLK / RGW) {
-        const int lane = t % RGW, r = r0 + rho;
-        int qb = cjb, qe = cje, qi = cip;
-        double qd = cdv;
-        if (rho != t / RGW) {   // later passes (runs of short rows): load the row data now
-          qb = M.roff[roff0 + rho];
-          qe = M.roff[roff0 + rho + 1];
-          qi = a.perm[r];
-          ownb = upper ? sf_peek(a.Y + r) : (unsigned long long)__double_as_longlong(a.rhs[qi]);
-          if (KIND == 1 || upper) qd = a.dinv[r];
-        }
-        double sum = 0.0;
-#pragma unroll 4
-        for (int k = qb + lane; k < qe; k += RGW) sum += prod[k];
-        sum = subwave_sum<RGW>(sum);
-        if (lane == 0) {
-          if (!upper) {
-            const double own = __longlong_as_double((long long)ownb);
-            sf_store(a.Y + r, KIND == 0 ? (own - sum) : (own - sum) * qd);
-          } else {
-            const double own = sf_wait(a.Y + r, ownb, a.err);
-            const double v = KIND == 0 ? (own - sum) * qd : own - sum * qd;
-            sf_store(a.X + r, v);
-            a.out[qi] = v;
-            // every reader of Y[r] (lower runs of later colours next to r) has finished: their results fed the
-            // X entries this row just consumed.  Leave the sentinel for the next call; same for its X buffer.
-            reinterpret_cast<unsigned long long *>(a.Y)[r] = kSentinel;
-            reinterpret_cast<unsigned long long *>(a.Xnext)[r] = kSentinel;
-          }
-        }
-      }
-      if (t == 0) win_stamp(a, win_at(a, i), 7);
-    }
-    i = inext;
-    d0 = n0;
-    d1 = n1;
-    if (i >= a.i1) break;
-  }
-}
-
-// Triangular solve, both halves in one run list (see nsk_kernels.h: tri_win_solve).
-// 512-thread workgroups with two roles, because a wavefront can only wait for its memory operations IN ORDER:
-//   waves 0-3 (stream role)  hold the matrix stream of the workgroup's NEXT run in registers — issued a whole step
-//                            ahead, one colour's worth of the factor is in flight chip-wide — multiply it with the
-//                            window and park the products in LDS;
-//   waves 4-7 (window role)  copy the run's window lines (the only loads that depend on other workgroups' results)
-//                            into LDS, then sum the rows and store the results.
-// Nothing the dependency chain waits for queues behind the bandwidth stream.  Two barriers per run; both roles walk
-// the same run sequence and execute the same number of barriers.
-// reverse == 2: CENSUS instead of a solve — every workgroup announces itself on err[0] and waits (bounded) until the
-// whole grid has: true iff all gridDim.x workgroups of THIS kernel (same registers, same LDS) are resident together,
-// which the occupancy API over-estimates at some SGPR counts (MI355X_MICROARCH.md, Residency).  err[1] = 1 on failure.
-template <int KIND>
-__global__ __launch_bounds__(TWB, 8) void tri_win_kernel(WinTriK a) {
-  __shared__ double win[WL * 16];
-  __shared__ double prod[2 * WQ * BLK];
-  __shared__ int s_lines[WL];
-  if (a.reverse == 2) {
-    if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int spins = 0;
-      while (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
-        if (++spins > (1 << 15)) { __hip_atomic_store(a.err + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        __builtin_amdgcn_s_sleep(8);
-      }
-    }
-    return;
-  }
-  if (a.i0 + (int)blockIdx.x >= a.i1) return;
-  const int t = (int)threadIdx.x & (BLK - 1);
-  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) < BLK) tri_win_stream_role(a, t, win, prod, s_lines);
-  else tri_win_window_role<KIND>(a, t, win, prod, s_lines);
-}
 
 
 __global__ __launch_bounds__(BLK) void gather_or_zero_kernel(long n, const int *__restrict__ idx,
@@ -1525,25 +1299,6 @@ void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, 
   if (n <= 0) return;
   const int grid = (int)std::min<long>(65535 * 8, (n + BLK * 4 - 1) / (BLK * 4));
   hipLaunchKernelGGL(gather_or_zero_kernel, dim3(grid), dim3(BLK), 0, s, n, idx, x, y);
-}
-void tri_win_solve(hipStream_t s, const WinView &M, int i0, int i1, int grid, int kind, int reverse, const WinTriArgs &a) {
-  if (i1 <= i0 || grid <= 0) return;
-  const WinTriK k{M, i0, i1, reverse, a.dinv, a.perm, a.rhs, a.Y, a.X, a.Xnext, a.out, a.err, a.dbg};
-  if (kind == 0) hipLaunchKernelGGL((tri_win_kernel<0>), dim3(grid), dim3(TWB), 0, s, k);
-  else hipLaunchKernelGGL((tri_win_kernel<1>), dim3(grid), dim3(TWB), 0, s, k);
-}
-int tri_win_max_resident_per_cu() {
-  int a = 0, b = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, tri_win_kernel<0>, TWB, 0) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, tri_win_kernel<1>, TWB, 0) != hipSuccess) return 0;
-  return std::min(a, b);
-}
-void tri_win_census(hipStream_t s, int grid, int kind, int *two_ints) {
-  WinTriK k{};
-  k.reverse = 2;
-  k.err = two_ints;
-  if (kind == 0) hipLaunchKernelGGL((tri_win_kernel<0>), dim3(grid), dim3(TWB), 0, s, k);
-  else hipLaunchKernelGGL((tri_win_kernel<1>), dim3(grid), dim3(TWB), 0, s, k);
 }
 void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra) {
   const int n = n_nodes;

@@ -419,12 +419,6 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       stream_ready = true;
     }
   }
-  win_ready = false;
-  if (!perm.empty() && !block2 && use_window) {
-    // study variant (NSK_IOPT_TRI_WINDOW): the same factor in the window format, colour-ordered working vectors,
-    // one persistent launch for both halves
-    build_window_factor(prp, pcol, pdiag, hLp, pcolor);
-  }
   rowptr.upload(prp, s);
   col.upload(pcol, s);
   srcpos.upload(psrc, s);
@@ -439,122 +433,8 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   ctx->sync();  // host staging vectors die at scope exit
 }
 
-void TriSolve::build_window_factor(const std::vector<int> &prp, const std::vector<int> &pcol,
-                                   const std::vector<int> &pdiag, const std::vector<int> &color_ptr,
-                                   const std::vector<int> &pcolor) {
-  hipStream_t s = ctx->stream;
-  // workgroups of the persistent launch: all of them must be resident together.  Start from the occupancy API's
-  // answer (at most 4 per CU: more do not help a stream that is one colour deep) and VERIFY it with a census launch
-  // of the same kernel, going down until a grid of that size has been seen resident as a whole.
-  int per_cu = std::min(tri_win_max_resident_per_cu(), 4);
-  {
-    DBuf<int> census;
-    census.alloc(2);
-    for (; per_cu > 0; --per_cu) {
-      int flags[2] = {0, 0};
-      bool ok = true;
-      for (int k = 0; k < 2 && ok; ++k) {
-        NSK_HIP(hipMemsetAsync(census.p, 0, 2 * sizeof(int), s));
-        tri_win_census(s, per_cu * ctx->n_cu, k, census.p);
-        NSK_HIP(hipMemcpyAsync(flags, census.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-        ctx->sync();
-        ok = flags[1] == 0 && flags[0] == per_cu * ctx->n_cu;
-      }
-      if (ok) break;
-    }
-  }
-  if (per_cu <= 0) return;
-  win_grid = std::max(8, per_cu * ctx->n_cu / 8 * 8);
-
-  std::vector<int> lrp(n + 1, 0), urp(n + 1, 0);
-  for (int i = 0; i < n; ++i) {
-    lrp[i + 1] = lrp[i] + (pdiag[i] - prp[i]);
-    urp[i + 1] = urp[i] + (prp[i + 1] - pdiag[i] - 1);
-  }
-  nnzL = lrp[n];
-  nnzU = urp[n];
-  std::vector<int> lcol((size_t)nnzL), lsrc((size_t)nnzL), ucol((size_t)nnzU), usrc((size_t)nnzU);
-#pragma omp parallel for schedule(static)
-  for (int i = 0; i < n; ++i) {   // pcol is sorted inside a row
-    int w = lrp[i];
-    for (int k = prp[i]; k < pdiag[i]; ++k) { lcol[w] = pcol[k]; lsrc[w] = k; ++w; }
-    w = urp[i];
-    for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k) { ucol[w] = pcol[k]; usrc[w] = k; ++w; }
-  }
-  // POSITION-PROPORTIONAL schedule.  The rows of a colour are in lattice order, and so are its runs (each as full
-  // as the caps allow).  Run j of the n_c runs of colour c goes to workgroup floor(j G / n_c) of the persistent
-  // launch: workgroup p then works on about the same patch of the mesh colour after colour, what it waits for was
-  // produced by itself and by the workgroups of the neighbouring patches one colour earlier, and patches far apart
-  // never wait for each other.  The list holds, per colour, ceil(n_c / G) rounds of G slots (empty where a
-  // workgroup has fewer runs than the round count).
-  const int G = win_grid;
-  std::vector<int> cuts(color_ptr.begin() + 1, color_ptr.end());   // colour boundaries
-  WinFormat WLo, WUp;
-  if (!build_win_format(n, lrp.data(), lcol.data(), lsrc.data(), &cuts, pcolor.data(), kWinMaxLines, 0, 0, WLo) ||
-      !build_win_format(n, urp.data(), ucol.data(), usrc.data(), &cuts, pcolor.data(), kWinMaxLines, 1, 0, WUp))
-    return;   // a row exceeds the window: the level-scheduled CSR kernels serve this factor
-  // one run list in dispatch order; lower and upper runs index the same value / position arrays (upper shifted)
-  const int64_t pair_shift = WLo.n_slots / 2;
-  const int line_shift = (int)WLo.lines.size(), roff_shift = (int)WLo.roff.size();
-  std::vector<WinRun> list;
-  win_level.assign(1, 0);
-  auto deal = [&](const WinFormat &W, int c, bool upper) {
-    // runs of colour c are contiguous in W.runs (built in row order, never crossing a colour boundary)
-    const int b = color_ptr[c], e = color_ptr[c + 1];
-    auto lo = std::lower_bound(W.runs.begin(), W.runs.end(), b, [](const WinRun &R, int r) { return R.r0 < r; });
-    auto hi = std::lower_bound(W.runs.begin(), W.runs.end(), e, [](const WinRun &R, int r) { return R.r0 < r; });
-    const int64_t nc = hi - lo;
-    std::vector<std::vector<const WinRun *>> chunk((size_t)G);
-    int depth = 0;
-    for (int64_t j = 0; j < nc; ++j) {
-      const int p = (int)(j * G / nc);
-      chunk[(size_t)p].push_back(&*(lo + j));
-      depth = std::max(depth, (int)chunk[(size_t)p].size());
-    }
-    const int per = G / 8;
-    for (int d = 0; d < depth; ++d)
-      for (int slot = 0; slot < G; ++slot) {
-        const int p = (slot & 7) * per + (slot >> 3);   // XCD k (= slot % 8) owns the k-th eighth of the chunks
-        WinRun R{};
-        if (d < (int)chunk[(size_t)p].size()) {
-          R = *chunk[(size_t)p][(size_t)d];
-          if (upper) { R.p0 += (int)pair_shift; R.l0 += line_shift; R.roff0 += roff_shift; }
-        }
-        R.flags = (R.flags & ~1) | (upper ? 1 : 0);   // (an empty slot has no entries: bits 1-12 are 0)
-        list.push_back(R);
-      }
-    win_level.push_back((int)list.size());
-    if (getenv("NSK_TRACE_ANALYZE")) fprintf(stderr, "[nsk] %s colour %d: %d runs, depth %d\n", upper ? "U" : "L", c, (int)(hi - lo), depth);
-  };
-  for (int c = 0; c < n_colors; ++c) deal(WLo, c, false);
-  for (int c = n_colors - 1; c >= 0; --c) deal(WUp, c, true);
-  win_nruns = (int)list.size();
-  win_slots = WLo.n_slots + WUp.n_slots;
-  win_bytes = WLo.bytes_per_apply() + WUp.bytes_per_apply();
-  WLo.lines.insert(WLo.lines.end(), WUp.lines.begin(), WUp.lines.end());
-  WLo.roff.insert(WLo.roff.end(), WUp.roff.begin(), WUp.roff.end());
-  WLo.pos.insert(WLo.pos.end(), WUp.pos.begin(), WUp.pos.end());
-  WLo.src.insert(WLo.src.end(), WUp.src.begin(), WUp.src.end());
-  win_runs.upload(win_pack_runs(list), s);
-  win_lines.upload(WLo.lines, s);
-  win_roff.upload(WLo.roff, s);
-  win_pos.upload(WLo.pos, s);
-  win_src.upload(WLo.src, s);
-  win_val.alloc((size_t)win_slots);
-  const size_t nw = ((size_t)n + kWinLine - 1) / kWinLine * kWinLine + kWinLine;   // whole lines
-  win_y.alloc(nw);
-  win_x0.alloc(nw);
-  win_x1.alloc(nw);
-  if (dinv.n != (size_t)n) dinv.alloc((size_t)n);
-  win_dirty = true;
-  win_parity = 0;
-  ctx->sync();
-  win_ready = true;
-}
 
 double TriSolve::format_bytes() const {
-  if (win_ready)   // window stream + per row: perm, rhs, dinv, Y (store, load, reset), X (store), Xnext (reset), result
-    return win_bytes + 68.0 * (double)n;
   if (stream_ready)   // CSR halves + per run: descriptor; per row: rowptr x2, perm x2, rhs, dinv, y (store + load), x (fill + store)
     return 12.0 * (double)(nnzL + nnzU) + 16.0 * (double)(n_Lsf + n_Usf) + (8.0 + 8.0 + 8.0 + 8.0 + 16.0 + 16.0 + 16.0) * (double)n;
   if (block2_ready)   // 2x2 blocks with one int32 block column + per node row: descriptor share, intra, rhs, y, x
@@ -583,7 +463,6 @@ void TriSolve::numeric(const double *a_val_dev) {
     vec_gather(s, n, diag.p, val.p, dinv.p);
     vec_recip(s, n, dinv.p, dinv.p);
   }
-  if (win_ready) vec_gather_or_zero(s, (long)win_slots, win_src.p, val.p, win_val.p);
 }
 
 void TriSolve::apply(const double *b, double *x) {
@@ -592,35 +471,7 @@ void TriSolve::apply(const double *b, double *x) {
   // one 1024-thread workgroup walking all levels with __syncthreads in between is faster there.
   const bool tiny = (double)nnz * 12.0 < tiny_bytes && !schedL.empty();
   // y stays armed with the sentinel only while consecutive applies go through the single-launch CSR kernels
-  if (!(sync_free && use_stream && !tiny && (stream_ready || block2_ready) && !(win_ready && !block2_ready))) sf_armed = false;
-  if (win_ready && use_stream && !tiny) {
-    // scalar multicolour factor in the window format, colour-ordered working vectors (see nsk_kernels.h: tri_win_solve)
-    if (!sf_err.p) {
-      sf_err.alloc(1);
-      NSK_HIP(hipMemsetAsync(sf_err.p, 0, sizeof(int), s));
-    }
-    if (win_dirty) {   // first call, or a call after a solve that gave up: every entry waits for its producer again
-      vec_fill_sentinel(s, (int)win_y.n, win_y.p);
-      vec_fill_sentinel(s, (int)win_x0.n, win_x0.p);
-      vec_fill_sentinel(s, (int)win_x1.n, win_x1.p);
-      win_dirty = false;
-    }
-    const WinView M{win_runs.p, win_lines.p, win_roff.p, reinterpret_cast<const unsigned *>(win_pos.p), win_val.p};
-    const WinTriArgs a{dinv.p, d_perm.p, b, win_y.p, win_parity ? win_x1.p : win_x0.p, win_parity ? win_x0.p : win_x1.p,
-                       x, sf_err.p, win_dbg};
-    if (sync_free) {
-      // ONE persistent launch for both halves; all its workgroups are resident together, so a wait never depends
-      // on a workgroup that has not started
-      tri_win_solve(s, M, 0, win_nruns, std::min(win_grid, win_nruns), kind, win_fault, a);
-    } else {
-      for (size_t l = 0; l + 1 < win_level.size(); ++l)   // one launch per colour, a workgroup per run
-        tri_win_solve(s, M, win_level[l], win_level[l + 1], win_level[l + 1] - win_level[l], kind, 0, a);
-    }
-    win_parity ^= 1;
-    ++ctx->st.tri_applies;
-    ctx->st.tri_bytes += (double)apply_bytes();
-    return;
-  }
+  if (!(sync_free && use_stream && !tiny && (stream_ready || block2_ready))) sf_armed = false;
   if (sync_free && use_stream && !tiny && stream_ready) {
     // scalar factor: lower half into y (pre-filled with the sentinel), upper half into x; each half is ONE launch
     if (!sf_err.p) {
@@ -630,9 +481,9 @@ void TriSolve::apply(const double *b, double *x) {
     const TriHalf L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
     // the lower half arms x for the upper half, the upper half re-arms y for the next call: no fill launches
     if (!sf_armed) { vec_fill_sentinel(s, n, y.p); sf_armed = true; }
-    tri_stream_syncfree(s, L, n_Lsf, 1, kind, kStreamNnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, x, sf_err.p, win_dbg);
+    tri_stream_syncfree(s, L, n_Lsf, 1, kind, kStreamNnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, x, sf_err.p, sf_dbg);
     tri_stream_syncfree(s, U, n_Usf, 0, kind, kStreamNnz, sf_fault ? 1 : 0, dinv.p, d_perm.p, nullptr, y.p, x, y.p, sf_err.p,
-                        win_dbg ? win_dbg + (size_t)n_Lsf * 16 : nullptr);
+                        sf_dbg ? sf_dbg + (size_t)n_Lsf * 16 : nullptr);
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
     return;

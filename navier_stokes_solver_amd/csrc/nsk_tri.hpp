@@ -45,7 +45,6 @@ struct TriSolve {
 
   // split factors for the streamed kernels (multicolour ordering: one colour = one contiguous level)
   bool use_stream = true, stream_ready = false;
-  bool use_window = false;    // NSK_IOPT_TRI_WINDOW: scalar factors on the window format (study variant)
   double tiny_bytes = 4.0e6;  // factors below this size take the single-workgroup path (NSK_IOPT_TINY_BYTES)
   bool sync_free = false;  // one launch per half with in-kernel producer/consumer hand-off (see nsk_kernels.h)
   bool sf_armed = false;   // y holds the sentinel everywhere (left so by every completed single-launch apply)
@@ -60,19 +59,7 @@ struct TriSolve {
   DBuf<double> Lval, Uval, dinv;
   std::vector<int> LB, UB;  // per colour: first workgroup of that colour in Lblk / Ublk (n_colors + 1)
   int64_t nnzL = 0, nnzU = 0;
-  // window format of the scalar multicolour factors (nsk_win.hpp): both halves in ONE run list in dispatch order
-  // (lower colours ascending, then upper colours descending; inside a colour XCD k owns the k-th eighth), solved on
-  // colour-ordered working vectors by a persistent single launch (sync_free) or level by level
-  bool win_ready = false, win_dirty = true;   // dirty: the working vectors must be re-filled with the sentinel
-  int win_nruns = 0, win_grid = 0, win_parity = 0, win_fault = 0;
-  int64_t win_slots = 0;
-  double win_bytes = 0;
-  std::vector<int> win_level;                 // run-list offsets of the 2 * n_colors levels (+ end)
-  DBuf<int4> win_runs;
-  DBuf<int> win_lines, win_src;
-  DBuf<unsigned short> win_roff, win_pos;
-  DBuf<double> win_val, win_y, win_x0, win_x1;
-  long long *win_dbg = nullptr;   // diagnostics buffer of the next apply (16 int64 per run), see nsk_debug_tri_trace
+  long long *sf_dbg = nullptr;   // diagnostics buffer of the next apply (16 int64 per workgroup), see nsk_debug_tri_trace
   // 2x2 node-block variant (velocity block): node rows in node-colour order, blocks in L*/U* above,
   // per node row {l10, u01, 1/d0, 1/d1} in `intra`
   bool block2_ready = false;
@@ -83,8 +70,6 @@ struct TriSolve {
   // sub_off: optional n_sub+1 offsets of emulated MPI ranks inside this GPU (block Jacobi)
   void analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off,
                bool want_block2 = false);
-  void build_window_factor(const std::vector<int> &prp, const std::vector<int> &pcol, const std::vector<int> &pdiag,
-                           const std::vector<int> &color_ptr, const std::vector<int> &pcolor);
   void numeric(const double *a_val_dev);           // refresh values (+ factorise for ILU)
   void apply(const double *b, double *x);          // x = M^{-1} b, caller's ordering
   TriView view() const { return TriView{n, rowptr.p, diag.p, col.p, val.p, perm.empty() ? nullptr : d_perm.p}; }

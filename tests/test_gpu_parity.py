@@ -465,12 +465,12 @@ def test_tri_x_layouts_agree():
 
 @pytest.mark.parametrize("name", ["ns60", "stokes60"])
 @pytest.mark.parametrize("sync_free", [0, 1])
-@pytest.mark.parametrize("window", [0, 1])
-def test_streamed_kernels_on_the_pressure_block(name, sync_free, window):
+def test_streamed_kernels_on_the_pressure_block(name, sync_free):
     """ILU(S) / SGS(Mp) applies and the S / Mp SpMVs through the streamed kernels (these factors are small enough for
-    the single-workgroup path, which is switched off here): CSR halves (default) and the window-format study variant
-    (LDS-staged column tiles, 16-bit positions, one persistent launch), single launch and per-colour launches, repeated
-    applies (the sentinel state of the working vectors is restored by every call); SpMV on the window format and on CSR."""
+    the single-workgroup path, which is switched off here): single launch and per-colour launches, repeated applies
+    (the sentinel state of the working vectors is restored by every call); SpMV on the window format (LDS-staged column
+    tiles, 16-bit positions) and on CSR."""
+    window = 0
     S, O = _S(), _O()
     import scipy.sparse as sp
     pr = problem(name)
@@ -480,7 +480,6 @@ def test_streamed_kernels_on_the_pressure_block(name, sync_free, window):
         ls.set_option(S.OPT_TRI_ORDERING, 1)
         ls.set_option(S.OPT_TRI_SYNC_FREE, sync_free)
         ls.set_option(S.IOPT_TINY_BYTES, 0)     # these factors are small: force them through the streamed kernels
-        ls.set_option(S.IOPT_TRI_WINDOW, window)
         ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
         rp, col, val = ls.get_block(S.BLK_S)
         Sm = sp.csr_matrix((val, col, rp), shape=(pr.n_p, pr.n_p))
