@@ -205,6 +205,20 @@ int nsk_get_block(nsk_handle h, int blk, int32_t *rowptr, int32_t *col, double *
 int nsk_assembly_set_cells(nsk_handle h, int64_t n_cells, const int32_t *cell_u_nodes, const int32_t *cell_p_dofs,
                            const uint8_t *cell_flags, const double *tables944, int32_t cell_of_dof0);
 int nsk_assembly_set_dirichlet(nsk_handle h, const uint8_t *dirichlet_u, const double *bc_u /* or NULL */);
+/* The same for general (non-congruent) P2/P1 triangles — the reference's `-M` path (FE_SimplexP, QGaussSimplex(3),
+ * NSSolverStationary.cpp:144-206), one rank.  Instead of nsk_assembly_set_cells.  Per cell: 6 velocity NODE ids
+ * (vertices, then the midpoints of edges (0,1), (1,2), (2,0)), 3 pressure DoF ids, the gradients of the three
+ * barycentric coordinates and the area (what MappingFE / FEValues::reinit give per cell).  The transposed connectivity
+ * the gather kernels need is computed by the caller's side once per mesh (navier_stokes_solver_amd/simplex.py:
+ * device_handoff): per 2x2 node block of block (0,0) the cells holding both nodes (cell * 36 + local row node * 6 +
+ * local column node) and the positions of the block's first entry in the node's two scalar CSR rows; per velocity node
+ * and per pressure DoF the cells touching it (cell * 6 + local node, cell * 3 + local vertex); outlet_w[2 node + c] =
+ * integral of phi_node n_c over the boundary-id-8 edges.  pos00: position of entry (0,0) of block (0,0). */
+int nsk_assembly_set_simplex(nsk_handle h, int64_t n_cells, const int32_t *cell_u_nodes, const int32_t *cell_p_dofs,
+                             const double *grad_lambda, const double *area, int64_t n_blocks, const int32_t *blk_ptr,
+                             const int32_t *blk_ent, const int64_t *blk_pos0, const int64_t *blk_pos1,
+                             const int32_t *node_ptr, const int32_t *node_ent, const int32_t *vert_ptr,
+                             const int32_t *vert_ent, const double *outlet_w, int64_t pos00);
 int nsk_state_set(nsk_handle h, const double *u_owned, const double *p_owned);
 int nsk_state_get(nsk_handle h, double *u_owned, double *p_owned);
 int nsk_state_save(nsk_handle h);

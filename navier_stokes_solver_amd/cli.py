@@ -141,7 +141,13 @@ def run_gmsh(cfg, unsteady: bool) -> int:
     print("-----------------------------------------------")
     ls = S.LinearSolver()
     ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
-    backend = N.SimplexBackend(ls, space, cfg["solver"], cfg["prec"], cfg["tol"])
+    host_assembly = bool(os.environ.get("NSK_HOST_ASSEMBLY"))
+    if host_assembly:      # the hand-off producer on the host for every assembly (the yardstick of the device assembly)
+        backend = N.SimplexBackend(ls, space, cfg["solver"], cfg["prec"], cfg["tol"])
+    else:                  # first hand-off (pattern, constant blocks) from the host, then nsk_assemble on the P2/P1 cells
+        first = SX.assemble(space, 0.1, mode=0, inlet_bc=1, U=0.1)
+        first.simplex = SX.device_handoff(space, first)
+        backend = N.DeviceBackend(ls, first, cfg["solver"], cfg["prec"], cfg["tol"])
     t0 = time.time()
     try:
         N.solve_newton(backend, cfg["Re"])
@@ -159,8 +165,8 @@ def run_gmsh(cfg, unsteady: bool) -> int:
     finally:
         dt = time.time() - t0
         its = backend.total_linear_iterations
-        print(f"[nsk] {backend.assemblies} assemblies (host, P2/P1), {its} outer iterations of solve_system() on the GPU, "
-              f"{dt:.3f} s in solve_newton")
+        print(f"[nsk] {backend.assemblies} assemblies ({'host' if host_assembly else 'device'}, P2/P1), {its} outer iterations "
+              f"of solve_system() on the GPU, {dt:.3f} s in solve_newton")
         ls.close()
     return 0
 

@@ -34,4 +34,25 @@ void asm_rhs_u(hipStream_t s, const AsmMesh &M, const double *cq, double nu, dou
                const double *d0, const double *bc, double *rhs, double *x0);
 void asm_rhs_p(hipStream_t s, const AsmMesh &M, const double *cq, int stokes, double *rhs);
 
+// ---- P2/P1 on triangles (general cells; the reference's -M path) ----
+struct SimplexMesh {  // device pointers
+  long n_cells, n_blocks;
+  int n_unodes, n_pdofs;
+  long pos00;               // position of entry (0,0) in the scalar CSR of block (0,0)
+  const int *cell_u;        // [n_cells][6] velocity node ids (vertices, then edge midpoints (0,1), (1,2), (2,0))
+  const int *cell_p;        // [n_cells][3]
+  const double *grad_lam;   // [n_cells][3][2] gradients of the barycentric coordinates
+  const double *area;       // [n_cells]
+  const int *blk_ptr;       // [n_blocks + 1] per 2x2 node block of (0,0): its cells ...
+  const int *blk_ent;       //   ... as cell * 36 + local row node * 6 + local column node
+  const long *blk_pos0, *blk_pos1;   // position of the block's first entry in the node's first / second scalar row
+  const int *node_ptr, *node_ent;    // per velocity node: cell * 6 + local node
+  const int *vert_ptr, *vert_ent;    // per pressure DoF: cell * 3 + local vertex
+  const double *outlet_w;   // [2 n_unodes] int phi_n n_c over the outlet (id 8) edges
+  const unsigned char *dirichlet;    // per velocity DoF
+};
+void simplex_assemble(hipStream_t s, const SimplexMesh &M, const double *su, const double *sp, const double *so, double nu,
+                      double inv_dt, double p_out, int stokes, const int *rowptr, const int *col, double *val, double *d0,
+                      const double *bc, double *rhs_u, double *rhs_p, double *x0_u, double *x0_p);
+
 }  // namespace nsk

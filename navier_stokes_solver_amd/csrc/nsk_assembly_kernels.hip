@@ -220,3 +220,206 @@ void asm_rhs_p(hipStream_t s, const AsmMesh &M, const double *cq, int stokes, do
 }
 
 }  // namespace nsk
+
+// ------------------------------------------------------------------------------------------------------------------
+// P2/P1 Taylor-Hood on triangles (the reference's -M path, NSSolverStationary.cpp:144-206: FE_SimplexP(2)^2 x
+// FE_SimplexP(1), QGaussSimplex(3)): general, non-congruent cells.  Gather instead of the reference's cell scatter
+// (jacobian_matrix.add, .cpp:534), like the Q3/Q2 kernels above, but one thread per 2x2 NODE BLOCK of (0,0): the
+// host hands over, per block (row node n, column node m), the list of cells holding both with their local indices
+// (1-2 cells for an edge pair, the whole patch for the diagonal); the thread integrates each cell's contribution
+// with the 7-point degree-5 rule and adds them in list order — deterministic, no atomics, two assemblies give the
+// same bits.  The element state (u, grad u at the quadrature points) is recomputed per (block, cell): a few hundred
+// flops against one 32-byte store.
+namespace nsk {
+namespace {
+
+__constant__ double kTriL[7][3] = {
+    {1.0 / 3, 1.0 / 3, 1.0 / 3},
+    {0.79742698535308731, 0.10128650732345633, 0.10128650732345633},
+    {0.10128650732345633, 0.79742698535308731, 0.10128650732345633},
+    {0.10128650732345633, 0.10128650732345633, 0.79742698535308731},
+    {0.05971587178976989, 0.47014206410511505, 0.47014206410511505},
+    {0.47014206410511505, 0.05971587178976989, 0.47014206410511505},
+    {0.47014206410511505, 0.47014206410511505, 0.05971587178976989}};
+__constant__ double kTriW[7] = {0.225,
+                                0.12593918054482717, 0.12593918054482717, 0.12593918054482717,
+                                0.13239415278850616, 0.13239415278850616, 0.13239415278850616};
+
+// value and barycentric derivatives of P2 function k (0-2 vertices, 3-5 edges (0,1), (1,2), (2,0)) at lam
+__device__ __forceinline__ void p2(int k, const double *lam, double &v, double dl[3]) {
+  dl[0] = dl[1] = dl[2] = 0.0;
+  if (k < 3) {
+    v = lam[k] * (2.0 * lam[k] - 1.0);
+    dl[k] = 4.0 * lam[k] - 1.0;
+  } else {
+    const int i = k - 3, j = (k - 2) % 3;
+    v = 4.0 * lam[i] * lam[j];
+    dl[i] = 4.0 * lam[j];
+    dl[j] = 4.0 * lam[i];
+  }
+}
+__device__ __forceinline__ void p2_grad(int k, const double *lam, const double *gl /* [3][2] */, double &v, double &gx,
+                                        double &gy) {
+  double dl[3];
+  p2(k, lam, v, dl);
+  gx = dl[0] * gl[0] + dl[1] * gl[2] + dl[2] * gl[4];
+  gy = dl[0] * gl[1] + dl[1] * gl[3] + dl[2] * gl[5];
+}
+
+struct ElemState {   // velocity and its gradient at one quadrature point
+  double u[2], g[2][2];
+};
+__device__ __forceinline__ ElemState elem_state(const int *cu, const double *gl, const double *lam, const double *su) {
+  ElemState S{};
+  for (int k = 0; k < 6; ++k) {
+    double v, gx, gy;
+    p2_grad(k, lam, gl, v, gx, gy);
+    const double ux = su[2 * (size_t)cu[k]], uy = su[2 * (size_t)cu[k] + 1];
+    S.u[0] += ux * v; S.u[1] += uy * v;
+    S.g[0][0] += ux * gx; S.g[0][1] += ux * gy;
+    S.g[1][0] += uy * gx; S.g[1][1] += uy * gy;
+  }
+  return S;
+}
+
+__global__ __launch_bounds__(256) void simplex_F_blocks_kernel(SimplexMesh M, const double *__restrict__ su, double nu,
+                                                              double inv_dt, int stokes, double *__restrict__ val) {
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= M.n_blocks) return;
+  double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+  for (int e = M.blk_ptr[b]; e < M.blk_ptr[b + 1]; ++e) {
+    const int code = M.blk_ent[e], t = code / 36, ln = (code % 36) / 6, lm = code % 6;
+    const int *cu = M.cell_u + 6 * (size_t)t;
+    const double *gl = M.grad_lam + 6 * (size_t)t;
+    const double area = M.area[t];
+    double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
+    for (int q = 0; q < 7; ++q) {
+      const double *lam = kTriL[q];
+      const double w = area * kTriW[q];
+      double vn, gnx, gny, vm, gmx, gmy;
+      p2_grad(ln, lam, gl, vn, gnx, gny);
+      p2_grad(lm, lam, gl, vm, gmx, gmy);
+      double diag = nu * (gnx * gmx + gny * gmy) + inv_dt * vn * vm;
+      if (!stokes) {
+        const ElemState S = elem_state(cu, gl, lam, su);
+        diag += vn * (S.u[0] * gmx + S.u[1] * gmy);               // phi_n (u . grad) phi_m
+        c00 += w * vn * S.g[0][0] * vm; c01 += w * vn * S.g[0][1] * vm;   // phi_n d_d u_c phi_m
+        c10 += w * vn * S.g[1][0] * vm; c11 += w * vn * S.g[1][1] * vm;
+      }
+      c00 += w * diag;
+      c11 += w * diag;
+    }
+    a00 += c00; a01 += c01; a10 += c10; a11 += c11;
+  }
+  const long p0 = M.blk_pos0[b], p1 = M.blk_pos1[b];
+  val[p0] = a00; val[p0 + 1] = a01;
+  val[p1] = a10; val[p1 + 1] = a11;
+}
+
+// Dirichlet rows: cleared, diagonal d0 = |(0,0) entry before clearing| (MatrixTools::apply_boundary_values, .cpp:574)
+__global__ __launch_bounds__(256) void simplex_dirichlet_rows_kernel(int n_u, const int *__restrict__ rowptr,
+                                                                    const int *__restrict__ col,
+                                                                    const unsigned char *__restrict__ dir,
+                                                                    const double *__restrict__ d0, double *__restrict__ val) {
+  const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (r >= n_u || !dir[r]) return;
+  const double d = d0[0];
+  for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) val[k] = col[k] == r ? d : 0.0;
+}
+__global__ void simplex_d0_kernel(const double *val, long pos, double *out) { out[0] = fabs(val[pos]); }
+
+__global__ __launch_bounds__(256) void simplex_rhs_u_kernel(SimplexMesh M, const double *__restrict__ su,
+                                                           const double *__restrict__ spv, const double *__restrict__ so,
+                                                           double nu, double inv_dt, double p_out, int stokes,
+                                                           const double *__restrict__ d0, const double *__restrict__ bc,
+                                                           double *__restrict__ rhs, double *__restrict__ x0) {
+  const int n = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (n >= M.n_unodes) return;
+  double r0 = 0.0, r1 = 0.0;
+  if (!stokes) {
+    for (int e = M.node_ptr[n]; e < M.node_ptr[n + 1]; ++e) {
+      const int code = M.node_ent[e], t = code / 6, ln = code % 6;
+      const int *cu = M.cell_u + 6 * (size_t)t;
+      const int *cp = M.cell_p + 3 * (size_t)t;
+      const double *gl = M.grad_lam + 6 * (size_t)t;
+      const double area = M.area[t];
+      double e0 = 0.0, e1 = 0.0;
+      for (int q = 0; q < 7; ++q) {
+        const double *lam = kTriL[q];
+        const double w = area * kTriW[q];
+        double vn, gnx, gny;
+        p2_grad(ln, lam, gl, vn, gnx, gny);
+        const ElemState S = elem_state(cu, gl, lam, su);
+        const double pq = spv[cp[0]] * lam[0] + spv[cp[1]] * lam[1] + spv[cp[2]] * lam[2];
+        double t0 = -nu * (S.g[0][0] * gnx + S.g[0][1] * gny) - (S.u[0] * S.g[0][0] + S.u[1] * S.g[0][1]) * vn + pq * gnx;
+        double t1 = -nu * (S.g[1][0] * gnx + S.g[1][1] * gny) - (S.u[0] * S.g[1][0] + S.u[1] * S.g[1][1]) * vn + pq * gny;
+        if (so && inv_dt != 0.0) {   // -(u - u_old) / dt . v
+          double ox = 0.0, oy = 0.0;
+          for (int k = 0; k < 6; ++k) {
+            double v, dl[3];
+            p2(k, lam, v, dl);
+            ox += so[2 * (size_t)cu[k]] * v; oy += so[2 * (size_t)cu[k] + 1] * v;
+          }
+          t0 -= inv_dt * (S.u[0] - ox) * vn;
+          t1 -= inv_dt * (S.u[1] - oy) * vn;
+        }
+        e0 += w * t0;
+        e1 += w * t1;
+      }
+      r0 += e0;
+      r1 += e1;
+    }
+  }
+  r0 -= p_out * M.outlet_w[2 * (size_t)n];       // - p_out int phi . n over the id-8 edges (state-independent weights)
+  r1 -= p_out * M.outlet_w[2 * (size_t)n + 1];
+  for (int c = 0; c < 2; ++c) {
+    const size_t r = 2 * (size_t)n + c;
+    if (M.dirichlet[r]) {
+      const double v = bc ? bc[r] : 0.0;
+      rhs[r] = d0[0] * v;
+      x0[r] = v;
+    } else {
+      rhs[r] = c ? r1 : r0;
+      x0[r] = 0.0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void simplex_rhs_p_kernel(SimplexMesh M, const double *__restrict__ su, int stokes,
+                                                           double *__restrict__ rhs, double *__restrict__ x0) {
+  const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (j >= M.n_pdofs) return;
+  double r = 0.0;
+  if (!stokes)
+    for (int e = M.vert_ptr[j]; e < M.vert_ptr[j + 1]; ++e) {
+      const int code = M.vert_ent[e], t = code / 3, lj = code % 3;
+      const int *cu = M.cell_u + 6 * (size_t)t;
+      const double *gl = M.grad_lam + 6 * (size_t)t;
+      double acc = 0.0;
+      for (int q = 0; q < 7; ++q) {
+        const ElemState S = elem_state(cu, gl, kTriL[q], su);
+        acc += M.area[t] * kTriW[q] * (S.g[0][0] + S.g[1][1]) * kTriL[q][lj];
+      }
+      r += acc;
+    }
+  rhs[j] = r;
+  x0[j] = 0.0;
+}
+
+}  // namespace
+
+void simplex_assemble(hipStream_t s, const SimplexMesh &M, const double *su, const double *sp, const double *so, double nu,
+                      double inv_dt, double p_out, int stokes, const int *rowptr, const int *col, double *val, double *d0,
+                      const double *bc, double *rhs_u, double *rhs_p, double *x0_u, double *x0_p) {
+  const int T = 256;
+  hipLaunchKernelGGL(simplex_F_blocks_kernel, dim3((unsigned)((M.n_blocks + T - 1) / T)), dim3(T), 0, s, M, su, nu, inv_dt,
+                     stokes, val);
+  hipLaunchKernelGGL(simplex_d0_kernel, dim3(1), dim3(1), 0, s, val, (long)M.pos00, d0);
+  hipLaunchKernelGGL(simplex_dirichlet_rows_kernel, dim3((2 * M.n_unodes + T - 1) / T), dim3(T), 0, s, 2 * M.n_unodes, rowptr,
+                     col, M.dirichlet, d0, val);
+  hipLaunchKernelGGL(simplex_rhs_u_kernel, dim3((M.n_unodes + T - 1) / T), dim3(T), 0, s, M, su, sp, so, nu, inv_dt, p_out,
+                     stokes, d0, bc, rhs_u, x0_u);
+  hipLaunchKernelGGL(simplex_rhs_p_kernel, dim3((M.n_pdofs + T - 1) / T), dim3(T), 0, s, M, su, stokes, rhs_p, x0_p);
+}
+
+}  // namespace nsk

@@ -130,6 +130,12 @@ struct nsk_handle_s {
     DBuf<unsigned char> cell_flags, node_off, dirichlet;
     DBuf<double> tables, cq, bc;
     double *sol_u = nullptr, *sol_p = nullptr, *eval_u = nullptr, *eval_p = nullptr;  // pool vectors [owned | ghost]
+    // P2/P1 triangles (nsk_assembly_set_simplex)
+    bool simplex = false;
+    long sx_blocks = 0, sx_pos00 = 0;
+    DBuf<int> sx_blk_ptr, sx_blk_ent, sx_node_ptr, sx_node_ent, sx_vert_ptr, sx_vert_ent;
+    DBuf<long> sx_pos0, sx_pos1;
+    DBuf<double> sx_grad, sx_area, sx_outlet;
     double *old_u = nullptr;  // solution_old of the time loop (velocity part; the pressure is not used)
     bool have_old = false;
     double assemble_ms = 0;
@@ -1123,6 +1129,66 @@ int nsk_state_update(nsk_handle h, double alpha) {
   NSK_CATCH(h)
 }
 
+int nsk_assembly_set_simplex(nsk_handle h, int64_t n_cells, const int32_t *cell_u_nodes, const int32_t *cell_p_dofs,
+                             const double *grad_lambda, const double *area, int64_t n_blocks, const int32_t *blk_ptr,
+                             const int32_t *blk_ent, const int64_t *blk_pos0, const int64_t *blk_pos1,
+                             const int32_t *node_ptr, const int32_t *node_ent, const int32_t *vert_ptr,
+                             const int32_t *vert_ent, const double *outlet_w, int64_t pos00) {
+  NSK_TRY(h)
+  (void)hipSetDevice(h->ctx.device);
+  if (h->ctx.comm.nranks > 1) throw Error(-65, "nsk_assembly_set_simplex: one rank only");
+  Csr &F = h->blk[NSK_BLK_F];
+  if (!F.present) throw Error(-63, "hand the blocks over before the assembly data");
+  h->ensure_pools();
+  const int nun = h->n_u() / 2, np = h->n_p();
+  if (n_cells <= 0 || n_blocks <= 0 || pos00 < 0 || pos00 >= F.nnz) throw Error(-64, "nsk_assembly_set_simplex: bad sizes");
+  // shapes the kernels index with: checked on the host before anything is launched
+  for (int64_t k = 0; k < 6 * n_cells; ++k)
+    if (cell_u_nodes[k] < 0 || cell_u_nodes[k] >= nun) throw Error(-64, "simplex assembly: velocity node id out of range");
+  for (int64_t k = 0; k < 3 * n_cells; ++k)
+    if (cell_p_dofs[k] < 0 || cell_p_dofs[k] >= np) throw Error(-64, "simplex assembly: pressure DoF id out of range");
+  if (blk_ptr[0] != 0 || node_ptr[0] != 0 || vert_ptr[0] != 0) throw Error(-64, "simplex assembly: lists must start at 0");
+  for (int64_t b = 0; b < n_blocks; ++b) {
+    if (blk_ptr[b + 1] < blk_ptr[b]) throw Error(-64, "simplex assembly: block list not ascending");
+    if (blk_pos0[b] < 0 || blk_pos0[b] + 1 >= F.nnz || blk_pos1[b] < 0 || blk_pos1[b] + 1 >= F.nnz)
+      throw Error(-64, "simplex assembly: block position outside block (0,0)");
+  }
+  for (int k = 0; k < blk_ptr[n_blocks]; ++k)
+    if (blk_ent[k] < 0 || blk_ent[k] / 36 >= n_cells) throw Error(-64, "simplex assembly: block entry names no cell");
+  for (int k = 0; k < node_ptr[nun]; ++k)
+    if (node_ent[k] < 0 || node_ent[k] / 6 >= n_cells) throw Error(-64, "simplex assembly: node entry names no cell");
+  for (int k = 0; k < vert_ptr[np]; ++k)
+    if (vert_ent[k] < 0 || vert_ent[k] / 3 >= n_cells) throw Error(-64, "simplex assembly: vertex entry names no cell");
+  auto &A = h->asmd;
+  hipStream_t s = h->s();
+  A.n_cells = (long)n_cells;
+  A.sx_blocks = (long)n_blocks;
+  A.sx_pos00 = (long)pos00;
+  A.cell_u.upload(cell_u_nodes, (size_t)n_cells * 6, s);
+  A.cell_p.upload(cell_p_dofs, (size_t)n_cells * 3, s);
+  A.sx_grad.upload(grad_lambda, (size_t)n_cells * 6, s);
+  A.sx_area.upload(area, (size_t)n_cells, s);
+  A.sx_blk_ptr.upload(blk_ptr, (size_t)n_blocks + 1, s);
+  A.sx_blk_ent.upload(blk_ent, (size_t)blk_ptr[n_blocks], s);
+  std::vector<long> p0(blk_pos0, blk_pos0 + n_blocks), p1(blk_pos1, blk_pos1 + n_blocks);
+  A.sx_pos0.upload(p0, s);
+  A.sx_pos1.upload(p1, s);
+  A.sx_node_ptr.upload(node_ptr, (size_t)nun + 1, s);
+  A.sx_node_ent.upload(node_ent, (size_t)node_ptr[nun], s);
+  A.sx_vert_ptr.upload(vert_ptr, (size_t)np + 1, s);
+  A.sx_vert_ent.upload(vert_ent, (size_t)vert_ptr[np], s);
+  A.sx_outlet.upload(outlet_w, (size_t)h->n_u(), s);
+  if (!A.sol_u) {
+    A.sol_u = h->pool_u.get(true); A.eval_u = h->pool_u.get(true); A.old_u = h->pool_u.get(true);
+    A.sol_p = h->pool_p.get(true); A.eval_p = h->pool_p.get(true);
+  }
+  h->ctx.sync();
+  A.simplex = true;
+  A.ready = true;
+  return 0;
+  NSK_CATCH(h)
+}
+
 int nsk_assemble(nsk_handle h, int stokes, double nu, double inv_dt, double p_out, int inhomogeneous_bc,
                  double *residual_norm) {
   NSK_TRY(h)
@@ -1136,9 +1202,23 @@ int nsk_assemble(nsk_handle h, int stokes, double nu, double inv_dt, double p_ou
   Csr &F = h->blk[NSK_BLK_F];
   hipStream_t s = h->s();
   const double t0 = wall_ms();
-  const AsmMesh M = h->asm_view();
   const int sl = h->ctx.alloc_slots(3);
   struct Rel { Ctx &c; int sl; ~Rel() { c.slot_top = sl; } } rel{h->ctx, sl};
+  if (A.simplex) {   // P2/P1 triangles: general cells (nsk_assembly_kernels.hip, second half)
+    const SimplexMesh SM{A.n_cells, A.sx_blocks, h->n_u() / 2, h->n_p(), A.sx_pos00, A.cell_u.p, A.cell_p.p, A.sx_grad.p,
+                         A.sx_area.p, A.sx_blk_ptr.p, A.sx_blk_ent.p, A.sx_pos0.p, A.sx_pos1.p, A.sx_node_ptr.p,
+                         A.sx_node_ent.p, A.sx_vert_ptr.p, A.sx_vert_ent.p, A.sx_outlet.p, A.dirichlet.p};
+    simplex_assemble(s, SM, A.sol_u, A.sol_p, (A.have_old && inv_dt != 0.0) ? A.old_u : nullptr, nu, inv_dt, p_out, stokes != 0,
+                     F.rowptr.p, F.col.p, F.val.p, h->ctx.slot(sl), inhomogeneous_bc ? A.bc.p : nullptr, h->rhs_b,
+                     h->rhs_b + h->n_u(), h->x_b, h->x_b + h->n_u());
+    F.refresh_blocked(s);
+    h->ctx.norm2(h->N(), h->rhs_b, sl + 1);
+    const double nrm = h->ctx.read_slots(sl + 2, 1)[0];
+    if (residual_norm) *residual_norm = nrm;
+    A.assemble_ms = wall_ms() - t0;
+    return 0;
+  }
+  const AsmMesh M = h->asm_view();
   asm_cell_state(s, M, A.sol_u, A.sol_p, A.have_old ? A.old_u : nullptr, A.cq.p);
   stokes = stokes != 0;
   asm_d0(s, M, A.cq.p, nu, inv_dt, stokes, h->ctx.slot(sl));

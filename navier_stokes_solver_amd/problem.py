@@ -121,6 +121,7 @@ class LocalProblem:
     cell_flags: np.ndarray = None     # [n_cells] bit 0: outlet face
     cell_of_dof0: int = -1
     cell_tables: np.ndarray = None    # 944 doubles, see nsk_problem.h
+    simplex: dict = None              # P2/P1 triangles instead (simplex.device_handoff): nsk_assembly_set_simplex
 
     @property
     def n_u(self) -> int:

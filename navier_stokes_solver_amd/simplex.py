@@ -219,6 +219,50 @@ def assemble(sp_: SimplexSpace, nu, mode=1, state=None, inlet_bc=0, inv_dt=0.0, 
                           params=dict(mode=mode, nu=nu, inv_dt=inv_dt, U=U, p_out=p_out, inlet_bc=inlet_bc))
 
 
+def device_handoff(sp_: SimplexSpace, pr) -> dict:
+    """What `nsk_assembly_set_simplex` takes (include/nsk.h): the cell data plus the transposed connectivity of the
+    gather kernels, from the sparsity of the handed-over block (0,0) (`pr.F`)."""
+    cu, cp = sp_.cell_u, sp_.cell_p
+    T = len(cu)
+    rp, col = pr.F.rowptr.astype(np.int64), pr.F.col.astype(np.int64)
+    n_un = sp_.n_un
+    nblk_of = (rp[1::2] - rp[0:-1:2]) // 2                                  # blocks per node row
+    bstart = np.concatenate([[0], np.cumsum(nblk_of)])
+    nb = int(bstart[-1])
+    node_of_blk = np.repeat(np.arange(n_un), nblk_of)
+    j_of_blk = np.arange(nb) - bstart[node_of_blk]
+    pos0 = rp[2 * node_of_blk] + 2 * j_of_blk
+    pos1 = rp[2 * node_of_blk + 1] + 2 * j_of_blk
+    mcol = col[pos0] // 2
+    lookup = sp.csr_matrix((np.arange(1, nb + 1), mcol, bstart), shape=(n_un, n_un))
+    n_idx = np.repeat(cu[:, :, None], 6, axis=2).ravel()
+    m_idx = np.repeat(cu[:, None, :], 6, axis=1).ravel()
+    bid = np.asarray(lookup[n_idx, m_idx]).ravel() - 1
+    if (bid < 0).any():
+        raise ValueError("a cell couples nodes that are not in the sparsity pattern of block (0,0)")
+    code = (np.arange(T)[:, None] * 36 + np.arange(36)[None, :]).ravel()
+    order = np.argsort(bid, kind="stable")
+    blk_ptr = np.concatenate([[0], np.cumsum(np.bincount(bid, minlength=nb))])
+
+    def per(ids, width, n):
+        c = (np.arange(T)[:, None] * width + np.arange(width)[None, :]).ravel()
+        o = np.argsort(ids.ravel(), kind="stable")
+        return np.concatenate([[0], np.cumsum(np.bincount(ids.ravel(), minlength=n))]).astype(np.int32), c[o].astype(np.int32)
+    node_ptr, node_ent = per(cu, 6, n_un)
+    vert_ptr, vert_ent = per(cp, 3, sp_.n_p)
+    outlet_w = np.zeros(sp_.n_u)
+    a, m, b, nx_, ny_, ln = sp_.outlet[:6]
+    for node, w in ((a, 1 / 6), (m, 4 / 6), (b, 1 / 6)):
+        if len(node):
+            np.add.at(outlet_w, 2 * node.astype(int), w * ln * nx_)
+            np.add.at(outlet_w, 2 * node.astype(int) + 1, w * ln * ny_)
+    pos00 = int(rp[0] + np.searchsorted(col[rp[0]:rp[1]], 0))
+    return dict(cell_u=cu.astype(np.int32), cell_p=cp.astype(np.int32), grad_lam=np.ascontiguousarray(sp_.grad_lam, float),
+                area=np.ascontiguousarray(sp_.area, float), n_blocks=nb, blk_ptr=blk_ptr.astype(np.int32),
+                blk_ent=code[order].astype(np.int32), blk_pos0=pos0.astype(np.int64), blk_pos1=pos1.astype(np.int64),
+                node_ptr=node_ptr, node_ent=node_ent, vert_ptr=vert_ptr, vert_ent=vert_ent, outlet_w=outlet_w, pos00=pos00)
+
+
 def lift_drag(sp_: SimplexSpace, u, p, nu):
     """Forces on the id-10 boundary (`compute_lift_drag`, `.cpp:836-897`): - int (nu (grad u + grad u^T) - p I) n ds with
     the fluid cell's outward normal, two Gauss points per edge (the integrand is at most quadratic there)."""

@@ -337,6 +337,20 @@ class LinearSolver:
     # ---- device assembly and Newton state ----
     def set_assembly(self, pr, bc_u=None):
         """Cell connectivity, reference-cell tables and Dirichlet flags of a LocalProblem."""
+        if getattr(pr, "simplex", None) is not None:      # P2/P1 triangles (general cells)
+            sx = pr.simplex
+            arrs = [np.ascontiguousarray(sx[k]) for k in ("cell_u", "cell_p", "grad_lam", "area")]
+            lst = [np.ascontiguousarray(sx[k]) for k in ("blk_ptr", "blk_ent", "blk_pos0", "blk_pos1", "node_ptr", "node_ent",
+                                                         "vert_ptr", "vert_ent", "outlet_w")]
+            self.L.nsk_assembly_set_simplex.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int64] + \
+                [C.c_void_p] * 9 + [C.c_int64]
+            self._ck(self.L.nsk_assembly_set_simplex(self.h, len(arrs[0]), *[a.ctypes.data for a in arrs], int(sx["n_blocks"]),
+                                                     *[a.ctypes.data for a in lst], int(sx["pos00"])))
+            self._keep_simplex = (arrs, lst)
+            d = np.ascontiguousarray(pr.dirichlet_u, np.uint8)
+            bc = None if bc_u is None else _f64(bc_u)
+            self._ck(self.L.nsk_assembly_set_dirichlet(self.h, d.ctypes.data, None if bc is None else bc.ctypes.data))
+            return
         cu = np.ascontiguousarray(pr.cell_u_nodes, np.int32)
         cp = np.ascontiguousarray(pr.cell_p_dofs, np.int32)
         cf = np.ascontiguousarray(pr.cell_flags, np.uint8)

@@ -75,3 +75,65 @@ def test_cli_reads_a_mesh_file(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert "Number of elements = 122" in out.stdout and "velocity = 568" in out.stdout and "Drag coefficient" in out.stdout
     assert os.path.exists(tmp_path / "output-stokes_0.vtu")
+
+
+@pytest.mark.parametrize("stokes,inv_dt", [(0, 0.0), (1, 0.0), (0, 100.0)])
+def test_device_assembly_of_p2p1_cells_matches_the_host_producer(tmp_path, stokes, inv_dt):
+    """nsk_assemble on general P2/P1 triangles (nsk_assembly_set_simplex): block (0,0) incl. Dirichlet rows, the residual
+    and its norm against the host producer about the same state, on jittered (non-congruent) cells and on the reference's
+    own mesh; two assemblies give the same bits."""
+    from navier_stokes_solver_amd import solver as S
+    for mesh in (channel_mesh(str(tmp_path / "c.msh"), 10, 5, jitter=0.25), REF_MESH):
+        s = SX.build_space(G.read_msh(mesh))
+        rng = np.random.default_rng(7)
+        free = np.repeat(s.dirichlet == 0, 2)
+        u = 0.3 * rng.uniform(-1, 1, s.n_u) * free
+        p = rng.uniform(-1, 1, s.n_p)
+        u_old = 0.3 * rng.uniform(-1, 1, s.n_u) * free
+        nu = 1.0 / 30.0
+        first = SX.assemble(s, 0.1, mode=0, inlet_bc=1, U=0.1)                # the hand-off of the first assembly: pattern
+        first.simplex = SX.device_handoff(s, first)
+        ref = SX.assemble(s, nu, mode=0 if stokes else 1, state=(u, p), inlet_bc=1, U=0.1, inv_dt=inv_dt,
+                          state_old=u_old if inv_dt else None)
+        ls = S.LinearSolver()
+        try:
+            ls.set_problem(first)
+            ls.set_assembly(first, bc_u=first.x0_u)
+            ls.state_set(u, p)
+            if inv_dt:
+                ls.state_set(u_old, p); ls.state_save_old(); ls.state_set(u, p)
+            nrm = ls.assemble(nu, inv_dt, 1.0, inhomogeneous_bc=True, stokes=bool(stokes))
+            rp, col, val = ls.get_block(S.BLK_F)
+            ru, rpp = ls.download_rhs()
+            assert np.array_equal(rp, ref.F.rowptr) and np.array_equal(col, ref.F.col)
+            assert np.abs(val - ref.F.val).max() <= 1e-13 * np.abs(ref.F.val).max()
+            scale = max(np.abs(ref.rhs_u).max(), np.abs(ref.rhs_p).max())
+            assert np.abs(ru - ref.rhs_u).max() <= 1e-13 * scale and np.abs(rpp - ref.rhs_p).max() <= 1e-13 * scale
+            assert abs(nrm - np.sqrt(ref.rhs_u @ ref.rhs_u + ref.rhs_p @ ref.rhs_p)) <= 1e-12 * nrm
+            ls.assemble(nu, inv_dt, 1.0, inhomogeneous_bc=True, stokes=bool(stokes))
+            assert np.array_equal(ls.get_block(S.BLK_F)[2], val)
+        finally:
+            ls.close()
+
+
+def test_newton_with_device_assembly_on_a_gmsh_mesh():
+    """The whole solve_newton() on the GPU for the -M path: DeviceBackend (resident state, nsk_assemble on P2/P1 cells,
+    GPU solves) against the host-assembly driver with sparse-direct solves."""
+    from navier_stokes_solver_amd import solver as S
+    s = SX.build_space(G.read_msh(REF_MESH))
+    ref = N.SimplexBackend(None, s, 1, 2, 1e-11, direct=True)
+    N.solve_newton(ref, 30.0, log=lambda *_: None)
+    first = SX.assemble(s, 0.1, mode=0, inlet_bc=1, U=0.1)
+    first.simplex = SX.device_handoff(s, first)
+    ls = S.LinearSolver()
+    try:
+        ls.set_option(S.OPT_TRI_ORDERING, 1)
+        dev = N.DeviceBackend(ls, first, S.FGMRES, S.ASIMPLE, 1e-11)
+        hist = N.solve_newton(dev, 30.0, log=lambda *_: None)
+        ug, pg = dev.solution()
+    finally:
+        ls.close()
+    ns = [h for h in hist if h[0] == 30.0 and h[5] is not None]
+    assert ns and ns[-1][6] < 1e-9
+    ur, prr = ref.solution()
+    assert rel_err(ug, ur) <= 1e-7 and rel_err(pg, prr) <= 1e-6
