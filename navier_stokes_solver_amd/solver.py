@@ -38,7 +38,7 @@ EXPORTS = [
     "nsk_set_block_csr", "nsk_update_values", "nsk_set_option", "nsk_setup_preconditioner", "nsk_solve",
     "nsk_upload_system", "nsk_solve_resident", "nsk_download_solution", "nsk_spmv", "nsk_jacobian_vmult", "nsk_dot", "nsk_vec_op",
     "nsk_tri_apply", "nsk_amg_info", "nsk_tri_get_perm", "nsk_precond_vmult", "nsk_block_nnz", "nsk_get_block", "nsk_get_stats",
-    "nsk_reset_stats", "nsk_get_history", "nsk_cancel", "nsk_assembly_set_cells", "nsk_assembly_set_dirichlet", "nsk_state_set", "nsk_state_get",
+    "nsk_reset_stats", "nsk_get_history", "nsk_cancel", "nsk_assembly_set_cells", "nsk_assembly_set_simplex", "nsk_assembly_set_dirichlet", "nsk_state_set", "nsk_state_get",
     "nsk_state_save", "nsk_state_save_old", "nsk_state_update", "nsk_assemble", "nsk_scale_values", "nsk_download_rhs", "nsk_time_assemble", "nsk_time_op", "nsk_profile_begin", "nsk_profile_read", "nsk_profile_end",
 ]
 
