@@ -10,8 +10,8 @@ level the reference would visit (`NSSolverStationary.cpp:662-665`, `NSSolver.cpp
 `StationaryNSSolver` runs the reference's whole `solve_newton()` (continuation, Stokes phase, Newton iterations
 with backtracking) with assembly, linear solves and vector updates resident on the GPU (`newton.py`);
 `NSSolver` runs the reference's time loop (`NSSolver::solve()`, one `solve_newton()` per step with the mass term
-and the `solution_old` term in the device assembly).  `-M FILE` (stationary driver): P2/P1 on a gmsh triangle mesh, host
-assembly (`simplex.py`) + the same GPU solves.
+and the `solution_old` term in the device assembly).  `-M FILE`: P2/P1 on a gmsh triangle mesh — hand-off producer `simplex.py`, device assembly on
+the general cells, the same GPU solves.
 """
 from __future__ import annotations
 
@@ -124,9 +124,6 @@ def run_gmsh(cfg, unsteady: bool) -> int:
     from . import newton as N
     from . import simplex as SX
     from . import solver as S
-    if unsteady:
-        sys.stderr.write("-M is built for the stationary driver only\n")
-        return 1
     if cfg["prec"] not in PRECS:
         raise ValueError("Invalid preconditioner type. Use 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE.")
     path = cfg["read_mesh"] if isinstance(cfg["read_mesh"], str) else ""
@@ -141,6 +138,32 @@ def run_gmsh(cfg, unsteady: bool) -> int:
     print("-----------------------------------------------")
     ls = S.LinearSolver()
     ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
+    from . import postprocess as PP
+
+    def report(name, nu, inlet_u):
+        u, p = backend.solution()
+        SX.write_vtu(os.path.join(os.environ.get("NSK_OUTPUT_DIR", "./"), name), space, u, p)
+        print("===============================================\nOutput written to output-stokes")
+        print("===============================================\n===============================================\nComputing lift and drag forces")
+        drag, lift = SX.lift_drag(space, u, p, nu)
+        cd, cl = PP.coefficients(drag, lift, inlet_u)
+        print(f"===============================================\nLift coefficient: {cl:g}")
+        print(f"===============================================\nDrag coefficient: {cd:g}")
+
+    if unsteady:           # NSSolver: the time loop over the same cells (mass and solution_old terms in nsk_assemble)
+        first = SX.assemble(space, 1.0, mode=0, inlet_bc=1, U=0.3)
+        first.simplex = SX.device_handoff(space, first)
+        backend = N.DeviceBackend(ls, first, cfg["solver"], cfg["prec"], cfg["tol"], max_iter=100000, inv_dt=1.0 / cfg["dt"])
+        t0 = time.time()
+        try:
+            nu_last = 1.0 / max(_levels(1.0, 10.0, cfg["Re"]))
+            N.time_loop(backend, cfg["T"], cfg["dt"], cfg["Re"],
+                        after_step=lambda step: report(f"output_{step:03d}.vtu", nu_last, 0.3))
+        finally:
+            print(f"[nsk] {backend.assemblies} assemblies (device, P2/P1), {backend.total_linear_iterations} outer iterations of "
+                  f"solve_system() on the GPU, {time.time() - t0:.3f} s in the time loop")
+            ls.close()
+        return 0
     host_assembly = bool(os.environ.get("NSK_HOST_ASSEMBLY"))
     if host_assembly:      # the hand-off producer on the host for every assembly (the yardstick of the device assembly)
         backend = N.SimplexBackend(ls, space, cfg["solver"], cfg["prec"], cfg["tol"])
@@ -151,17 +174,7 @@ def run_gmsh(cfg, unsteady: bool) -> int:
     t0 = time.time()
     try:
         N.solve_newton(backend, cfg["Re"])
-        u, p = backend.solution()
-        out = os.path.join(os.environ.get("NSK_OUTPUT_DIR", "./"), "output-stokes_0.vtu")
-        SX.write_vtu(out, space, u, p)
-        print("===============================================\nOutput written to output-stokes")
-        nu = 1.0 / max(_levels(10.0, 20.0, cfg["Re"]))
-        print("===============================================\n===============================================\nComputing lift and drag forces")
-        from . import postprocess as PP
-        drag, lift = SX.lift_drag(space, u, p, nu)
-        cd, cl = PP.coefficients(drag, lift, 1.0)
-        print(f"===============================================\nLift coefficient: {cl:g}")
-        print(f"===============================================\nDrag coefficient: {cd:g}")
+        report("output-stokes_0.vtu", 1.0 / max(_levels(10.0, 20.0, cfg["Re"])), 1.0)
     finally:
         dt = time.time() - t0
         its = backend.total_linear_iterations
