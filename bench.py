@@ -69,6 +69,25 @@ def parse():
     return ap.parse_args()
 
 
+def choose_workload(world, scaling="auto", mesh="", reynolds=0.0):
+    """(scaling, nx, ny, Reynolds number) of a run on `world` GPUs.  N = 1: BASELINE configs[2] (1200x400, Re 100).
+    N >= 2: the north star's workload — strong scaling on 4800x1600, Re 200 — whenever a rank's share fits its HBM
+    (3.9 KB per DoF measured; from N = 4), otherwise weak scaling with 1200x400 per GPU.  `mesh` is the per-GPU mesh
+    (weak) or the global one (strong); explicit arguments win."""
+    if scaling == "auto":
+        scaling = "weak"
+        if world > 1 and not mesh and BYTES_PER_DOF * N_DOFS_NORTH_STAR / world <= 0.8 * HBM_BYTES:
+            scaling = "strong"
+    if mesh:
+        mx, my = (int(v) for v in mesh.split(","))
+    else:
+        mx, my = (4800, 1600) if scaling == "strong" else (1200, 400)
+    nx = mx * world if scaling == "weak" else mx
+    if reynolds <= 0.0:
+        reynolds = 200.0 if (scaling == "strong" and not mesh) else 100.0
+    return scaling, nx, my, reynolds
+
+
 def make_solver(S, PT, P, dist, args, nx, ny, nu, inv_dt, world, rank, local_rank):
     """Generate this rank's hand-off, create the handle, upload.  Returns (ls, pr, n_global, t_gen, t_upload)."""
     t0 = time.time()
@@ -230,19 +249,7 @@ def main():
     from navier_stokes_solver_amd import solver as S
 
     # ---- workload (see the module docstring)
-    scaling = args.scaling
-    if scaling == "auto":
-        scaling = "weak"
-        if world > 1 and not args.mesh and BYTES_PER_DOF * N_DOFS_NORTH_STAR / world <= 0.8 * HBM_BYTES:
-            scaling = "strong"
-    if args.mesh:
-        mx, my = (int(v) for v in args.mesh.split(","))
-    else:
-        mx, my = (4800, 1600) if scaling == "strong" else (1200, 400)
-    nx = mx * world if scaling == "weak" else mx
-    ny = my
-    if args.reynolds <= 0.0:
-        args.reynolds = 200.0 if (scaling == "strong" and not args.mesh) else 100.0
+    scaling, nx, ny, args.reynolds = choose_workload(world, args.scaling, args.mesh, args.reynolds)
     nu = P.reynolds_to_nu(args.reynolds, stationary=(args.variant == 0))
     inv_dt = 0.0 if args.variant == 0 else 100.0
 
