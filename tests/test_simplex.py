@@ -111,3 +111,33 @@ def test_newton_driver_with_direct_solves_converges_on_the_reference_mesh():
     u, p = backend.solution()
     assert np.abs(u[0::2][(s.dirichlet & 2) != 0] - SX.inlet_profile(s.xy_u[(s.dirichlet & 2) != 0, 1], 0.1)).max() < 1e-12
     assert np.isfinite(SX.lift_drag(s, u, p, 0.1)).all()
+
+
+def test_device_handoff_lists_are_a_transposition_of_the_cell_lists(tmp_path):
+    """`simplex.device_handoff` (input of nsk_assembly_set_simplex): every (cell, local row node, local column node) sits
+    in exactly one block list, that block is the (row node, column node) entry of block (0,0), and the node / vertex
+    lists hold every (cell, local node) once — checked by scattering a tag per entry through the lists on the host."""
+    s = SX.build_space(G.read_msh(channel_mesh(str(tmp_path / "c.msh"), 6, 4, jitter=0.2)))
+    pr = SX.assemble(s, 0.1, mode=0, inlet_bc=1)
+    h = SX.device_handoff(s, pr)
+    T = len(s.cell_u)
+    assert sorted(h["blk_ent"].tolist()) == list(range(36 * T))
+    assert sorted(h["node_ent"].tolist()) == list(range(6 * T)) and sorted(h["vert_ent"].tolist()) == list(range(3 * T))
+    rp, col = pr.F.rowptr, pr.F.col
+    assert h["n_blocks"] * 4 == pr.F.nnz and h["pos00"] == 0 and col[0] == 0
+    for b in range(h["n_blocks"]):
+        p0, p1 = int(h["blk_pos0"][b]), int(h["blk_pos1"][b])
+        n = int(np.searchsorted(rp, p0, side="right") - 1) // 2
+        m = int(col[p0]) // 2
+        assert col[p0 + 1] == 2 * m + 1 and col[p1] == 2 * m and rp[2 * n] <= p0 < rp[2 * n + 1] <= p1 < rp[2 * n + 2]
+        for code in h["blk_ent"][h["blk_ptr"][b]:h["blk_ptr"][b + 1]]:
+            t, ln, lm = code // 36, (code % 36) // 6, code % 6
+            assert s.cell_u[t, ln] == n and s.cell_u[t, lm] == m
+    for n in range(s.n_un):
+        for code in h["node_ent"][h["node_ptr"][n]:h["node_ptr"][n + 1]]:
+            assert s.cell_u[code // 6, code % 6] == n
+    for j in range(s.n_p):
+        for code in h["vert_ent"][h["vert_ptr"][j]:h["vert_ptr"][j + 1]]:
+            assert s.cell_p[code // 3, code % 3] == j
+    # outlet weights: integral of phi_n . n over the outlet = its length for the sum of all shape functions (partition of unity)
+    assert abs(h["outlet_w"][0::2].sum() - 0.41) < 1e-14 and abs(h["outlet_w"][1::2].sum()) < 1e-14
