@@ -779,6 +779,7 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
       h->fault_inject = (int)v;
       h->tMp.sf_fault = h->tS.sf_fault = (h->fault_inject & 1) != 0;
       h->tF.sf_fault = (h->fault_inject & 2) != 0;
+      h->ctx.mgs_fault = (h->fault_inject & 4) != 0;
       break;
     case NSK_IOPT_WINDOW_SPMV:   // set before the blocks are handed over (the window copy is built with the block)
       h->use_win_spmv = v != 0.0;

@@ -339,6 +339,7 @@ bool Ctx::mgs_sweep(int n, double *w, double *const *v, int nv, int so) {
   A.rearm = mgs_tables.p + (size_t)(1 - mgs_parity) * tab;
   A.out = slot(so);
   A.err = mgs_err.p;
+  A.fault = mgs_fault ? 1 : 0;
   if (!nsk::mgs_sweep(stream, A, G)) return false;
   mgs_parity = 1 - mgs_parity;
   st.reductions += nv + 1;

@@ -242,6 +242,8 @@ struct Ctx {
   // false: not applicable, nothing done — the caller runs the chain of dot / axpy_dot launches.
   bool mgs_sweep(int n, double *w, double *const *v, int nv, int slot_out);
   bool fused_mgs = true;   // NSK_IOPT_FUSED_MGS
+  long mgs_fallbacks = 0;  // sweeps that timed out and were redone link by link (FGMRES)
+  bool mgs_fault = false;  // NSK_IOPT_FAULT_INJECT bit 2
   DBuf<double> mgs_tables;
   DBuf<int> mgs_err;
   int mgs_parity = 0, mgs_grid = 0;

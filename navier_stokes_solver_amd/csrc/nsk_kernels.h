@@ -117,6 +117,7 @@ struct MgsArgs {
   const double *v[kMgsMaxVecs];
   double *aux, *table, *rearm, *out;
   int *err;
+  int fault;   // test hook: workgroup 0 withholds its first partial sum, so every wait on it runs out
 };
 bool mgs_sweep(hipStream_t s, const MgsArgs &A, int G);
 // single-reduction (Chronopoulos-Gear) CG building blocks: see SolverCG::solve_fused

@@ -1405,7 +1405,7 @@ __global__ __launch_bounds__(kMgsThreads) void mgs_sweep_kernel(MgsArgs A) {
     if (t == 0) {
       double sblk = 0.0;
       for (int q = 0; q < kMgsThreads / 64; ++q) sblk += wsum[q];
-      sf_store(A.table + (size_t)k * G + blockIdx.x, sblk);
+      if (!(A.fault && blockIdx.x == 0 && k == 0)) sf_store(A.table + (size_t)k * G + blockIdx.x, sblk);
     }
     double q = 0.0;
     if (t < G && !dead) {

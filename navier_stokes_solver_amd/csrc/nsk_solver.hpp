@@ -264,7 +264,18 @@ struct SolverFGMRES : SolverBase {
           ctx.axpy_norm2(n, sref(-1.0, ctx.slot(HS + j)), v[j], aux.own, HS + j + 1);
         }
         const double *h = ctx.read_slots(HS, j + 4);
-        if (mgs_flag >= 0 && h[j + 3] != 0.0) throw Error(-71, "one-launch Gram-Schmidt sweep timed out (workgroups not co-resident?)");
+        if (mgs_flag >= 0 && h[j + 3] != 0.0) {
+          // a wait of the one-launch sweep gave up (its workgroups were not co-resident: another process on the GPU?):
+          // w = A z_j is formed again and orthogonalised link by link; the sweep stays off for this handle
+          ctx.fused_mgs = false;
+          ++ctx.mgs_fallbacks;
+          A(zj, aux.own);
+          ctx.dot(n, aux.own, v[0], HS);
+          for (int i = 1; i <= j; ++i)
+            ctx.axpy_dot(n, sref(-1.0, ctx.slot(HS + i - 1)), v[i - 1], aux.own, v[i], HS + i);
+          ctx.axpy_norm2(n, sref(-1.0, ctx.slot(HS + j)), v[j], aux.own, HS + j + 1);
+          h = ctx.read_slots(HS, j + 3);
+        }
         for (int i = 0; i <= j; ++i) H[i * kBasis + j] = h[i];
         H[(j + 1) * kBasis + j] = a = h[j + 2];
         a_slot = HS + j + 2;

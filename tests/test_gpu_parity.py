@@ -641,3 +641,26 @@ def test_one_launch_gram_schmidt_matches_the_chain_of_launches(mesh, solver):
     assert len(h1) == len(h0) >= 24
     assert np.abs(h1 - h0).max() <= 1e-9 * np.abs(h0).max()
     assert rel_err(x1, x0) <= 1e-9
+
+
+def test_one_launch_gram_schmidt_times_out_and_falls_back():
+    """Fault injection (NSK_IOPT_FAULT_INJECT bit 2): workgroup 0 of the first sweep withholds a partial sum, every wait
+    on it runs out (bounded spin), FGMRES forms w = A z_j again and orthogonalises it link by link, the sweep stays off:
+    the solve must give exactly what the handle without the sweep gives."""
+    S = _S()
+    from navier_stokes_solver_amd import problem as P
+    pr = P.generate(60, 20, nu=1.0 / 91.0, mode=1, state=1, inv_dt=100.0, U=0.3)
+    out = []
+    for fused, fault in ((1, 4), (0, 0)):
+        ls = S.LinearSolver()
+        try:
+            ls.set_option(S.OPT_TRI_ORDERING, 1)
+            ls.set_option(S.IOPT_FUSED_MGS, fused)
+            ls.set_option(S.IOPT_FAULT_INJECT, fault)
+            ls.set_problem(pr)
+            ls.setup_preconditioner(S.ASIMPLE, S.UNSTEADY, 0.5)
+            xu, xp, its, res, rc = ls.solve(S.FGMRES, 0.0, 12, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+            out.append((np.concatenate([xu, xp]), ls.history()))
+        finally:
+            ls.close()
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
