@@ -2,6 +2,7 @@
 #include "nsk_amg.hpp"
 
 #include <omp.h>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 
@@ -173,23 +174,52 @@ HostCsr smoothed_prolongator(const HostCsr &A, const std::vector<int> &agg, int 
   });
 }
 
+// stable counting sort by column, row chunks in parallel (per-thread column histograms)
 HostCsr transpose(const HostCsr &A) {
   HostCsr T;
   T.n_rows = A.n_cols;
   T.n_cols = A.n_rows;
   const size_t nnz = A.col.size();
-  T.rp.assign((size_t)T.n_rows + 1, 0);
+  const int nc = A.n_cols;
+  T.rp.assign((size_t)nc + 1, 0);
   T.col.resize(nnz);
   T.val.resize(nnz);
-  for (size_t k = 0; k < nnz; ++k) ++T.rp[A.col[k] + 1];
-  for (int j = 0; j < T.n_rows; ++j) T.rp[j + 1] += T.rp[j];
-  std::vector<int> w(T.rp.begin(), T.rp.end() - 1);
-  for (int i = 0; i < A.n_rows; ++i)
-    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) {
-      const int p = w[A.col[k]]++;
-      T.col[p] = i;
-      T.val[p] = A.val[k];
+  const int nt = std::max(1, omp_get_max_threads());
+  std::vector<std::vector<int>> cnt((size_t)nt);
+  int team_used = 1;
+#pragma omp parallel num_threads(nt)
+  {
+    const int t = omp_get_thread_num(), team = omp_get_num_threads();
+    if (t == 0) team_used = team;
+    const int r0 = (int)((int64_t)A.n_rows * t / team), r1 = (int)((int64_t)A.n_rows * (t + 1) / team);
+    std::vector<int> &c = cnt[t];
+    c.assign((size_t)nc, 0);
+    for (int k = A.rp[r0]; k < A.rp[r1]; ++k) ++c[A.col[k]];
+  }
+  // position of (column j, thread t)'s first entry: columns in order, inside a column the threads (= row chunks) in order
+  int64_t run = 0;
+  for (int j = 0; j < nc; ++j) {
+    T.rp[j] = (int)run;
+    for (int t = 0; t < nt; ++t) {
+      if (cnt[t].empty()) continue;
+      const int c = cnt[t][j];
+      cnt[t][j] = (int)run;
+      run += c;
     }
+  }
+  T.rp[nc] = (int)run;
+#pragma omp parallel for schedule(static, 1) num_threads(team_used)
+  for (int t = 0; t < team_used; ++t) {   // the same row chunks as above, whoever runs them
+    const int team = team_used;
+    const int r0 = (int)((int64_t)A.n_rows * t / team), r1 = (int)((int64_t)A.n_rows * (t + 1) / team);
+    std::vector<int> &w = cnt[t];
+    for (int i = r0; i < r1; ++i)
+      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+        const int p = w[A.col[k]]++;
+        T.col[p] = i;
+        T.val[p] = A.val[k];
+      }
+  }
   return T;
 }
 
