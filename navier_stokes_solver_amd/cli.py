@@ -126,7 +126,11 @@ def run_gmsh(cfg, unsteady: bool) -> int:
     from . import solver as S
     if cfg["prec"] not in PRECS:
         raise ValueError("Invalid preconditioner type. Use 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE.")
-    path = cfg["read_mesh"] if isinstance(cfg["read_mesh"], str) else ""
+    # no file after -M: the reference's hard-coded path (testStationary.cpp:127), or $NSK_MESH_FILE
+    path = cfg["read_mesh"] if isinstance(cfg["read_mesh"], str) else os.environ.get(
+        "NSK_MESH_FILE", "/home/users/gdaneri/navier_stokes_solver/lab_new/mesh/new_mesh.msh")
+    if not os.path.isfile(path):
+        raise SystemExit(f"Error: mesh file '{path}' not found (give it after -M, or set NSK_MESH_FILE)")
     print("Initializing the mesh")
     print(f"Mesh file name = {path}")
     space = SX.build_space(G.read_msh(path))

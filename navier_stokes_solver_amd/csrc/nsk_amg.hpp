@@ -51,6 +51,13 @@ struct Amg {
   void setup(Ctx *ctx, Csr &F, const std::vector<int> &shard_off);
   void apply(const double *b, double *x);
   void clear() { shards.clear(); }   // (the host copy of level 0 stays: see host0)
+  // a new PATTERN of the block (nsk_set_block_csr): the kept host copy of level 0 describes the old one
+  void drop_host_copy() {
+    std::vector<HostCsr>().swap(host0);
+    host0_key = nullptr;
+    host0_nnz = 0;
+    host0_off.clear();
+  }
   int n_levels(int shard = 0) const { return shards.empty() ? 0 : (int)shards[shard].lev.size(); }
   int level_rows(int shard, int l) const { return shards[shard].lev[l]->n; }
   int64_t level_nnz(int shard, int l) const { return shards[shard].lev[l]->A->nnz; }

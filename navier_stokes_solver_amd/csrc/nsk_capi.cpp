@@ -86,7 +86,6 @@ struct nsk_handle_s {
   int x_layout_mode = 2;   // NSK_IOPT_TRI_X_LAYOUT
   int sync_free_mode = 2;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
   int fault_inject = 0;    // NSK_IOPT_FAULT_INJECT
-  int use_win_spmv = 0;    // NSK_IOPT_WINDOW_SPMV
   DBuf<int> jrow_blk, jblk_blk;  // row runs of the fused (F | Bt) block row: CSR and blocked variants
   int jrow_nblk = 0, jblk_nblk = 0;
   bool jrow_ok = false, jblk_ok = false;
@@ -107,7 +106,9 @@ struct nsk_handle_s {
     const double t0 = wall_ms();
     amgF.setup(&ctx, blk[NSK_BLK_F], sub_offsets(0));
     setup_ms += wall_ms() - t0;
+    lazy_setup_ms += wall_ms() - t0;   // set-up work that ran inside a solve: counted as set-up, not as solve time
   }
+  double lazy_setup_ms = 0;
   bool tF_ok = false, tMp_ok = false, tS_ok = false, s_symbolic = false;
   int tF_key = -1, tMp_key = -1, tS_key = -1;
   TriSolve *tP = nullptr;
@@ -171,9 +172,6 @@ struct nsk_handle_s {
     if (smp) (void)hipEventRecord(smp->e0[smp->used], s());
     if (A.blk_ok && use_stream && use_bsr && mode == 0)
       nsk::spmv_blk_stream(s(), A.blk_view(), A.blk_R, A.blk_C, A.blk_rowblk.p, A.blk_nblk, x.own, x.ghost, y);
-    else if (A.win_ok && use_stream && use_win_spmv && x.ghost == x.own + A.n_own_cols &&
-             (reinterpret_cast<uintptr_t>(x.own) & 127u) == 0)
-      nsk::spmv_win(s(), A.win_view(), A.win_nruns, x.own, y, mode, z);   // scalar blocks S, Mp: window format
     else if (A.stream_ok && use_stream)
       nsk::spmv_stream(s(), A.view(), A.rowblk.p, A.nblk, A.even_rows, x.own, x.ghost, y, mode, z);
     else
@@ -190,7 +188,7 @@ struct nsk_handle_s {
   long overlapped_spmvs = 0;
   void spmv_halo(Csr &A, int space, const DVec &x, double *y) {
     const bool blocked = A.blk_ok && use_stream && use_bsr;
-    const bool streamed = !blocked && A.stream_ok && use_stream && !(A.win_ok && use_win_spmv);
+    const bool streamed = !blocked && A.stream_ok && use_stream;
     const int b0 = blocked ? A.blk_int_b0 : A.int_b0, b1 = blocked ? A.blk_int_b1 : A.int_b1;
     const int nb = blocked ? A.blk_nblk : A.nblk;
     EventSampler::Slot *smp = sampler.find((int)(&A - blk));
@@ -252,10 +250,6 @@ struct nsk_handle_s {
       ctx.st.spmv_bytes += fused_bytes;
     } else if (fuse_block_row && use_stream && jrow_ok) {
       nsk::spmv2_stream(s(), F.view(), xu.own, xu.ghost, Bt.view(), xp.own, xp.ghost, jrow_blk.p, jrow_nblk, yb);
-      ctx.st.spmv_calls += 2;
-      ctx.st.spmv_bytes += fused_bytes;
-    } else if (fuse_block_row) {
-      nsk::spmv2(s(), F.view(), xu.own, xu.ghost, Bt.view(), xp.own, xp.ghost, yb, F.lpr);
       ctx.st.spmv_calls += 2;
       ctx.st.spmv_bytes += fused_bytes;
     } else {
@@ -362,7 +356,6 @@ void H::schur_symbolic() {
   S.lpr = pick_lpr(S.nnz, S.n_rows);
   S.present = true;
   S.build_stream_plan(s());
-  if (use_win_spmv) S.build_win(s());
   ctx.sync();
   s_symbolic = true;
 }
@@ -415,7 +408,6 @@ void H::setup(int type, int variant_, double alpha_) {
     Csr &S = blk[NSK_BLK_S], &B = blk[NSK_BLK_B], &Bt = blk[NSK_BLK_BT], &Btg = blk[NSK_BLK_BT_GHOST];
     spgemm_bdbt_numeric(s(), B.view(), Dinv, Dinv + n_u(), Bt.view(), Btg.present ? Btg.view() : Bt.view(), S.rowptr.p,
                         S.col.p, S.val.p, S.n_rows, std::max(1, s_max_row));
-    S.refresh_win(s());
     if (!tS_ok || tS_key != key) {
       tS.analyze(&ctx, S, 0, tri_ordering, sub_offsets(1));
       tS_ok = true;
@@ -582,6 +574,7 @@ int H::solve_resident(int solver, double tol, int max_iter, int *iters, double *
   if (prec_type < 0) throw Error(-46, "call nsk_setup_preconditioner first");
   if (solver < 0 || solver > 2) throw Error(-47, "Invalid solver type. Use 0: GMRES, 1: FGMRES, 2: Bicgstab.");
   const double t0 = wall_ms();
+  lazy_setup_ms = 0;
   cancel = 0;
   const bool guarded = sync_free_mode > 0;
   if (guarded) {   // keep the initial guess: a failed attempt leaves garbage in x_b
@@ -597,12 +590,15 @@ int H::solve_resident(int solver, double tol, int max_iter, int *iters, double *
     sync_free_mode = 0;
     tMp.sync_free = tS.sync_free = tF.sync_free = false;
     ++sync_free_fallbacks;
+    ctx.warn("single-launch triangular solve: a producer/consumer wait ran out of spins (workgroups not resident in "
+             "dispatch order: another process on the GPU?); the solve is redone from the caller's initial guess with one "
+             "launch per colour, and this handle keeps that slower path (NSK_OPT_TRI_SYNC_FREE = 0)");
     setup(prec_type, variant, alpha);
     vec_copy(s(), N(), x_keep, x_b);
     outer_iters = undo;
     rc = solve_once(solver, tol, max_iter, iters, final_res);
   }
-  solve_ms = wall_ms() - t0;
+  solve_ms = wall_ms() - t0 - lazy_setup_ms;
   return rc;
 }
 
@@ -648,6 +644,7 @@ nsk_handle nsk_create(int rank, int nranks, int device_id, const void *uid) {
   H *h = new H();
   try {
     h->ctx.init(device_id);
+    h->ctx.warn_text = &h->err;
     h->ctx.comm.init(rank, nranks, uid);
 
   } catch (const std::exception &e) {
@@ -737,11 +734,15 @@ int nsk_set_block_csr(nsk_handle h, int b, int n_rows, int n_cols, const int32_t
   if (b == NSK_BLK_F) A.build_blocked(2, 2, h->s());
   if (b == NSK_BLK_BT) A.build_blocked(2, 1, h->s());
   if (b == NSK_BLK_B) A.build_blocked(1, 2, h->s());
-  if (b == NSK_BLK_MP && h->use_win_spmv) A.build_win(h->s());
   h->ctx.sync();
   if (b == NSK_BLK_F || b == NSK_BLK_BT) { h->jrow_ok = h->jblk_ok = false; h->jrow_nblk = h->jblk_nblk = 0; }
   // a new pattern invalidates cached symbolic data
-  if (b == NSK_BLK_F) h->tF_ok = false;
+  if (b == NSK_BLK_F) {
+    h->tF_ok = false;
+    h->amgF.clear();
+    h->amgF.drop_host_copy();   // same address, same nnz, other pattern: the kept level-0 copy must not be reused
+    if (h->amg_active) h->amg_pending = true;
+  }
   if (b == NSK_BLK_MP) h->tMp_ok = false;
   if (b == NSK_BLK_B || b == NSK_BLK_BT || b == NSK_BLK_BT_GHOST) { h->s_symbolic = false; h->tS_ok = false; }
   return 0;
@@ -756,7 +757,6 @@ int nsk_update_values(nsk_handle h, int b, const double *val) {
   Csr &A = h->blk[b];
   NSK_HIP(hipMemcpyAsync(A.val.p, val, sizeof(double) * (size_t)A.nnz, hipMemcpyHostToDevice, h->s()));
   A.refresh_blocked(h->s());
-  A.refresh_win(h->s());
   h->ctx.sync();
   return 0;
   NSK_CATCH(h)
@@ -780,13 +780,6 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
       h->tMp.sf_fault = h->tS.sf_fault = (h->fault_inject & 1) != 0;
       h->tF.sf_fault = (h->fault_inject & 2) != 0;
       h->ctx.mgs_fault = (h->fault_inject & 4) != 0;
-      break;
-    case NSK_IOPT_WINDOW_SPMV:   // set before the blocks are handed over (the window copy is built with the block)
-      h->use_win_spmv = v != 0.0;
-      if (h->use_win_spmv) {
-        if (h->blk[NSK_BLK_MP].present && !h->blk[NSK_BLK_MP].win_ok) { h->blk[NSK_BLK_MP].build_win(h->s()); h->ctx.sync(); }
-        if (h->blk[NSK_BLK_S].present && !h->blk[NSK_BLK_S].win_ok) { h->blk[NSK_BLK_S].build_win(h->s()); h->ctx.sync(); }
-      }
       break;
     case NSK_IOPT_FUSED_MGS: h->ctx.fused_mgs = v != 0.0; break;
     case NSK_IOPT_OVERLAP_HALO: h->overlap_halo = v != 0.0; break;
@@ -1154,6 +1147,10 @@ int nsk_assembly_set_simplex(nsk_handle h, int64_t n_cells, const int32_t *cell_
     if (blk_pos0[b] < 0 || blk_pos0[b] + 1 >= F.nnz || blk_pos1[b] < 0 || blk_pos1[b] + 1 >= F.nnz)
       throw Error(-64, "simplex assembly: block position outside block (0,0)");
   }
+  for (int i = 0; i < nun; ++i)
+    if (node_ptr[i + 1] < node_ptr[i]) throw Error(-64, "simplex assembly: node list not ascending");
+  for (int i = 0; i < np; ++i)
+    if (vert_ptr[i + 1] < vert_ptr[i]) throw Error(-64, "simplex assembly: vertex list not ascending");
   for (int k = 0; k < blk_ptr[n_blocks]; ++k)
     if (blk_ent[k] < 0 || blk_ent[k] / 36 >= n_cells) throw Error(-64, "simplex assembly: block entry names no cell");
   for (int k = 0; k < node_ptr[nun]; ++k)
@@ -1246,7 +1243,6 @@ int nsk_scale_values(nsk_handle h, int blk, double factor) {
   Csr &A = h->blk[blk];
   vec_scale(h->s(), (int)A.nnz, sref(factor), A.val.p);
   A.refresh_blocked(h->s());
-  A.refresh_win(h->s());
   return 0;
   NSK_CATCH(h)
 }
@@ -1502,7 +1498,7 @@ int nsk_profile_read(nsk_handle h, int op, double *avg_ms, int *n_samples, doubl
     else *bytes = 0.0;
   }
   if (bytes_format) {   // what the storage format in use really holds (<= the CSR figure for the node-block copies)
-    if (op >= 0 && op <= NSK_BLK_S) *bytes_format = h->blk[op].format_bytes(h->use_stream && h->use_bsr, h->use_stream && h->use_win_spmv);
+    if (op >= 0 && op <= NSK_BLK_S) *bytes_format = h->blk[op].format_bytes(h->use_stream && h->use_bsr);
     else if (op == 20) *bytes_format = h->tF.format_bytes();
     else if (op == 21 && h->tP) *bytes_format = h->tP->format_bytes();
     else *bytes_format = 0.0;

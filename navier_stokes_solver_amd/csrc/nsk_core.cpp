@@ -317,10 +317,30 @@ void Ctx::multi_axpy(int n, double *w, double *const *v, int m, int coef_slot, i
   st.blas1_bytes += 8.0 * n * (m + 2);
 }
 
-bool Ctx::mgs_sweep(int n, double *w, double *const *v, int nv, int so) {
+bool Ctx::mgs_applicable(int n, int nv) const {
   if (!fused_mgs || comm.active() || nv < 1 || nv > kMgsMaxVecs) return false;
   const int G = std::min(n_cu, kMgsThreads);
-  if ((long)n > (long)G * kMgsThreads * 12) return false;   // 12 entries per thread: 3.1 M rows on 256 CUs
+  return (long)n <= (long)G * kMgsThreads * 12;   // 12 entries per thread: 3.1 M rows on 256 CUs
+}
+
+void Ctx::warn(const std::string &msg) {
+  fprintf(stderr, "[nsk] warning: %s\n", msg.c_str());
+  if (warn_text) *warn_text = "warning: " + msg;
+}
+
+// A wait of the sweep ran out: leave the sweep off for this handle, say so, and clear the error word (a set word makes
+// every later wait give up at its first look).
+void Ctx::mgs_timed_out() {
+  fused_mgs = false;
+  ++mgs_fallbacks;
+  if (mgs_err.p) NSK_HIP(hipMemsetAsync(mgs_err.p, 0, sizeof(int), stream));
+  warn("one-launch Gram-Schmidt sweep: a wait ran out of spins (workgroups not co-resident: another process on the "
+       "GPU?); this column is redone link by link and the sweep stays off for this handle (slower, same results)");
+}
+
+bool Ctx::mgs_sweep(int n, double *w, double *const *v, int nv, int so) {
+  if (!mgs_applicable(n, nv)) return false;
+  const int G = std::min(n_cu, kMgsThreads);
   const size_t tab = (size_t)(kMgsMaxVecs + 1) * G;
   if (mgs_grid != G) {
     mgs_tables.alloc(2 * tab);
@@ -340,6 +360,7 @@ bool Ctx::mgs_sweep(int n, double *w, double *const *v, int nv, int so) {
   A.out = slot(so);
   A.err = mgs_err.p;
   A.fault = mgs_fault ? 1 : 0;
+  NSK_HIP(hipMemsetAsync(slot(so + nv + 2), 0, sizeof(double), stream));   // the "sums invalid" flag: raised by any workgroup
   if (!nsk::mgs_sweep(stream, A, G)) return false;
   mgs_parity = 1 - mgs_parity;
   st.reductions += nv + 1;
@@ -478,40 +499,6 @@ void Csr::build_blocked(int R, int C, hipStream_t s) {
   refresh_blocked(s);
 }
 
-// upload helper of the window format: two int4 per run
-std::vector<int4> win_pack_runs(const std::vector<WinRun> &runs) {
-  std::vector<int4> out(2 * runs.size());
-  for (size_t b = 0; b < runs.size(); ++b) {
-    const WinRun &R = runs[b];
-    out[2 * b] = make_int4(R.r0, R.nrows, R.l0, R.nl);
-    out[2 * b + 1] = make_int4(R.p0, R.q2, R.roff0, R.flags);
-  }
-  return out;
-}
-
-void Csr::build_win(hipStream_t s) {
-  win_ok = false;
-  if (n_rows <= 0 || nnz <= 0) return;
-  WinFormat W;
-  if (!build_win_format(n_rows, h_rowptr.data(), h_col.data(), nullptr, nullptr, nullptr, kWinMaxLines, 0, 0, W)) return;
-  win_nruns = (int)W.runs.size();
-  win_slots = W.n_slots;
-  win_bytes = W.bytes_per_apply();
-  win_runs.upload(win_pack_runs(W.runs), s);
-  win_lines.upload(W.lines, s);
-  win_roff.upload(W.roff, s);
-  win_pos.upload(W.pos, s);
-  win_src.upload(W.src, s);
-  win_val.alloc((size_t)W.n_slots);
-  NSK_HIP(hipStreamSynchronize(s));
-  win_ok = true;
-  refresh_win(s);
-}
-
-void Csr::refresh_win(hipStream_t s) {
-  if (win_ok) vec_gather_or_zero(s, (long)win_slots, win_src.p, val.p, win_val.p);
-}
-
 void Csr::refresh_blocked(hipStream_t s) {
   if (blk_ok) vec_gather(s, (int)(blk_count * blk_R * blk_C), blk_src.p, val.p, blk_val.p);
 }
@@ -522,7 +509,7 @@ double *VecPool::get(bool zero) {
     p = free_list.back();
     free_list.pop_back();
   } else {
-    // whole 128-byte lines plus one: the window kernels copy the lines a run touches, including the last, partial one
+    // whole 128-byte lines plus one
     NSK_HIP(hipMalloc((void **)&p, sizeof(double) * (((size_t)n + ng + 15) / 16 * 16 + 16)));
     all.push_back(p);
     zero = true;

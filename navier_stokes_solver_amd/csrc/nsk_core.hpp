@@ -19,7 +19,6 @@
 #include <vector>
 
 #include "nsk_kernels.h"
-#include "nsk_win.hpp"
 
 struct ncclComm;
 
@@ -116,26 +115,11 @@ struct Csr {  // device CSR block with host copy of the pattern
   void build_blocked(int R, int C, hipStream_t s);  // pattern analysis + upload (host); values via refresh_blocked
   void refresh_blocked(hipStream_t s);              // blk_val[k] = val[blk_src[k]] on the device
   BlkView blk_view() const { return BlkView{blk_rows, n_own_cols / blk_C, blk_rowptr.p, blk_col.p, blk_val.p}; }
-  // window-format copy (nsk_win.hpp; scalar blocks S and Mp): used when x is one contiguous, 128-byte aligned vector
-  bool win_ok = false;
-  int win_nruns = 0;
-  int64_t win_slots = 0;
-  double win_bytes = 0;   // bytes one pass over the window copy reads (values, positions, lines, descriptors)
-  DBuf<int4> win_runs;
-  DBuf<int> win_lines, win_src;
-  DBuf<unsigned short> win_roff, win_pos;
-  DBuf<double> win_val;
-  void build_win(hipStream_t s);     // pattern analysis + upload (host); values via refresh_win
-  void refresh_win(hipStream_t s);   // win_val[k] = val[win_src[k]] (0 in padding slots) on the device
-  WinView win_view() const {
-    return WinView{win_runs.p, win_lines.p, win_roff.p, reinterpret_cast<const unsigned *>(win_pos.p), win_val.p};
-  }
   CsrView view() const { return CsrView{n_rows, n_own_cols, rowptr.p, col.p, val.p}; }
   // bytes the storage format the SpMV kernels actually stream holds (values, indices, descriptors) + y + x once
-  double format_bytes(bool blocked, bool window) const {
+  double format_bytes(bool blocked) const {
     if (blocked && blk_ok)
       return (double)blk_count * (4.0 + 8.0 * blk_R * blk_C) + 4.0 * (blk_rows + 1.0) + 8.0 * n_rows + 8.0 * n_cols;
-    if (window && win_ok) return win_bytes + 8.0 * n_rows + 8.0 * n_cols;
     return (double)spmv_bytes();
   }
   size_t spmv_bytes() const {  // 12 nnz + 4 (rows+1) + 8 rows + 8 cols
@@ -148,9 +132,6 @@ struct Csr {  // device CSR block with host copy of the pattern
 // single row exceeds max_nnz.
 bool build_rowblocks(const int *rowptr_a, const int *rowptr_b, int n_rows, int max_nnz, const std::vector<int> *cuts,
                      std::vector<int> &rowblk);
-
-// device layout of the window format's run list: two int4 per run
-std::vector<int4> win_pack_runs(const std::vector<WinRun> &runs);
 
 inline int pick_lpr(int64_t nnz, int n_rows) {
   const double mean = n_rows > 0 ? (double)nnz / n_rows : 0.0;
@@ -241,6 +222,11 @@ struct Ctx {
   // in registers): slots[so + i] = h_i, [so + nv] = |w|^2, [so + nv + 1] = |w|, [so + nv + 2] = 1 if it timed out.
   // false: not applicable, nothing done — the caller runs the chain of dot / axpy_dot launches.
   bool mgs_sweep(int n, double *w, double *const *v, int nv, int slot_out);
+  bool mgs_applicable(int n, int nv) const;   // would mgs_sweep run for this shape?
+  void mgs_timed_out();                       // consume a timeout: sweep off, counter, error word cleared, warning
+  // warnings (a fallback that changes speed, not results): one line on stderr and the text nsk_last_error returns
+  std::string *warn_text = nullptr;
+  void warn(const std::string &msg);
   bool fused_mgs = true;   // NSK_IOPT_FUSED_MGS
   long mgs_fallbacks = 0;  // sweeps that timed out and were redone link by link (FGMRES)
   bool mgs_fault = false;  // NSK_IOPT_FAULT_INJECT bit 2

@@ -10,8 +10,6 @@ enum {
                                 // bit 1: the blocked velocity solve walks its upper half backwards — consumers before
                                 // producers, so the bounded spins give up and the fallback has to take over;
                                 // bit 2: workgroup 0 of the one-launch Gram-Schmidt sweep withholds its first partial sum
-  NSK_IOPT_WINDOW_SPMV = 101,   // 1: SpMV with S / Mp on the window format (measured on par with the CSR-stream kernel at
-                                // 1200x400: 0.256 vs 0.249 ms for S); 0 (default): CSR-stream kernel
   NSK_IOPT_TINY_BYTES = 102,    // triangular factors below this many bytes (default 4e6) are solved by ONE workgroup walking
                                 // all levels; the tests set 0 to run the streamed kernels on small meshes
   NSK_IOPT_OVERLAP_HALO = 107,  // 1 (default): several ranks — interior rows of the inner solvers' SpMVs (F, S, Mp) run on a

@@ -37,9 +37,6 @@ struct CsrView {
 // mode 0: y = A x ; 1: y += A x ; 2: y = z - A x
 void spmv(hipStream_t s, const CsrView &A, int lanes_per_row, const double *x_own, const double *x_ghost, double *y,
           int mode, const double *z);
-// y_u = F x_u + Bt x_p in one pass (the (0,:) block row of jacobian_matrix.vmult)
-void spmv2(hipStream_t s, const CsrView &A, const double *xa_own, const double *xa_ghost, const CsrView &B,
-           const double *xb_own, const double *xb_ghost, double *y, int lanes_per_row);
 
 // LDS-staged "CSR-stream" SpMV: each 256-thread workgroup owns a run of whole rows holding at most
 // kStreamNnz non-zeros (rowblk[b]..rowblk[b+1]); it streams val/col fully coalesced, stages the
@@ -162,11 +159,9 @@ struct TriHalf {
   const double *val;
   const int4 *desc;  // per workgroup: {first row, end row, first nnz, end nnz} — one load instead of a chain
 };
-// permx = 1: w is an internal colour-ordered vector and M.col holds colour-order ids; the lower solve gathers
-// rhs through perm, the upper solve also scatters its result to out[perm[r]].
 // run_nnz: the non-zero cap the row runs in M.desc were built with (512, 1024 or 2048)
-void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx, int run_nnz,
-                      const double *dinv, const int *perm, const double *rhs, double *w, double *out);
+void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int run_nnz,
+                      const double *dinv, const int *perm, const double *rhs, double *w);
 
 // 2x2 node-block streamed level of a triangular solve (velocity block): node rows (two adjacent DoF rows) in node-colour order,
 // 2x2 blocks towards other nodes, and per node row intra = {l10, u01, 1/d0, 1/d1} for its own diagonal block.
@@ -199,18 +194,6 @@ void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int n_blocks, int lower, i
                       int wrong_order /* test hook */, const double *intra, const int *permn, const double *rhs,
                       const double *own, double *w, double *out, double *reset, int *err);
 
-// ---- window format (nsk_win.hpp): LDS-staged column tiles, 16-bit window positions, transposed value stream ----
-struct WinView {
-  const int4 *runs;            // two int4 per run: {r0, nrows, l0, nl}, {p0, q2, roff0, flags}
-  const int *lines;            // window line ids (16 doubles per line)
-  const unsigned short *roff;  // per run nrows + 1 entry offsets
-  const unsigned *pos;         // one dword per pair: two 16-bit window positions
-  const double *val;           // two doubles per pair
-};
-// y = A x (mode 0) | y += A x (1) | y = z - A x (2); x = [owned | ghost] as ONE contiguous, 128-byte aligned vector
-void spmv_win(hipStream_t s, const WinView &A, int n_runs, const double *x, double *y, int mode, const double *z);
-// y[i] = idx[i] >= 0 ? x[idx[i]] : 0   (values of the padded window slots)
-void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, double *y);
 
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,

@@ -73,31 +73,6 @@ __global__ __launch_bounds__(BLK) void spmv_kernel(CsrView A, const double *__re
   }
 }
 
-template <int LPR>
-__global__ __launch_bounds__(BLK) void spmv2_kernel(CsrView A, const double *__restrict__ xao,
-                                                    const double *__restrict__ xag, CsrView B,
-                                                    const double *__restrict__ xbo, const double *__restrict__ xbg,
-                                                    double *__restrict__ y) {
-  const long tid = (long)blockIdx.x * BLK + threadIdx.x;
-  const int row = (int)(tid / LPR);
-  const int lane = (int)(tid % LPR);
-  double s = 0.0;
-  if (row < A.n_rows) {
-    int re = A.rowptr[row + 1];
-    for (int k = A.rowptr[row] + lane; k < re; k += LPR) {
-      const int c = A.col[k];
-      s += A.val[k] * (c < A.n_own_cols ? xao[c] : xag[c - A.n_own_cols]);
-    }
-    re = B.rowptr[row + 1];
-    for (int k = B.rowptr[row] + lane; k < re; k += LPR) {
-      const int c = B.col[k];
-      s += B.val[k] * (c < B.n_own_cols ? xbo[c] : xbg[c - B.n_own_cols]);
-    }
-  }
-  s = subwave_sum<LPR>(s);
-  if (lane == 0 && row < A.n_rows) y[row] = s;
-}
-
 // ------------------------------------------------------------------ LDS-staged CSR-stream kernels
 // Workgroup = a run of whole rows with <= kStreamNnz non-zeros.  Phase 1 streams val/col with every
 // lane busy (no per-row divergence) and parks the products in LDS; phase 2 sums each row's slice
@@ -337,17 +312,11 @@ __global__ __launch_bounds__(BLK) void spmv_blk_fused_kernel(BlkView A, const do
 }
 
 // Streamed level of a triangular solve on split CSR halves (scalar factors): rows of the level are contiguous in the
-// permuted (colour) order, the solution vector and the column ids stay in the caller's numbering.
-// PERMX = 0: w is the caller-order vector x (i = perm[r]), column ids are caller-order ids.
-// PERMX = 1: w is an internal colour-ordered vector (i = r), column ids are colour-order ids; the lower
-//            solve gathers rhs through perm and the upper solve scatters the result to `out`.  A level
-//            then only touches the segments of the colours it depends on (fewer bytes per level), at
-//            the price of one cache line per gathered entry.
-template <int LOWER, int KIND, int PERMX, int NNZ>
+// permuted (colour) order, the solution vector w and the column ids stay in the caller's numbering (i = perm[r]).
+template <int LOWER, int KIND, int NNZ>
 __global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int nb, const double *__restrict__ dinv,
                                                          const int *__restrict__ perm,
-                                                         const double *__restrict__ rhs, double *__restrict__ w,
-                                                         double *__restrict__ out) {
+                                                         const double *__restrict__ rhs, double *__restrict__ w) {
   __shared__ double prod[NNZ];
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the k-th
   // contiguous eighth of the level's row runs.  Neighbouring rows then share one L2, and the same
@@ -359,14 +328,13 @@ __global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int 
   const int r0 = d.x, r1 = d.y, k0 = d.z, k1 = d.w;
   const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
   const bool have = r < r1;
-  int jb = 0, je = 0, i = 0, ip = 0;
+  int jb = 0, je = 0, i = 0;
   double own = 0.0, dv = 1.0;
   if (have) {
     jb = M.rowptr[r] - k0;
     je = M.rowptr[r + 1] - k0;
-    ip = perm[r];
-    i = PERMX ? r : ip;
-    own = LOWER ? rhs[ip] : w[i];  // w[i] of this level's own rows is not written by anyone else
+    i = perm[r];
+    own = LOWER ? rhs[i] : w[i];  // w[i] of this level's own rows is not written by anyone else
     if (KIND == 1 || !LOWER) dv = dinv[r];
   }
   // the factor is streamed once per apply: non-temporal loads keep it from evicting the lines the
@@ -397,7 +365,6 @@ __global__ __launch_bounds__(BLK) void tri_stream_kernel(TriHalf M, int b0, int 
     if (LOWER) v = KIND == 0 ? (own - sum) : (own - sum) * dv;
     else v = KIND == 0 ? (own - sum) * dv : own - sum * dv;
     w[i] = v;
-    if (PERMX && !LOWER) out[ip] = v;
   }
 }
 
@@ -496,7 +463,7 @@ __device__ __forceinline__ bool sf_keep_polling(int &spins, int *err) {
   if (spins > 1) __builtin_amdgcn_s_sleep(1);
   return true;
 }
-// re-poll one word until the producer's store is visible (window kernels)
+// re-poll one word until the producer's store is visible
 __device__ __forceinline__ double sf_wait(const double *p, unsigned long long first, int *err) {
   unsigned long long v = first;
   int spins = 0;
@@ -704,101 +671,6 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int w
     // arm the vector of the next launch (see tri_stream_sf_kernel)
     reinterpret_cast<unsigned long long *>(reset)[i] = kSentinel;
     reinterpret_cast<unsigned long long *>(reset)[i + 1] = kSentinel;
-  }
-}
-
-// ------------------------------------------------------------------ window format (nsk_win.hpp)
-// One workgroup per run: (1) stream the run's values and 16-bit window positions with 16-byte / 4-byte loads per
-// lane (transposed storage: every wave instruction reads contiguous memory), (2) copy the run's window lines of the
-// gathered vector into LDS with 16-byte loads, (3) products from LDS, (4) per-row sums with RG lanes.
-// Address-unit work per non-zero drops from {4 B load, 8 B load, 64-address gather} to ~1/3 of a wide load.
-constexpr int WQ = 4;       // pairs per thread (kWinMaxQ2)
-constexpr int WL = 160;     // window lines (kWinMaxLines)
-constexpr int WLD = (WL * 8 + BLK - 1) / BLK;  // 16-byte window chunks per thread
-
-typedef double dvec2 __attribute__((ext_vector_type(2)));
-struct WinRegs {            // the matrix stream of one run in flight
-  dvec2 v[WQ];
-  unsigned c[WQ];
-};
-__device__ __forceinline__ void win_issue(const WinView &M, int p0, int q2, WinRegs &R) {
-#pragma unroll
-  for (int j = 0; j < WQ; ++j) {
-    const bool ok = j < q2;   // uniform in the workgroup
-    const size_t pi = (size_t)p0 + (size_t)(ok ? j : 0) * BLK + threadIdx.x;
-    R.v[j] = ok ? __builtin_nontemporal_load(reinterpret_cast<const dvec2 *>(M.val) + pi) : dvec2{0.0, 0.0};
-    R.c[j] = ok ? __builtin_nontemporal_load(M.pos + pi) : 0u;
-  }
-}
-// window lines -> LDS (and the line ids, which the sentinel polls need)
-__device__ __forceinline__ void win_stage(const int *__restrict__ lines, int l0, int nl, const double *w, double *win,
-                                          int *s_lines) {
-  int ln[WLD];
-  double2 ch[WLD];
-#pragma unroll
-  for (int u = 0; u < WLD; ++u) {
-    const int k = (int)threadIdx.x + u * BLK;
-    ln[u] = k < nl * 8 ? lines[l0 + (k >> 3)] : -1;
-  }
-#pragma unroll
-  for (int u = 0; u < WLD; ++u) {
-    const int k = (int)threadIdx.x + u * BLK;
-    ch[u] = ln[u] >= 0 ? *reinterpret_cast<const double2 *>(w + (size_t)ln[u] * 16 + (size_t)(k & 7) * 2)
-                       : make_double2(0.0, 0.0);
-  }
-#pragma unroll
-  for (int u = 0; u < WLD; ++u) {
-    const int k = (int)threadIdx.x + u * BLK;
-    if (ln[u] >= 0) {
-      *reinterpret_cast<double2 *>(win + 2 * k) = ch[u];
-      if ((k & 7) == 0) s_lines[k >> 3] = ln[u];
-    }
-  }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(BLK) void spmv_win_kernel(WinView M, const double *__restrict__ x, double *__restrict__ y,
-                                                       const double *__restrict__ z) {
-  __shared__ double win[WL * 16];
-  __shared__ double prod[2 * WQ * BLK];
-  __shared__ int s_lines[WL];
-  const int4 d0 = M.runs[2 * blockIdx.x], d1 = M.runs[2 * blockIdx.x + 1];
-  const int r0 = d0.x, nrows = d0.y, l0 = d0.z, nl = d0.w, p0 = d1.x, q2 = d1.y, roff0 = d1.z;
-  WinRegs R;
-  win_issue(M, p0, q2, R);
-  win_stage(M.lines, l0, nl, x, win, s_lines);
-  __syncthreads();
-  const int e0 = (int)threadIdx.x * 2 * q2;
-#pragma unroll
-  for (int j = 0; j < WQ; ++j)
-    if (j < q2) {
-      prod[e0 + 2 * j] = R.v[j].x * win[R.c[j] & 0xffffu];
-      prod[e0 + 2 * j + 1] = R.v[j].y * win[R.c[j] >> 16];
-    }
-  __syncthreads();
-  constexpr int RGW = 8;  // lanes per row in the reduce phase
-  for (int rho = (int)threadIdx.x / RGW; rho < nrows; rho += BLK / RGW) {
-    const int lane = threadIdx.x % RGW;
-    const int jb = M.roff[roff0 + rho], je = M.roff[roff0 + rho + 1];
-    double sum = 0.0;
-    for (int k = jb + lane; k < je; k += RGW) sum += prod[k];
-    sum = subwave_sum<RGW>(sum);
-    if (lane == 0) {
-      const int r = r0 + rho;
-      if (MODE == 0) y[r] = sum;
-      else if (MODE == 1) y[r] = (z ? z[r] : y[r]) + sum;
-      else y[r] = z[r] - sum;
-    }
-  }
-}
-
-
-
-__global__ __launch_bounds__(BLK) void gather_or_zero_kernel(long n, const int *__restrict__ idx,
-                                                            const double *__restrict__ x, double *__restrict__ y) {
-  for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
-    const int k = idx[i];
-    y[i] = k >= 0 ? x[k] : 0.0;
   }
 }
 
@@ -1100,16 +972,6 @@ void spmv(hipStream_t s, const CsrView &A, int lpr, const double *xo, const doub
   }
 }
 
-void spmv2(hipStream_t s, const CsrView &A, const double *xao, const double *xag, const CsrView &B, const double *xbo,
-           const double *xbg, double *y, int lpr) {
-  const int L = lpr >= 32 ? 32 : (lpr >= 16 ? 16 : 8);
-  const int grid = (int)(((long)A.n_rows * L + BLK - 1) / BLK);
-  if (grid <= 0) return;
-  if (L == 32) hipLaunchKernelGGL((spmv2_kernel<32>), dim3(grid), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, y);
-  else if (L == 16) hipLaunchKernelGGL((spmv2_kernel<16>), dim3(grid), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, y);
-  else hipLaunchKernelGGL((spmv2_kernel<8>), dim3(grid), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, y);
-}
-
 void spmv_stream(hipStream_t s, const CsrView &A, const int *rowblk, int nblk, int even_rows, const double *xo,
                  const double *xg, double *y, int mode, const double *z) {
   if (nblk <= 0) return;
@@ -1160,25 +1022,20 @@ void spmv_blk_fused22_21(hipStream_t s, const BlkView &A, const double *xao, con
     hipLaunchKernelGGL(spmv_blk_fused_kernel, dim3(nblk), dim3(BLK), 0, s, A, xao, xag, B, xbo, xbg, rowblk, y);
 }
 
-void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int permx, int run_nnz,
-                      const double *dinv, const int *perm, const double *rhs, double *w, double *out) {
+void tri_stream_level(hipStream_t s, const TriHalf &M, int b0, int b1, int lower, int kind, int run_nnz,
+                      const double *dinv, const int *perm, const double *rhs, double *w) {
   const int nb = b1 - b0;
   if (nb <= 0) return;
   const int grid = ((nb + 7) / 8) * 8;
-#define NSK_TS(L, K, P, N) hipLaunchKernelGGL((tri_stream_kernel<L, K, P, N>), dim3(grid), dim3(BLK), 0, s, M, b0, nb, dinv, perm, rhs, w, out)
-#define NSK_TSN(L, K, P)                                            \
-  do {                                                              \
-    if (run_nnz <= 512) NSK_TS(L, K, P, 512);                       \
-    else if (run_nnz <= 1024) NSK_TS(L, K, P, 1024);                \
-    else NSK_TS(L, K, P, 2048);                                     \
+#define NSK_TS(L, K, N) hipLaunchKernelGGL((tri_stream_kernel<L, K, N>), dim3(grid), dim3(BLK), 0, s, M, b0, nb, dinv, perm, rhs, w)
+#define NSK_TSN(L, K)                                            \
+  do {                                                           \
+    if (run_nnz <= 512) NSK_TS(L, K, 512);                       \
+    else if (run_nnz <= 1024) NSK_TS(L, K, 1024);                \
+    else NSK_TS(L, K, 2048);                                     \
   } while (0)
-  if (permx) {
-    if (lower) { if (kind == 0) NSK_TSN(1, 0, 1); else NSK_TSN(1, 1, 1); }
-    else { if (kind == 0) NSK_TSN(0, 0, 1); else NSK_TSN(0, 1, 1); }
-  } else {
-    if (lower) { if (kind == 0) NSK_TSN(1, 0, 0); else NSK_TSN(1, 1, 0); }
-    else { if (kind == 0) NSK_TSN(0, 0, 0); else NSK_TSN(0, 1, 0); }
-  }
+  if (lower) { if (kind == 0) NSK_TSN(1, 0); else NSK_TSN(1, 1); }
+  else { if (kind == 0) NSK_TSN(0, 0); else NSK_TSN(0, 1); }
 #undef NSK_TSN
 #undef NSK_TS
 }
@@ -1288,17 +1145,6 @@ void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int nb, int lower, int kin
     else { if (kind == 0) NSK_SB(0, 0, 0); else NSK_SB(0, 1, 0); }
   }
 #undef NSK_SB
-}
-void spmv_win(hipStream_t s, const WinView &A, int n_runs, const double *x, double *y, int mode, const double *z) {
-  if (n_runs <= 0) return;
-  if (mode == 0) hipLaunchKernelGGL((spmv_win_kernel<0>), dim3(n_runs), dim3(BLK), 0, s, A, x, y, z);
-  else if (mode == 1) hipLaunchKernelGGL((spmv_win_kernel<1>), dim3(n_runs), dim3(BLK), 0, s, A, x, y, z);
-  else hipLaunchKernelGGL((spmv_win_kernel<2>), dim3(n_runs), dim3(BLK), 0, s, A, x, y, z);
-}
-void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, double *y) {
-  if (n <= 0) return;
-  const int grid = (int)std::min<long>(65535 * 8, (n + BLK * 4 - 1) / (BLK * 4));
-  hipLaunchKernelGGL(gather_or_zero_kernel, dim3(grid), dim3(BLK), 0, s, n, idx, x, y);
 }
 void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra) {
   const int n = n_nodes;
@@ -1447,9 +1293,10 @@ __global__ __launch_bounds__(kMgsThreads) void mgs_sweep_kernel(MgsArgs A) {
     const unsigned i = base + e * stride;
     if (i < n) A.aux[i] = a[e];
   }
-  // a wait that gave up (workgroup 0 polls every other workgroup's word, so it notices): the caller must not use the sums
+  // a wait that gave up in ANY workgroup: the caller must not use the sums.  The launcher zeroes the flag before the
+  // launch; every workgroup with a dead wait raises it (the same value from whoever gives up: no race that matters).
   const int gave_up = __syncthreads_or(dead ? 1 : 0);
-  if (blockIdx.x == 0 && t == 0) A.out[A.nv + 2] = gave_up ? 1.0 : 0.0;
+  if (gave_up && t == 0) A.out[A.nv + 2] = 1.0;
 }
 
 bool mgs_sweep(hipStream_t s, const MgsArgs &A, int G) {

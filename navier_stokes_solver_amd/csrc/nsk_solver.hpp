@@ -267,8 +267,7 @@ struct SolverFGMRES : SolverBase {
         if (mgs_flag >= 0 && h[j + 3] != 0.0) {
           // a wait of the one-launch sweep gave up (its workgroups were not co-resident: another process on the GPU?):
           // w = A z_j is formed again and orthogonalised link by link; the sweep stays off for this handle
-          ctx.fused_mgs = false;
-          ++ctx.mgs_fallbacks;
+          ctx.mgs_timed_out();
           A(zj, aux.own);
           ctx.dot(n, aux.own, v[0], HS);
           for (int i = 1; i <= j; ++i)
@@ -300,10 +299,11 @@ struct SolverGMRES : SolverBase {
   void solve(const MatVec &A, DVec &x, const DVec &b, const PrecVmult &P) {
     std::vector<double *> tmp(kTmp, nullptr);
     const int sl = ctx.alloc_slots(kTmp + 8);
+    double *keep = nullptr;
     struct Release {
-      SolverGMRES &S; std::vector<double *> &t; int sl;
-      ~Release() { for (double *p : t) if (p) S.pool.put(p); S.ctx.slot_top = sl; }
-    } rel{*this, tmp, sl};
+      SolverGMRES &S; std::vector<double *> &t; double *&keep; int sl;
+      ~Release() { for (double *p : t) if (p) S.pool.put(p); if (keep) S.pool.put(keep); S.ctx.slot_top = sl; }
+    } rel{*this, tmp, keep, sl};
     const int RS = sl, NS = sl + 2, HS = sl + 4;
     double Hm[kTmp * (kTmp - 1)], gamma[kTmp], ci[kTmp - 1], si[kTmp - 1], h[kTmp];
     int accumulated = 0;
@@ -313,6 +313,26 @@ struct SolverGMRES : SolverBase {
     tmp[kTmp - 1] = pool.get(true);
     DVec v = pool.view(tmp[0]), p = pool.view(tmp[kTmp - 1]);
     double rho = 0.0;
+    // Modified Gram-Schmidt of w against tmp[0 .. dim): slots HS + i = h_i, HS + dim = |w|^2, HS + dim + 1 = |w|;
+    // returns the host copy of slots NS ... (NS + 1 = the norm before, when it was asked for).  One launch when the
+    // vector fits the co-resident grid (Ctx::mgs_sweep).  The left preconditioner may carry state (aSIMPLE's stale
+    // delta_p), so w = P A v cannot be formed a second time: a copy of w is kept, and a sweep whose wait ran out is
+    // redone link by link from it.
+    auto mgs = [&](DVec &w, int dim) -> const double * {
+      if (ctx.mgs_applicable(n, dim)) {
+        if (!keep) keep = pool.get(false);
+        vec_copy(s(), n, w.own, keep);
+        ctx.mgs_sweep(n, w.own, tmp.data(), dim, HS);
+        const double *hh = ctx.read_slots(NS, 2 + dim + 3);
+        if (hh[2 + dim + 2] == 0.0) return hh;
+        ctx.mgs_timed_out();
+        vec_copy(s(), n, keep, w.own);
+      }
+      ctx.dot(n, w.own, tmp[0], HS);
+      for (int i = 1; i < dim; ++i) ctx.axpy_dot(n, sref(-1.0, ctx.slot(HS + i - 1)), tmp[i - 1], w.own, tmp[i], HS + i);
+      ctx.axpy_norm2(n, sref(-1.0, ctx.slot(HS + dim - 1)), tmp[dim - 1], w.own, HS + dim);
+      return ctx.read_slots(NS, 2 + dim + 2);
+    };
     do {
       std::fill(h, h + kTmp, 0.0);
       A(x, p.own);
@@ -334,27 +354,13 @@ struct SolverGMRES : SolverBase {
         dim = inner + 1;
         const bool consider = !re_orth && (inner % 5 == 4);
         if (consider) ctx.norm2(n, vv.own, NS);
-        const bool one_launch = ctx.mgs_sweep(n, vv.own, tmp.data(), dim, HS);
-        if (!one_launch) {
-          ctx.dot(n, vv.own, tmp[0], HS);
-          for (int i = 1; i < dim; ++i) ctx.axpy_dot(n, sref(-1.0, ctx.slot(HS + i - 1)), tmp[i - 1], vv.own, tmp[i], HS + i);
-          ctx.axpy_norm2(n, sref(-1.0, ctx.slot(HS + dim - 1)), tmp[dim - 1], vv.own, HS + dim);
-        }
-        const double *hh = ctx.read_slots(NS, 2 + dim + 3);
-        if (one_launch && hh[2 + dim + 2] != 0.0) throw Error(-71, "one-launch Gram-Schmidt sweep timed out (workgroups not co-resident?)");
+        const double *hh = mgs(vv, dim);
         const double norm_start = hh[1];
         for (int i = 0; i < dim; ++i) h[i] = hh[2 + i];
         double snorm = hh[2 + dim + 1];
         if (consider && !(snorm > 10.0 * norm_start * std::sqrt(std::numeric_limits<double>::epsilon()))) re_orth = true;
         if (re_orth) {
-          const bool again = ctx.mgs_sweep(n, vv.own, tmp.data(), dim, HS);
-          if (!again) {
-            ctx.dot(n, vv.own, tmp[0], HS);
-            for (int i = 1; i < dim; ++i) ctx.axpy_dot(n, sref(-1.0, ctx.slot(HS + i - 1)), tmp[i - 1], vv.own, tmp[i], HS + i);
-            ctx.axpy_norm2(n, sref(-1.0, ctx.slot(HS + dim - 1)), tmp[dim - 1], vv.own, HS + dim);
-          }
-          const double *h2 = ctx.read_slots(HS, dim + 3);
-          if (again && h2[dim + 2] != 0.0) throw Error(-71, "one-launch Gram-Schmidt sweep timed out (workgroups not co-resident?)");
+          const double *h2 = mgs(vv, dim) + 2;
           for (int i = 0; i < dim; ++i) h[i] += h2[i];
           snorm = h2[dim + 1];
         }

@@ -491,8 +491,8 @@ void TriSolve::apply(const double *b, double *x) {
   if (stream_ready && use_stream && !tiny) {
     // x doubles as the intermediate vector: rows not yet solved hold L^-1 b, solved rows hold the result
     const TriHalf L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
-    for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, 0, kStreamNnz, dinv.p, d_perm.p, b, x, nullptr);
-    for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, 0, kStreamNnz, dinv.p, d_perm.p, nullptr, x, nullptr);
+    for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, kStreamNnz, dinv.p, d_perm.p, b, x);
+    for (int c = n_colors - 1; c >= 0; --c) tri_stream_level(s, U, UB[c], UB[c + 1], 0, kind, kStreamNnz, dinv.p, d_perm.p, nullptr, x);
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
     return;

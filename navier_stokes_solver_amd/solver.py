@@ -29,7 +29,7 @@ OPT_TRI_SYNC_FREE = 9
 OPT_VELOCITY_AMG = 10
 OPT_CG_SINGLE_REDUCTION = 11
 # not part of the public ABI (csrc/nsk_internal.h): study switches and the fault-injection hook of the tests
-IOPT_TRI_X_LAYOUT, IOPT_FAULT_INJECT, IOPT_WINDOW_SPMV, IOPT_TINY_BYTES = 6, 100, 101, 102
+IOPT_TRI_X_LAYOUT, IOPT_FAULT_INJECT, IOPT_TINY_BYTES = 6, 100, 102
 IOPT_FUSED_MGS, IOPT_OVERLAP_HALO = 106, 107
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
 
@@ -183,6 +183,10 @@ class LinearSolver:
             self.close()
         except Exception:
             pass
+
+    def last_error(self) -> str:
+        """Text of the last error — or of the last warning (a fallback that costs speed, not results)."""
+        return self.L.nsk_last_error(self.h).decode()
 
     def _ck(self, rc, allow=()):
         if rc < 0 or (rc > 0 and rc not in allow):

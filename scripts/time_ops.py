@@ -12,7 +12,6 @@ ap.add_argument("--prec", type=int, default=2)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--xlayout", type=int, default=2)
 ap.add_argument("--syncfree", type=int, default=2)
-ap.add_argument("--win-spmv", type=int, default=0)
 a = ap.parse_args()
 nx, ny = (int(v) for v in a.mesh.split(","))
 pr = P.generate(nx, ny, nu=1 / 90.0)
@@ -21,7 +20,6 @@ ls.set_option(S.OPT_TRI_ORDERING, a.ordering)
 ls.set_option(S.OPT_STREAM_KERNELS, a.stream)
 ls.set_option(S.IOPT_TRI_X_LAYOUT, a.xlayout)
 ls.set_option(S.OPT_TRI_SYNC_FREE, a.syncfree)
-ls.set_option(S.IOPT_WINDOW_SPMV, a.win_spmv)
 ls.set_problem(pr)
 t0 = time.time(); ls.setup_preconditioner(a.prec, 0, 0.5); t1 = time.time()
 ls.setup_preconditioner(a.prec, 0, 0.5); t2 = time.time()
