@@ -39,6 +39,27 @@ NAMES_S = ["GMRES", "FGMRES", "Bicgstab"]
 NAMES_P = ["blockDiagonal", "blockTriangular", "aSIMPLE"]
 
 
+_T0 = time.time()
+_PHASE = ["start"]
+
+
+def say(msg):
+    """Progress line on stderr (rank 0 of a multi-rank run prints too little otherwise: a silent run looks hung)."""
+    _PHASE[0] = msg
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def start_pulse(period=60.0):
+    """One line per minute while a long host-side phase (hand-off generation, symbolic analysis) runs."""
+    def run():
+        while True:
+            time.sleep(period)
+            if int(os.environ.get("RANK", "0")) == 0:
+                print(f"[bench {time.time() - _T0:7.1f}s] ... still in: {_PHASE[0]}", file=sys.stderr, flush=True)
+    threading.Thread(target=run, daemon=True).start()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +67,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mesh", type=str, default="", help="X,Y: per-GPU mesh (weak) or global mesh (strong); default per --scaling")
     ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto")
+    ap.add_argument("--lx", type=float, default=2.2,
+                    help="channel length of the generated mesh (default: the reference's 2.2).  --mesh 600,1600 --lx 0.275 is "
+                         "ONE RANK'S SHARE of BASELINE configs[3] (4800x1600 on 8 ranks) as a channel of its own: same cells, "
+                         "same lattice height, same sizes per rank; 600x1600 on the whole channel would stretch the cells 8x")
     ap.add_argument("--reynolds", type=float, default=0.0, help="default: 100 (N = 1, weak) / 200 (strong: configs[3])")
     ap.add_argument("--solver", type=int, default=1)
     ap.add_argument("--preconditioner", type=int, default=2)
@@ -88,12 +113,14 @@ def choose_workload(world, scaling="auto", mesh="", reynolds=0.0):
     return scaling, nx, my, reynolds
 
 
-def make_solver(S, PT, P, dist, args, nx, ny, nu, inv_dt, world, rank, local_rank):
+def make_solver(S, PT, P, dist, args, nx, ny, nu, inv_dt, world, rank, local_rank, lx=2.2):
     """Generate this rank's hand-off, create the handle, upload.  Returns (ls, pr, n_global, t_gen, t_upload)."""
     t0 = time.time()
+    say(f"generating the hand-off of {nx}x{ny} (rank {rank} of {world}) on the host")
     pr = P.generate(nx, ny, nu=nu, mode=1, state=1, inv_dt=inv_dt, U=0.1 if args.variant == 0 else 0.3,
-                    nranks=world, rank=rank)
+                    nranks=world, rank=rank, lx=lx)
     t_gen = time.time() - t0
+    say(f"hand-off ready ({t_gen:.1f} s): n_u {pr.n_u}, n_p {pr.n_p}, nnz(F) {pr.F.nnz}; uploading blocks")
     n_global = int(pr.info["n_u_global"] + pr.info["n_p_global"])
     uid, plan = None, None
     if world > 1:
@@ -113,6 +140,7 @@ def make_solver(S, PT, P, dist, args, nx, ny, nu, inv_dt, world, rank, local_ran
     ls.set_option(S.OPT_INNER_FUSED_GS, int(args.inner_gs if args.inner_gs >= 0 else (2 if world > 1 else 1)))
     t0 = time.time()
     ls.set_problem(pr, plan)
+    say(f"blocks on the device ({time.time() - t0:.1f} s)")
     return ls, pr, n_global, t_gen, time.time() - t0
 
 
@@ -258,13 +286,18 @@ def main():
             dist.barrier()
 
     sync = torch.cuda.synchronize
-    ls, pr, n_global, t_gen, t_upload = make_solver(S, PT, P, dist, args, nx, ny, nu, inv_dt, world, rank, local_rank)
+    start_pulse()
+    ls, pr, n_global, t_gen, t_upload = make_solver(S, PT, P, dist, args, nx, ny, nu, inv_dt, world, rank, local_rank,
+                                                    lx=args.lx)
     t0 = time.time()
+    say("first preconditioner set-up (symbolic analysis on the host + numeric phase on the device)")
     ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
     t_setup_first = time.time() - t0     # includes the one-off symbolic analysis
     t0 = time.time()
+    say(f"first set-up done ({t_setup_first:.1f} s); numeric set-up again")
     ls.setup_preconditioner(args.preconditioner, args.variant, 0.5)
     t_setup = time.time() - t0           # numeric refactorisation only (what every Newton step pays)
+    say(f"numeric set-up {t_setup:.2f} s; warm-up of {max(1, args.warmup)} outer iterations")
 
     aS = args.preconditioner == 2
     ops = (20, 0, 21) + ((5,) if aS else (3,))
@@ -277,6 +310,7 @@ def main():
     ls.reset_stats()
     for op in ops:
         ls.profile_begin(op, 1024)
+    say(f"timed region: {args.steps} outer iterations")
     barrier()
     sync()
     t0 = time.perf_counter()
@@ -284,6 +318,7 @@ def main():
     sync()
     barrier()
     dt = time.perf_counter() - t0
+    say(f"timed region done: {dt:.2f} s")
     prof = {op: ls.profile_read(op) for op in ops}
     ls.profile_end()
     if world > 1:
@@ -357,7 +392,8 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{'stationary' if args.variant == 0 else 'unsteady (dt=0.01)'} {nx}x{ny} Q3/Q2, "
+                "workload": f"{'stationary' if args.variant == 0 else 'unsteady (dt=0.01)'} {nx}x{ny} Q3/Q2"
+                            f"{'' if args.lx == 2.2 else f' on the leading {args.lx:g} of the 2.2 x 0.41 channel'}, "
                             f"Re={args.reynolds:g} (nu=1/{1 / nu:g}) Newton system, "
                             f"solver {NAMES_S[args.solver]} + {NAMES_P[args.preconditioner]}",
                 "K": args.steps, "restart": 30, "tolerance": 0.0,

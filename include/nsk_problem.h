@@ -59,6 +59,10 @@ typedef struct {
 
 /* Build lattice, DoF numbering and the x-strip partition.  Returns NULL on bad arguments. */
 nsp_mesh *nsp_mesh_create(int32_t nx, int32_t ny, int32_t nranks, int32_t rank);
+/* The same on the leading piece [0, lx] x [0, 0.41] of the channel (0.25 < lx <= 2.2; outlet at x = lx): a mesh of
+ * nx = 4800/8 cell columns on lx = 2.2/8 has the cells, the lattice height and the per-rank sizes of one rank's strip of
+ * the 4800 x 1600 mesh (BASELINE configs[3]) — nx x ny on the whole channel would stretch the cells eight times. */
+nsp_mesh *nsp_mesh_create_lx(int32_t nx, int32_t ny, int32_t nranks, int32_t rank, double lx);
 void nsp_mesh_destroy(nsp_mesh *m);
 void nsp_mesh_info(const nsp_mesh *m, nsp_info *out);
 

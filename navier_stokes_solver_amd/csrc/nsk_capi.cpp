@@ -27,6 +27,19 @@ namespace {
 double wall_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+// NSK_VERBOSE=1: one stderr line per host-side phase of a hand-off / set-up (where the seconds of a large mesh go)
+bool verbose() {
+  static const bool v = getenv("NSK_VERBOSE") && atoi(getenv("NSK_VERBOSE")) > 0;
+  return v;
+}
+struct Phase {
+  const char *name;
+  double t0;
+  explicit Phase(const char *n) : name(n), t0(wall_ms()) {}
+  ~Phase() {
+    if (verbose()) fprintf(stderr, "[nsk] %-34s %9.1f ms\n", name, wall_ms() - t0);
+  }
+};
 }  // namespace
 
 // HIP-event sampler: brackets launches of up to four operation classes inside a running solve
@@ -389,15 +402,23 @@ void H::setup(int type, int variant_, double alpha_) {
   } else {
     amgF.clear();
     if (!tF_ok || tF_key != key) {
+      Phase ph("analyse F factor (host)");
       tF.analyze(&ctx, F, kindF, tri_ordering, sub_offsets(0), use_bsr && F.blk_ok && F.blk_R == 2 && F.blk_C == 2);
       tF_ok = true;
       tF_key = key;
     }
     tF.kind = kindF;
-    tF.numeric(F.val.p);
+    {
+      Phase ph("factorise F (device)");
+      tF.numeric(F.val.p);
+      if (verbose()) ctx.sync();
+    }
   }
   if (type == 2) {
-    if (!s_symbolic) schur_symbolic();
+    if (!s_symbolic) {
+      Phase ph("Schur pattern (host)");
+      schur_symbolic();
+    }
     if (!D) { D = pool_u.get(true); Dinv = pool_u.get(true); tmp_u = pool_u.get(true); }
     if (!tmp_p) tmp_p = pool_p.get(true);
     if (!delta_p) delta_p = pool_p.get(true);
@@ -409,6 +430,7 @@ void H::setup(int type, int variant_, double alpha_) {
     spgemm_bdbt_numeric(s(), B.view(), Dinv, Dinv + n_u(), Bt.view(), Btg.present ? Btg.view() : Bt.view(), S.rowptr.p,
                         S.col.p, S.val.p, S.n_rows, std::max(1, s_max_row));
     if (!tS_ok || tS_key != key) {
+      Phase ph("analyse S factor (host)");
       tS.analyze(&ctx, S, 0, tri_ordering, sub_offsets(1));
       tS_ok = true;
       tS_key = key;
@@ -626,7 +648,13 @@ int nsk_get_unique_id(void *out128) {
 
 int nsk_local_group_id(int nranks, void *out128) {
   if (nranks < 1 || !out128) return -1;
-  make_local_group(nranks, out128);
+  make_local_group(nranks, out128, 0);
+  return 0;
+}
+
+int nsk_local_group_id_mode(int nranks, int on_stream, void *out128) {   // nsk_internal.h
+  if (nranks < 1 || !out128) return -1;
+  make_local_group(nranks, out128, on_stream);
   return 0;
 }
 
@@ -645,7 +673,7 @@ nsk_handle nsk_create(int rank, int nranks, int device_id, const void *uid) {
   try {
     h->ctx.init(device_id);
     h->ctx.warn_text = &h->err;
-    h->ctx.comm.init(rank, nranks, uid);
+    h->ctx.comm.init(rank, nranks, uid, device_id);
 
   } catch (const std::exception &e) {
     fprintf(stderr, "nsk_create: %s\n", e.what());
@@ -719,6 +747,7 @@ int nsk_set_block_csr(nsk_handle h, int b, int n_rows, int n_cols, const int32_t
   for (int64_t k = 0; k < nnz; ++k)
     if (col[k] < 0 || col[k] >= n_cols) throw Error(-59, "nsk_set_block_csr: column id out of range");
   Csr &A = h->blk[b];
+  Phase ph("hand-off of one block");
   A.n_rows = n_rows;
   A.n_cols = n_cols;
   A.n_own_cols = Cc.n;

@@ -28,6 +28,7 @@ struct LocalGroup {
   std::vector<Comm *> members;
   std::vector<double> scratch;  // n * kCap
   static constexpr int kCap = 64;
+  bool on_stream = false;
   void barrier() {
     std::unique_lock<std::mutex> lk(m);
     const long gen = generation;
@@ -47,10 +48,11 @@ int g_next_group = 1;
 constexpr char kLocalMagic[8] = {'N', 'S', 'K', 'L', 'O', 'C', 'A', 'L'};
 }  // namespace
 
-int make_local_group(int nranks, void *out128) {
+int make_local_group(int nranks, void *out128, int on_stream) {
   std::lock_guard<std::mutex> lk(g_groups_mutex);
   auto g = std::make_shared<LocalGroup>();
   g->n = nranks;
+  g->on_stream = on_stream != 0;
   g->members.assign(nranks, nullptr);
   g->scratch.assign((size_t)nranks * LocalGroup::kCap, 0.0);
   const int id = g_next_group++;
@@ -62,9 +64,10 @@ int make_local_group(int nranks, void *out128) {
   return id;
 }
 
-void Comm::init(int rank_, int nranks_, const void *unique_id) {
+void Comm::init(int rank_, int nranks_, const void *unique_id, int device_id) {
   rank = rank_;
   nranks = nranks_;
+  device = device_id;
   comm = nullptr;
   local = nullptr;
   if (nranks <= 1 && !unique_id) return;  // a one-rank run with an id still goes through RCCL (self-test of the transport)
@@ -83,6 +86,19 @@ void Comm::init(int rank_, int nranks_, const void *unique_id) {
     local = g.get();
     local->members[rank] = this;
     NSK_HIP(hipHostMalloc((void **)&h_tmp, sizeof(double) * LocalGroup::kCap, hipHostMallocDefault));
+    if (local->on_stream) {
+      if (nranks > kLocalSumMax) throw Error(-22, "local group, on-stream mode: too many ranks");
+      for (int k = 0; k < 2; ++k) {
+        ar_stage[k].alloc(LocalGroup::kCap);
+        NSK_HIP(hipEventCreateWithFlags(&ar_ready[k], hipEventDisableTiming));
+        NSK_HIP(hipEventCreateWithFlags(&ar_done[k], hipEventDisableTiming));
+      }
+    }
+    local->barrier();
+    // the summing kernel reads the peers' staging buffers directly: one device for the whole group, else host-staged
+    bool same = true;
+    for (int r = 0; r < nranks; ++r) same = same && local->members[r]->device == device;
+    on_stream = local->on_stream && same;
     local->barrier();
     return;
   }
@@ -97,6 +113,12 @@ void Comm::init(int rank_, int nranks_, const void *unique_id) {
 void Comm::destroy() {
   if (comm) ncclCommDestroy((ncclComm_t)comm);
   comm = nullptr;
+  for (int k = 0; k < 2; ++k) {
+    if (ar_ready[k]) (void)hipEventDestroy(ar_ready[k]);
+    if (ar_done[k]) (void)hipEventDestroy(ar_done[k]);
+    ar_ready[k] = ar_done[k] = nullptr;
+    ar_stage[k].release();
+  }
   if (h_tmp) (void)hipHostFree(h_tmp);
   h_tmp = nullptr;
   local = nullptr;
@@ -104,6 +126,30 @@ void Comm::destroy() {
 
 void Comm::allreduce_sum(double *d, int count, hipStream_t s) {
   if (nranks <= 1 && !comm) return;
+  if (local && on_stream) {
+    // No host synchronisation of the streams: every rank copies its values into a staging buffer of its own, the host
+    // threads rendezvous (so that the events below exist in program order), each stream then waits for the peers'
+    // "staged" events and sums all staging buffers in rank order (same bits on every rank) into its own slots.
+    // Two staging buffers in turn: a rank overwrites buffer p only after the peers' sums of two calls ago have run.
+    if (count > LocalGroup::kCap) throw Error(-23, "local allreduce: too many values");
+    const int p = (int)(ar_seq & 1);
+    if (ar_seq >= 2)
+      for (int r = 0; r < nranks; ++r)
+        if (r != rank) NSK_HIP(hipStreamWaitEvent(s, local->members[r]->ar_done[p], 0));
+    ++ar_seq;
+    NSK_HIP(hipMemcpyAsync(ar_stage[p].p, d, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, s));
+    NSK_HIP(hipEventRecord(ar_ready[p], s));
+    local->barrier();
+    LocalSumArgs A{};
+    A.n = nranks;
+    for (int r = 0; r < nranks; ++r) {
+      if (r != rank) NSK_HIP(hipStreamWaitEvent(s, local->members[r]->ar_ready[p], 0));
+      A.src[r] = local->members[r]->ar_stage[p].p;
+    }
+    local_sum(s, count, A, d);
+    NSK_HIP(hipEventRecord(ar_done[p], s));
+    return;
+  }
   if (local) {
     if (count > LocalGroup::kCap) throw Error(-23, "local allreduce: too many values");
     NSK_HIP(hipMemcpyAsync(h_tmp, d, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
@@ -125,8 +171,72 @@ void Comm::allreduce_sum(double *d, int count, hipStream_t s) {
 
 // SpMV ghost import (Epetra_Import equivalent): pack owned boundary entries, grouped
 // send/recv with each strip neighbour, ghosts land directly in the vector's ghost tail.
+// Local group, on-stream mode: the ghost import(s) of `count` spaces in one rendezvous.  Per space and rank two send
+// buffers used in turn and two pairs of events: ready[p] (my pack into buf[p] has been enqueued) and done[p] (my copies
+// out of the neighbours' buf[p] have been enqueued).  A stream waits for the neighbours' ready events before it copies
+// and, two exchanges later, for their done events before it packs into the same buffer again — the ordering an
+// ncclSend / ncclRecv pair gives, without ever synchronising a stream with the host.  The host threads rendezvous once
+// per exchange so that every event a stream is told to wait for has been recorded (in host program order) before.
+void Comm::local_exchange_on_stream(Space *const *sps, const DVec *xs, int count, hipStream_t s) {
+  const int slot = (int)(coll_seq & 1);
+  ++coll_seq;
+  Pub &mine = pub[slot];
+  for (int q = 0; q < 2; ++q) mine.x[q] = nullptr;
+  for (int q = 0; q < count; ++q) {
+    Space &sp = *sps[q];
+    if (!sp.lx) {
+      sp.lx.reset(new LocalXchg());
+      for (int k = 0; k < 2; ++k) {
+        sp.lx->buf[k].alloc((size_t)std::max(1, sp.n_send));
+        NSK_HIP(hipEventCreateWithFlags(&sp.lx->ready[k], hipEventDisableTiming));
+        NSK_HIP(hipEventCreateWithFlags(&sp.lx->done[k], hipEventDisableTiming));
+      }
+      sp.lx->peer.assign(sp.peers.size(), nullptr);
+    }
+    LocalXchg &X = *sp.lx;
+    const int p = (int)(X.seq & 1);
+    if (X.seq >= 2)
+      for (size_t k = 0; k < sp.peers.size(); ++k)
+        if (X.peer[k] && sp.send_ptr[k + 1] > sp.send_ptr[k]) NSK_HIP(hipStreamWaitEvent(s, X.peer[k]->done[p], 0));
+    ++X.seq;
+    if (sp.n_send > 0) halo_pack(s, sp.n_send, sp.d_send_idx.p, xs[q].own, X.buf[p].p);
+    NSK_HIP(hipEventRecord(X.ready[p], s));
+    mine.x[q] = &X;
+    mine.peers[q] = &sp.peers;
+    mine.send_ptr[q] = &sp.send_ptr;
+    mine.parity[q] = p;
+  }
+  local->barrier();
+  for (int q = 0; q < count; ++q) {
+    Space &sp = *sps[q];
+    LocalXchg &X = *sp.lx;
+    for (size_t k = 0; k < sp.peers.size(); ++k) {
+      const Pub &theirs = local->members[sp.peers[k]]->pub[slot];
+      if (!theirs.x[q]) throw Error(-24, "local halo exchange: the ranks are not in the same exchange");
+      X.peer[k] = theirs.x[q];
+      const int nr = sp.recv_ptr[k + 1] - sp.recv_ptr[k];
+      if (nr <= 0) continue;
+      int idx = -1;
+      for (size_t j = 0; j < theirs.peers[q]->size(); ++j)
+        if ((*theirs.peers[q])[j] == rank) idx = (int)j;
+      if (idx < 0 || (*theirs.send_ptr[q])[idx + 1] - (*theirs.send_ptr[q])[idx] != nr)
+        throw Error(-24, "local halo exchange: plans of the two ranks do not match");
+      const int pp = theirs.parity[q];
+      NSK_HIP(hipStreamWaitEvent(s, theirs.x[q]->ready[pp], 0));
+      NSK_HIP(hipMemcpyAsync(xs[q].ghost + sp.recv_ptr[k], theirs.x[q]->buf[pp].p + (*theirs.send_ptr[q])[idx],
+                             sizeof(double) * (size_t)nr, hipMemcpyDeviceToDevice, s));
+    }
+    NSK_HIP(hipEventRecord(X.done[mine.parity[q]], s));
+  }
+}
+
 void Comm::halo_exchange(Space &sp, const DVec &x, hipStream_t s) {
   if (nranks <= 1) return;
+  if (local && on_stream) {
+    Space *sps[1] = {&sp};
+    local_exchange_on_stream(sps, &x, 1, s);
+    return;
+  }
   if (local) {
     // every rank of the group enters, also one without neighbours in this space
     if (sp.n_send > 0) halo_pack(s, sp.n_send, sp.d_send_idx.p, x.own, sp.d_send_buf.p);
@@ -169,7 +279,13 @@ void Comm::halo_exchange(Space &sp, const DVec &x, hipStream_t s) {
 // launch-side round trip instead of two; the pack kernels of both spaces run before the group.
 void Comm::halo_exchange2(Space &sa, const DVec &xa, Space &sb, const DVec &xb, hipStream_t s) {
   if (nranks <= 1) return;
-  if (local) {   // in-process test transport: no grouping to gain
+  if (local && on_stream) {   // both spaces in one rendezvous, like the one RCCL group below
+    Space *sps[2] = {&sa, &sb};
+    const DVec xs[2] = {xa, xb};
+    local_exchange_on_stream(sps, xs, 2, s);
+    return;
+  }
+  if (local) {   // in-process test transport, host-staged: no grouping to gain
     halo_exchange(sa, xa, s);
     halo_exchange(sb, xb, s);
     return;

@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -67,6 +68,20 @@ struct DBuf {  // owning device buffer
   void upload(const std::vector<T> &h, hipStream_t s) { upload(h.data(), h.size(), s); }
 };
 
+// Local-group transport, on-stream mode: send buffers and events of one space (see Comm::local_exchange_on_stream)
+struct LocalXchg {
+  DBuf<double> buf[2];                   // packed owned entries, used in turn
+  hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+  long seq = 0;                          // exchanges of this space so far
+  std::vector<const LocalXchg *> peer;   // the neighbours' objects for this space, known after the first exchange
+  ~LocalXchg() {
+    for (int k = 0; k < 2; ++k) {
+      if (ready[k]) (void)hipEventDestroy(ready[k]);
+      if (done[k]) (void)hipEventDestroy(done[k]);
+    }
+  }
+};
+
 // index space (velocity or pressure DoFs of this rank)
 struct Space {
   int n = 0;   // owned
@@ -78,6 +93,7 @@ struct Space {
   DBuf<int> d_send_idx;
   DBuf<double> d_send_buf;
   int n_send = 0;
+  std::unique_ptr<LocalXchg> lx;
 };
 
 // view of a vector on one space: owned part and ghost tail
@@ -156,16 +172,31 @@ struct Comm {
   const double *pub_buf = nullptr;
   const std::vector<int> *pub_peers = nullptr, *pub_send_ptr = nullptr;
   double *h_tmp = nullptr;
+  // on-stream mode of the local group (no host synchronisation of the streams: events order the ranks' streams)
+  bool on_stream = false;
+  int device = 0;
+  struct Pub {   // what a rank offers in collective number c (slot c & 1)
+    const LocalXchg *x[2] = {nullptr, nullptr};
+    const std::vector<int> *peers[2] = {nullptr, nullptr}, *send_ptr[2] = {nullptr, nullptr};
+    int parity[2] = {0, 0};
+  } pub[2];
+  long coll_seq = 0, ar_seq = 0;
+  DBuf<double> ar_stage[2];
+  hipEvent_t ar_ready[2] = {nullptr, nullptr}, ar_done[2] = {nullptr, nullptr};
+  void local_exchange_on_stream(Space *const *sps, const DVec *xs, int count, hipStream_t s);
   bool active() const { return nranks > 1 || comm != nullptr; }
-  void init(int rank, int nranks, const void *unique_id);
+  void init(int rank, int nranks, const void *unique_id, int device_id = 0);
   void destroy();
   void allreduce_sum(double *d, int count, hipStream_t s);
   void halo_exchange(Space &sp, const DVec &x, hipStream_t s);
   void halo_exchange2(Space &sa, const DVec &xa, Space &sb, const DVec &xb, hipStream_t s);   // both in one RCCL group
 };
 
-// 128-byte pseudo unique id that makes nsk_create join an in-process group instead of RCCL
-int make_local_group(int nranks, void *out128);
+// 128-byte pseudo unique id that makes nsk_create join an in-process group instead of RCCL.
+// on_stream = 0: host-staged (streams synchronised around every collective: proves plans, ghost rows, block Jacobi);
+// on_stream = 1: device-to-device copies and a summing kernel ordered by events across the ranks' streams, host threads
+// only rendezvous — the stream ordering RCCL would see (second-stream overlap, grouped exchange) races for real.
+int make_local_group(int nranks, void *out128, int on_stream = 0);
 
 struct Stats {
   double setup_ms = 0, solve_ms = 0;

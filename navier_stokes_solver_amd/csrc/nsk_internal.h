@@ -29,6 +29,11 @@ extern "C" {
  * Returns the number of workgroups (0: this factor does not run the scalar single-launch kernels); *grid = -(workgroups
  * of the lower launch). */
 int nsk_debug_tri_trace(struct nsk_handle_s *h, int which, int64_t *out16, int max_runs, int *grid);
+/* In-process test transport (nsk_local_group_id) with the mode chosen: on_stream = 1 keeps every collective on the
+ * ranks' streams (device-to-device copies into the peers' ghost tails and a summing kernel, ordered by events; the host
+ * threads only rendezvous), so the second-stream overlap of the SpMVs and the grouped exchange race as they would under
+ * RCCL; on_stream = 0 is nsk_local_group_id (streams synchronised with the host around every collective). */
+int nsk_local_group_id_mode(int nranks, int on_stream, void *out128);
 #ifdef __cplusplus
 }
 #endif

@@ -209,5 +209,12 @@ void spgemm_bdbt_numeric(hipStream_t s, const CsrView &B, const double *dinv_own
 
 // ---- halo pack ----
 void halo_pack(hipStream_t s, int n, const int *idx, const double *x, double *buf);
+// out[i] = sum over r < n of src[r][i] in this order (all-reduce of the in-process test transport, on-stream mode)
+constexpr int kLocalSumMax = 16;
+struct LocalSumArgs {
+  int n;
+  const double *src[kLocalSumMax];
+};
+void local_sum(hipStream_t s, int count, const LocalSumArgs &A, double *out);
 
 }  // namespace nsk

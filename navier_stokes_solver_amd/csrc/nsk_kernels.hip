@@ -1157,6 +1157,14 @@ void vec_gather(hipStream_t s, int n, const int *idx, const double *x, double *y
   NSK_EW(n, [=] __device__(int i) { y[i] = x[idx[i]]; });
 }
 void halo_pack(hipStream_t s, int n, const int *idx, const double *x, double *buf) { vec_gather(s, n, idx, x, buf); }
+void local_sum(hipStream_t s, int count, const LocalSumArgs &A, double *out) {
+  const int n = count;
+  NSK_EW(n, [=] __device__(int i) {
+    double sum = 0.0;
+    for (int r = 0; r < A.n; ++r) sum += A.src[r][i];
+    out[i] = sum;
+  });
+}
 
 void extract_diag(hipStream_t s, const CsrView &A, double *d, double *dinv) {
   const int n = A.n_rows;

@@ -136,6 +136,7 @@ struct Touch {  // a cell touching a lattice node, with the node's local index i
 
 struct nsp_mesh {
   int nx, ny, nranks, rank;
+  double lx = LX;   // channel length (nsp_mesh_create_lx: a leading piece of the reference's 2.2 x 0.41 channel)
   double hx, hy;
   int NX3, NY3, NX2, NY2;
   std::vector<uint8_t> kept;          // [ci*ny + cj]
@@ -201,7 +202,7 @@ namespace {
 
 static void build_lattice(nsp_mesh &M) {
   const int nx = M.nx, ny = M.ny;
-  M.hx = LX / nx;
+  M.hx = M.lx / nx;
   M.hy = LY / ny;
   M.kept.assign((size_t)nx * ny, 1);
   M.n_removed = 0;
@@ -598,11 +599,17 @@ static void cap_host_threads() {  // see nsk_threads.h
 }
 
 nsp_mesh *nsp_mesh_create(int32_t nx, int32_t ny, int32_t nranks, int32_t rank) {
+  return nsp_mesh_create_lx(nx, ny, nranks, rank, LX);
+}
+
+nsp_mesh *nsp_mesh_create_lx(int32_t nx, int32_t ny, int32_t nranks, int32_t rank, double lx) {
   cap_host_threads();
   if (nx < 1 || ny < 1 || nranks < 1 || rank < 0 || rank >= nranks || nranks > nx) return nullptr;
+  if (!(lx > HOLE_X + HOLE_R) || lx > LX) return nullptr;   // the piece keeps the whole obstacle
   if ((int64_t)(3 * (int64_t)nx + 1) * (3 * (int64_t)ny + 1) * 2 > INT32_MAX) return nullptr;
   nsp_mesh *M = new nsp_mesh();
   M->nx = nx; M->ny = ny; M->nranks = nranks; M->rank = rank;
+  M->lx = lx;
   std::memset(&M->prm, 0, sizeof(M->prm));
   build_lattice(*M);
   build_tables(M->T, M->hx, M->hy);

@@ -43,6 +43,8 @@ def lib() -> C.CDLL:
         L = C.CDLL(path)
         L.nsp_mesh_create.restype = C.c_void_p
         L.nsp_mesh_create.argtypes = [C.c_int32] * 4
+        L.nsp_mesh_create_lx.restype = C.c_void_p
+        L.nsp_mesh_create_lx.argtypes = [C.c_int32] * 4 + [C.c_double]
         L.nsp_mesh_destroy.argtypes = [C.c_void_p]
         L.nsp_mesh_info.argtypes = [C.c_void_p, C.POINTER(_Info)]
         L.nsp_mesh_ranges.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -155,9 +157,9 @@ def reynolds_to_nu(Re: float, stationary: bool = True) -> float:
     return 1.0 / float(level)
 
 
-def mesh_info(nx: int, ny: int, nranks: int = 1, rank: int = 0) -> dict:
+def mesh_info(nx: int, ny: int, nranks: int = 1, rank: int = 0, lx: float = 2.2) -> dict:
     L = lib()
-    h = L.nsp_mesh_create(nx, ny, nranks, rank)
+    h = L.nsp_mesh_create_lx(nx, ny, nranks, rank, lx)
     if not h:
         raise ValueError("nsp_mesh_create rejected the arguments")
     info = _Info()
@@ -168,12 +170,13 @@ def mesh_info(nx: int, ny: int, nranks: int = 1, rank: int = 0) -> dict:
 
 def generate(nx: int, ny: int, *, nu: float, mode: int = 1, state=1, inlet_bc: int = 0,
              inv_dt: float = 0.0, U: float = 0.1, p_out: float = 1.0, nranks: int = 1, rank: int = 0,
-             copy: bool = True, state_old=None) -> LocalProblem:
+             copy: bool = True, state_old=None, lx: float = 2.2) -> LocalProblem:
     """Assemble rank ``rank``'s share of the nx x ny problem.  ``state``: 0 / 1 (analytic) or a pair
     (u, p) of GLOBAL velocity / pressure vectors to linearise about (the Newton loop's `solution`);
-    ``state_old``: GLOBAL velocity of the previous time step (`solution_old`) for the residual's time term."""
+    ``state_old``: GLOBAL velocity of the previous time step (`solution_old`) for the residual's time term;
+    ``lx``: channel length (default: the reference's 2.2; shorter = the leading piece, see nsp_mesh_create_lx)."""
     L = lib()
-    h = L.nsp_mesh_create(nx, ny, nranks, rank)
+    h = L.nsp_mesh_create_lx(nx, ny, nranks, rank, lx)
     if not h:
         raise ValueError("nsp_mesh_create rejected the arguments")
     try:

@@ -153,10 +153,13 @@ def get_unique_id() -> bytes:
     return buf.raw
 
 
-def local_group_id(nranks: int) -> bytes:
-    """Pseudo unique id for `nranks` handles living in threads of this process (test transport)."""
+def local_group_id(nranks: int, on_stream: bool = False) -> bytes:
+    """Pseudo unique id for `nranks` handles living in threads of this process (test transport).  on_stream: the
+    collectives stay on the ranks' streams (events across streams, no host synchronisation), see nsk_internal.h."""
     buf = C.create_string_buffer(128)
-    if lib().nsk_local_group_id(nranks, buf) != 0:
+    L = lib()
+    L.nsk_local_group_id_mode.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    if L.nsk_local_group_id_mode(nranks, 1 if on_stream else 0, buf) != 0:
         raise RuntimeError("nsk_local_group_id failed")
     return buf.raw
 

@@ -95,23 +95,30 @@ def test_multi_rank_path_over_gloo(world):
     (2, 2, 0, 1, "ns16+cg1"),       # the same with the single-reduction inner CG (NSK_OPT_CG_SINGLE_REDUCTION)
     (2, 2, 0, 1, "ns16_re200+cg1+gs2"),   # what bench.py --gpus N runs: plus one reduction per inner FGMRES iteration
     (2, 2, 0, 1, "ns16+noovl"),     # halo exchange first, then one SpMV launch (default: interior rows overlap the exchange)
+    # the same cases with the collectives kept on the ranks' streams (events across streams, no host synchronisation:
+    # the second-stream overlap and the grouped two-space exchange race as they would under RCCL)
+    (2, 2, 1, 0, "unsteady16+onstream"), (3, 2, 1, 1, "unsteady16+onstream"), (2, 2, 0, 1, "ns16+onstream"),
+    (2, 0, 0, 0, "ns16+onstream"), (2, 1, 0, 1, "ns16+onstream"), (2, 2, 0, 1, "ns16_re200+onstream"),
+    (2, 2, 0, 1, "ns16+cg1+onstream"), (3, 2, 0, 1, "ns16_re200+cg1+gs2+onstream"), (2, 2, 0, 1, "ns16+noovl+onstream"),
 ])
 def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name):
     """N rank threads on one GPU: ghost import, global reductions, D^-1 halo, SpGEMM with imported
-    (0,1) rows, rank-local ILU, full FGMRES solve — against the oracle with N emulated ranks."""
+    (0,1) rows, rank-local ILU, full FGMRES solve — against the oracle with N emulated ranks.  Two transports:
+    host-staged (streams synchronised around every collective) and on-stream (+onstream)."""
     import scipy.sparse.linalg as spl
     from navier_stokes_solver_amd import solver as S
     from oracle import oracle as O
     cg_fused = "+cg1" in name
     inner_gs = 2 if "+gs2" in name else 1
     overlap = "+noovl" not in name
+    on_stream = "+onstream" in name
     name = name.split("+")[0]
     case = CASES[name]
     pr = problem(name)
     parts = [P.generate(**case, nranks=world, rank=r) for r in range(world)]
     plans = [{S.SPACE_U: PT.build_halo_plan(r, parts[0].u_ranges, [p.ghost_u for p in parts]),
               S.SPACE_P: PT.build_halo_plan(r, parts[0].p_ranges, [p.ghost_p for p in parts])} for r in range(world)]
-    uid = S.local_group_id(world)
+    uid = S.local_group_id(world, on_stream)
     xu = rng_vec(pr.n_u, 1)
     xp = rng_vec(pr.n_p, 2)
     res, errs = [None] * world, []
@@ -171,6 +178,48 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name
                         velocity_amg=amg)
     assert info["status"] == 0 and rel_err(x, xo) <= 1e-7
     assert abs(res[0]["its"] - info["iters"]) <= max(3, (0.35 if cg_fused else 0.2) * info["iters"])
+
+
+@pytest.mark.gpu
+def test_both_local_transports_give_the_same_bits():
+    """Host-staged and on-stream collectives sum in rank order and move the same ghost values: J x, one preconditioner
+    application and twelve outer iterations must agree bit for bit (a race in the on-stream ordering would not)."""
+    from navier_stokes_solver_amd import solver as S
+    world, name = 3, "ns16_re200"
+    case = CASES[name]
+    parts = [P.generate(**case, nranks=world, rank=r) for r in range(world)]
+    plans = [{S.SPACE_U: PT.build_halo_plan(r, parts[0].u_ranges, [p.ghost_u for p in parts]),
+              S.SPACE_P: PT.build_halo_plan(r, parts[0].p_ranges, [p.ghost_p for p in parts])} for r in range(world)]
+    n_u, n_p = parts[0].u_ranges[-1], parts[0].p_ranges[-1]
+    xu, xp = rng_vec(n_u, 1), rng_vec(n_p, 2)
+    outs = []
+    for on_stream in (False, True):
+        uid = S.local_group_id(world, on_stream)
+        res, errs = [None] * world, []
+
+        def run(r):
+            try:
+                ls = S.LinearSolver(r, world, 0, uid)
+                p = parts[r]
+                ls.set_option(S.OPT_TRI_ORDERING, 1)
+                ls.set_problem(p, plans[r])
+                ur, prg = p.u_ranges, p.p_ranges
+                yu, yp = ls.jacobian_vmult(xu[ur[r]:ur[r + 1]], xp[prg[r]:prg[r + 1]])
+                ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+                du, dp, rc = ls.precond_vmult(xu[ur[r]:ur[r + 1]], xp[prg[r]:prg[r + 1]])
+                ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+                su, spp, its, fres, src = ls.solve(S.FGMRES, 0.0, 12, p.rhs_u, p.rhs_p, p.x0_u, p.x0_p)
+                res[r] = np.concatenate([yu, yp, du, dp, su, spp, [fres, ls.stats()["overlapped_spmvs"]]])
+                ls.close()
+            except Exception as e:  # noqa: BLE001
+                errs.append((r, repr(e)))
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join(600) for t in th]
+        assert not errs, errs
+        outs.append(np.concatenate(res))
+    assert outs[0][-1] > 0 and np.array_equal(outs[0], outs[1])
 
 
 @pytest.mark.gpu

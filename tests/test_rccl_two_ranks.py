@@ -14,6 +14,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_two_process_rccl_solve_matches_one_rank():
     import torch
     if torch.cuda.device_count() < 2:       # (device_count() does not initialise the GPU on this image)
@@ -23,7 +30,7 @@ def test_two_process_rccl_solve_matches_one_rank():
         out = os.path.join(td, "out.npz")
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
         subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29611",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                         os.path.join(ROOT, "tests", "rccl_two_rank_worker.py"), out], check=True, env=env, timeout=600)
         got = np.load(out)
     pr = problem("ns16_re200")
