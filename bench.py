@@ -189,13 +189,19 @@ def cpu_baseline(args, nu):
     its = max(1, info["iters"])
     return {
         "value": pr.n * its / info["solve_seconds"], "unit": "DoF*iters/s", "cores": cores, "kind": "port",
-        "sample": f"oracle (C restatement, {cores} OpenMP threads = {cores} emulated MPI ranks with block-Jacobi ILU(0)), "
-                  f"stationary {nx}x{ny} Re={args.reynolds:g}, first {its} outer iterations, "
-                  f"{info['inner_u_its'] / max(1, info['prec_applies']):.0f} / {info['inner_p_its'] / max(1, info['prec_applies']):.0f} "
-                  f"inner F / S iterations per step; solve {info['solve_seconds']:.1f}s + setup {info['setup_seconds']:.1f}s "
-                  f"(wall {wall:.1f}s)",
+        "sample": f"oracle (C restatement, {cores} OpenMP threads = {cores} emulated MPI ranks: {cores} x-strip shards, each "
+                  f"with its own ILU(0) in NATURAL order = Ifpack overlap 0, how the reference runs on a CPU node; the GPU "
+                  f"pair below is ONE shard in multicolour order, so the inner iteration counts per step differ — "
+                  f"dof_inner_iters_per_s counts the work actually done), "
+                  f"stationary {nx}x{ny} Re={args.reynolds:g}, first {its} outer iterations; "
+                  f"solve {info['solve_seconds']:.1f}s + setup {info['setup_seconds']:.1f}s (wall {wall:.1f}s)",
         "incl_setup_value": pr.n * its / (info["solve_seconds"] + info["setup_seconds"]),
         "mesh": f"{nx}x{ny}", "K": its,
+        "inner_F_its_per_step": info["inner_u_its"] / max(1, info["prec_applies"]),
+        "inner_S_its_per_step": info["inner_p_its"] / max(1, info["prec_applies"]),
+        # inner-iteration throughput: (velocity DoFs x F iterations + pressure DoFs x S iterations) per second of solve
+        "dof_inner_iters_per_s": (pr.n_u * info["inner_u_its"] + pr.n_p * info["inner_p_its"]) / info["solve_seconds"],
+        "ordering": "natural, per shard", "shards": cores,
     }
 
 
@@ -342,7 +348,9 @@ def main():
         gpu_same = {"value": n2 * i2 / dt2, "unit": "DoF*iters/s", "mesh": f"{cx}x{cy}", "K": i2,
                     "ms_per_step": 1e3 * dt2 / max(1, i2),
                     "inner_F_its_per_step": st2["inner_u_its"] / max(1, st2["prec_applies"]),
-                    "inner_S_its_per_step": st2["inner_p_its"] / max(1, st2["prec_applies"])}
+                    "inner_S_its_per_step": st2["inner_p_its"] / max(1, st2["prec_applies"]),
+                    "dof_inner_iters_per_s": (pr2.n_u * st2["inner_u_its"] + pr2.n_p * st2["inner_p_its"]) / dt2,
+                    "ordering": ["natural", "multicolour"][args.ordering], "shards": args.subdomains}
         ls2.close()
 
     conv = None
@@ -375,14 +383,20 @@ def main():
         D = klass[dom]
         # HBM traffic of the dominant class from the committed PMC passes (rocprofv3 --pmc cannot run inside
         # this process); only quoted when it was measured on this very workload
-        traffic, traffic_src = None, None
-        for pmc_name in ("r02_pmc_traffic_1200x400.json", "r01_pmc_traffic_1200x400.json"):
+        traffic, traffic_src, traffic_stale = None, None, None
+        import hashlib
+        ksrc = [os.path.join(ROOT, "navier_stokes_solver_amd", "csrc", f) for f in ("nsk_kernels.hip", "nsk_tri.cpp")]
+        sha_now = hashlib.sha256(b"".join(open(f, "rb").read() for f in ksrc)).hexdigest()
+        for pmc_name in ("r03_pmc_traffic_1200x400.json", "r02_pmc_traffic_1200x400.json"):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
-            if (nx, ny, world) == (1200, 400, 1) and os.path.exists(pmc):
-                kk = json.load(open(pmc)).get("by_op", {})
+            if (nx, ny, world, args.lx) == (1200, 400, 1, 2.2) and os.path.exists(pmc):
+                rec = json.load(open(pmc))
+                kk = rec.get("by_op", {})
                 if str(dom) in kk:
                     traffic = kk[str(dom)]["traffic_bytes_corrected"]
                     traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                    # the counters belong to the kernel sources they were taken from (sha recorded by scripts/pmc_traffic.py)
+                    traffic_stale = rec.get("kernel_sources_sha256") != sha_now
                     break
         label = f"{NAMES_S[args.solver]}+{NAMES_P[args.preconditioner]}, Re={args.reynolds:g}"
         out = {
@@ -413,7 +427,7 @@ def main():
                 "bound": "hbm", "kernel": D["kernel"], "time_share": D["time_share"],
                 "achieved": D["achieved_algorithmic"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": D["achieved_algorithmic"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                "traffic_source": traffic_src,
+                "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                 "bytes_per_launch": D["bytes_csr_algorithmic"], "bytes_format": D["bytes_format"],
                 "frac_format": D["frac"], "avg_ms": D["avg_ms"], "launches_sampled": D["launches_sampled"],
             },
@@ -437,6 +451,7 @@ def main():
             cb["gpu_same_mesh"] = gpu_same    # the like-for-like pair: same mesh, same K, same inner work per iteration
             if gpu_same:
                 cb["gpu_over_cpu_same_mesh"] = gpu_same["value"] / cb["value"]
+                cb["gpu_over_cpu_inner_work"] = gpu_same["dof_inner_iters_per_s"] / cb["dof_inner_iters_per_s"]
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:

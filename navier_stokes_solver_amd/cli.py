@@ -120,6 +120,8 @@ def _report(backend, nx, ny, nu, inlet_u, name, counter, n_digits):
 def run_gmsh(cfg, unsteady: bool) -> int:
     """`-M FILE`: P2/P1 on a gmsh triangle mesh (NSSolverStationary.cpp:144-206).  The reference reads a hard-coded
     path (testStationary.cpp:127) and its getopt string lets -M swallow the next token: here that token names the file."""
+    import numpy as np
+
     from . import gmsh as G
     from . import newton as N
     from . import simplex as SX
@@ -140,16 +142,31 @@ def run_gmsh(cfg, unsteady: bool) -> int:
     print("-----------------------------------------------\nInitializing the DoF handler\n  Number of DoFs: ")
     print(f"    velocity = {space.n_u}\n    pressure = {space.n_p}\n    total    = {space.n_u + space.n_p}")
     print("-----------------------------------------------")
-    ls = S.LinearSolver()
-    ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
     from . import postprocess as PP
+    nranks = int(os.environ.get("NSK_RANKS", "1"))    # `mpirun -n N`: N rank threads (in-process transport), see below
+    ls = None
+    if nranks <= 1 or unsteady:
+        ls = S.LinearSolver()
+        ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
 
     def report(name, nu, inlet_u):
         u, p = backend.solution()
-        SX.write_vtu(os.path.join(os.environ.get("NSK_OUTPUT_DIR", "./"), name), space, u, p)
+        out_dir = os.environ.get("NSK_OUTPUT_DIR", "./")
+        if nranks > 1 and not unsteady:     # every rank writes its own piece, rank 0 the record naming them (.cpp:793-796)
+            stem = name[:-4]
+            pieces = [f"{stem}.{r}.vtu" for r in range(nranks)]
+            for r in range(nranks):
+                SX.write_vtu(os.path.join(out_dir, pieces[r]), space, u, p, cells=np.nonzero(backend.layout.cell_rank == r)[0])
+            SX.write_pvtu(os.path.join(out_dir, stem + ".pvtu"), pieces)
+        else:
+            SX.write_vtu(os.path.join(out_dir, name), space, u, p)
+        # (the reference prints this fixed name in both drivers, whatever file DataOut wrote)
         print("===============================================\nOutput written to output-stokes")
         print("===============================================\n===============================================\nComputing lift and drag forces")
-        drag, lift = SX.lift_drag(space, u, p, nu)
+        if nranks > 1 and not unsteady:     # each rank its own share of the obstacle, summed (Utilities::MPI::sum, .cpp:895-896)
+            drag, lift, _ = backend.lift_drag(nu)
+        else:
+            drag, lift = SX.lift_drag(space, u, p, nu)
         cd, cl = PP.coefficients(drag, lift, inlet_u)
         print(f"===============================================\nLift coefficient: {cl:g}")
         print(f"===============================================\nDrag coefficient: {cd:g}")
@@ -168,8 +185,19 @@ def run_gmsh(cfg, unsteady: bool) -> int:
                   f"solve_system() on the GPU, {time.time() - t0:.3f} s in the time loop")
             ls.close()
         return 0
-    host_assembly = bool(os.environ.get("NSK_HOST_ASSEMBLY"))
-    if host_assembly:      # the hand-off producer on the host for every assembly (the yardstick of the device assembly)
+    host_assembly = bool(os.environ.get("NSK_HOST_ASSEMBLY")) or nranks > 1
+    if nranks > 1:
+        # Several ranks (the reference: mpirun -n N, METIS partition, NSSolverStationary.cpp:160-166): coordinate bisection of
+        # the cells, one handle per rank.  Here the ranks are threads of this process joined by the in-process transport,
+        # one GPU each when the process sees several, else sharing the one there is; assembly on the host.
+        import torch
+        ndev = max(1, torch.cuda.device_count())
+        devices = [r % ndev for r in range(nranks)]
+        uid = S.local_group_id(nranks, on_stream=(ndev == 1))
+        backend = N.MultiRankSimplexBackend(space, nranks, cfg["solver"], cfg["prec"], cfg["tol"], uid, devices=devices)
+        print(f"  Number of ranks            = {nranks} (cells per rank: "
+              f"{' '.join(str(int(c)) for c in np.bincount(backend.layout.cell_rank, minlength=nranks))})")
+    elif host_assembly:      # the hand-off producer on the host for every assembly (the yardstick of the device assembly)
         backend = N.SimplexBackend(ls, space, cfg["solver"], cfg["prec"], cfg["tol"])
     else:                  # first hand-off (pattern, constant blocks) from the host, then nsk_assemble on the P2/P1 cells
         first = SX.assemble(space, 0.1, mode=0, inlet_bc=1, U=0.1)
@@ -184,7 +212,10 @@ def run_gmsh(cfg, unsteady: bool) -> int:
         its = backend.total_linear_iterations
         print(f"[nsk] {backend.assemblies} assemblies ({'host' if host_assembly else 'device'}, P2/P1), {its} outer iterations "
               f"of solve_system() on the GPU, {dt:.3f} s in solve_newton")
-        ls.close()
+        if ls is not None:
+            ls.close()
+        else:
+            backend.close()
     return 0
 
 

@@ -299,3 +299,121 @@ class SimplexBackend:
 
     def solution(self):
         return self.sol_u, self.sol_p
+
+
+class MultiRankSimplexBackend(SimplexBackend):
+    """`-M` on several ranks: the cells are cut into `nranks` parts (`simplex.rank_layout`: coordinate bisection in place of
+    the reference's METIS call, NSSolverStationary.cpp:166), every rank holds the rows of its own DoFs with ghost columns,
+    and `solve_system()` runs on `nranks` handles — one per GPU under RCCL, or rank threads of this process joined by the
+    in-process transport (`unique_ids` from `solver.local_group_id`), which is how a one-GPU box exercises the path.
+    Assembly stays on the host, once for all ranks (each rank's rows are a slice of it)."""
+
+    def __init__(self, space, nranks, solver, preconditioner, tolerance, unique_id, devices=None, max_iter=20000, alpha=0.5,
+                 U=0.1, p_out=1.0, options=()):
+        import queue
+        import threading
+
+        from . import partition as PT
+        from . import simplex as SX
+        super().__init__(None, space, solver, preconditioner, tolerance, max_iter, alpha, U, p_out)
+        self.SX, self.PT, self.nranks = SX, PT, nranks
+        self.layout = SX.rank_layout(space, nranks)
+        self.handles = [None] * nranks
+        self.queues = [queue.Queue() for _ in range(nranks)]
+        self.results = queue.Queue()
+        devices = devices or [0] * nranks
+
+        def worker(r):
+            while True:
+                fn = self.queues[r].get()
+                if fn is None:
+                    return
+                try:
+                    self.results.put((r, fn(r), None))
+                except Exception as e:  # noqa: BLE001
+                    self.results.put((r, None, e))
+
+        self.threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(nranks)]
+        for t in self.threads:
+            t.start()
+
+        def create(r):
+            ls = self.S.LinearSolver(r, nranks, devices[r], unique_id)
+            ls.set_option(self.S.OPT_TRI_ORDERING, self.S.ORDER_MULTICOLOR)
+            for opt, val in options:
+                ls.set_option(opt, val)
+            self.handles[r] = ls
+
+        self.on_all(create)
+
+    def on_all(self, fn):
+        """Run fn(rank) on every rank thread at once (collective calls need all ranks inside) and collect the results."""
+        for q in self.queues:
+            q.put(fn)
+        out = [None] * self.nranks
+        err = None
+        for _ in range(self.nranks):
+            r, val, e = self.results.get()
+            out[r] = val
+            err = err or e
+        if err:
+            raise err
+        return out
+
+    def assemble(self, first, stokes, nu):
+        np, S, SX = self.np, self.S, self.SX
+        pr = SX.assemble(self.space, nu, mode=0 if stokes else 1, state=(self.sol_u, self.sol_p), inlet_bc=int(bool(first)),
+                         U=self.U, p_out=self.p_out)
+        self.pr = pr
+        self.assemblies += 1
+        parts = [SX.local_problem(pr, self.layout, r) for r in range(self.nranks)]
+        if not self.handed_over:
+            gu, gp = [q.ghost_u for q in parts], [q.ghost_p for q in parts]
+            plans = [{S.SPACE_U: self.PT.build_halo_plan(r, self.layout.u_ranges, gu),
+                      S.SPACE_P: self.PT.build_halo_plan(r, self.layout.p_ranges, gp)} for r in range(self.nranks)]
+
+        def hand_over(r):
+            ls, q = self.handles[r], parts[r]
+            if not self.handed_over:
+                ls.set_problem(q, plans[r])
+            else:
+                for blk, A in ((S.BLK_F, q.F), (S.BLK_BT, q.Bt), (S.BLK_B, q.B), (S.BLK_MP, q.Mp)) + (
+                        ((S.BLK_BT_GHOST, q.Bt_ghost),) if len(q.ghost_u) else ()):
+                    ls.update_values(blk, A.val)
+            ls.upload_system(q.rhs_u, q.rhs_p, q.x0_u, q.x0_p)
+
+        self.on_all(hand_over)
+        self.handed_over = True
+        return float(np.sqrt(pr.rhs_u @ pr.rhs_u + pr.rhs_p @ pr.rhs_p))
+
+    def solve(self):
+        def run(r):
+            ls = self.handles[r]
+            ls.setup_preconditioner(self.prec, self.S.STATIONARY, self.alpha)
+            its, res, rc = ls.solve_resident(self.solver, self.tol, self.max_iter)
+            return (its, res, rc) + ls.download_solution()
+
+        out = self.on_all(run)
+        its, res, rc = out[0][:3]
+        if any(o[:3] != (its, res, rc) for o in out):
+            raise RuntimeError(f"the ranks disagree about the solve: {[o[:3] for o in out]}")
+        if rc != 0:
+            raise RuntimeError(f"solve_system: no convergence (status {rc}) after {its} iterations, residual {res:g}")
+        self.delta_u, self.delta_p = self.SX.gather_solution(self.layout, [o[3] for o in out], [o[4] for o in out])
+        self.total_linear_iterations += its
+        return its
+
+    def lift_drag(self, nu):
+        """Sum of the ranks' shares of the obstacle forces (Utilities::MPI::sum, NSSolverStationary.cpp:895-896)."""
+        parts = [self.SX.lift_drag_rank(self.space, self.layout, r, self.sol_u, self.sol_p, nu) for r in range(self.nranks)]
+        return sum(p[0] for p in parts), sum(p[1] for p in parts), parts
+
+    def close(self):
+        def stop(r):
+            if self.handles[r] is not None:
+                self.handles[r].close()
+                self.handles[r] = None
+
+        self.on_all(stop)
+        for q in self.queues:
+            q.put(None)

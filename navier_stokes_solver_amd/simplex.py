@@ -287,20 +287,36 @@ def lift_drag(sp_: SimplexSpace, u, p, nu):
     return drag, lift
 
 
-def write_vtu(path, sp_: SimplexSpace, u, p):
-    """One-piece ASCII VTU of the solution on the mesh's vertices (linear triangles; the midside values are dropped)."""
+def write_pvtu(path, piece_names):
+    """The record naming the ranks' pieces (`write_vtu_with_pvtu_record`, NSSolverStationary.cpp:793-796)."""
+    with open(path, "w") as f:
+        f.write('<?xml version="1.0"?>\n<VTKFile type="PUnstructuredGrid" version="0.1" byte_order="LittleEndian">\n'
+                '<PUnstructuredGrid GhostLevel="0">\n<PPointData Vectors="velocity" Scalars="pressure">\n'
+                '<PDataArray type="Float64" Name="velocity" NumberOfComponents="3" format="ascii"/>\n'
+                '<PDataArray type="Float64" Name="pressure" format="ascii"/>\n</PPointData>\n'
+                '<PPoints>\n<PDataArray type="Float64" NumberOfComponents="3"/>\n</PPoints>\n')
+        for n in piece_names:
+            f.write(f'<Piece Source="{n}"/>\n')
+        f.write('</PUnstructuredGrid>\n</VTKFile>\n')
+
+
+def write_vtu(path, sp_: SimplexSpace, u, p, cells=None):
+    """ASCII VTU of the solution on the mesh's vertices (linear triangles; the midside values are dropped); `cells`:
+    only these triangles — one rank's piece (all vertices are listed, the piece's cells index into them)."""
     nv = sp_.n_p
+    all_cells = sp_.cell_p
+    sp_cells = all_cells if cells is None else all_cells[np.asarray(cells)]
     with open(path, "w") as f:
         f.write('<?xml version="1.0"?>\n<VTKFile type="UnstructuredGrid" version="0.1" byte_order="LittleEndian">\n<UnstructuredGrid>\n')
-        f.write(f'<Piece NumberOfPoints="{nv}" NumberOfCells="{len(sp_.cell_p)}">\n<Points>\n<DataArray type="Float64" NumberOfComponents="3" format="ascii">\n')
+        f.write(f'<Piece NumberOfPoints="{nv}" NumberOfCells="{len(sp_cells)}">\n<Points>\n<DataArray type="Float64" NumberOfComponents="3" format="ascii">\n')
         for x, y in sp_.mesh.nodes:
             f.write(f"{x:.16g} {y:.16g} 0\n")
         f.write('</DataArray>\n</Points>\n<Cells>\n<DataArray type="Int32" Name="connectivity" format="ascii">\n')
-        for t in sp_.cell_p:
+        for t in sp_cells:
             f.write(f"{t[0]} {t[1]} {t[2]}\n")
         f.write('</DataArray>\n<DataArray type="Int32" Name="offsets" format="ascii">\n')
-        f.write(" ".join(str(3 * (k + 1)) for k in range(len(sp_.cell_p))))
-        f.write('\n</DataArray>\n<DataArray type="UInt8" Name="types" format="ascii">\n' + " ".join(["5"] * len(sp_.cell_p)))
+        f.write(" ".join(str(3 * (k + 1)) for k in range(len(sp_cells))))
+        f.write('\n</DataArray>\n<DataArray type="UInt8" Name="types" format="ascii">\n' + " ".join(["5"] * len(sp_cells)))
         f.write('\n</DataArray>\n</Cells>\n<PointData Vectors="velocity" Scalars="pressure">\n')
         f.write('<DataArray type="Float64" Name="velocity" NumberOfComponents="3" format="ascii">\n')
         for k in range(nv):
@@ -308,3 +324,132 @@ def write_vtu(path, sp_: SimplexSpace, u, p):
         f.write('</DataArray>\n<DataArray type="Float64" Name="pressure" format="ascii">\n')
         f.write("\n".join(f"{v:.16g}" for v in p[:nv]))
         f.write('\n</DataArray>\n</PointData>\n</Piece>\n</UnstructuredGrid>\n</VTKFile>\n')
+
+
+# ------------------------------------------------------------------ several ranks (-M under mpirun)
+# The reference cuts the gmsh mesh with METIS (`GridTools::partition_triangulation(mpi_size, mesh_serial)`,
+# NSSolverStationary.cpp:166) and lets deal.II number the DoFs rank by rank.  METIS is a third-party graph partitioner;
+# here the cells are cut by recursive coordinate bisection of their centroids (balanced parts, straight cuts), a DoF
+# belongs to the lowest rank among the cells holding it, and the DoFs are renumbered rank by rank (owned ranges
+# contiguous, as Epetra's maps are) — everything after that (ghost lists, halo plans, rank-local ILU) is the library's
+# general multi-rank path.
+
+def partition_cells(sp_: SimplexSpace, nranks: int) -> np.ndarray:
+    """Rank of every triangle: recursive coordinate bisection (longest extent, sizes proportional to the ranks)."""
+    cen = sp_.mesh.nodes[sp_.cell_p].mean(axis=1)
+    out = np.zeros(len(cen), np.int32)
+
+    def cut(idx, r0, r1):
+        if r1 - r0 <= 1 or len(idx) == 0:
+            out[idx] = r0
+            return
+        ext = cen[idx].max(axis=0) - cen[idx].min(axis=0)
+        d = int(np.argmax(ext))
+        order = idx[np.argsort(cen[idx, d], kind="stable")]
+        mid = (r0 + r1) // 2
+        k = int(round(len(order) * (mid - r0) / (r1 - r0)))
+        cut(order[:k], r0, mid)
+        cut(order[k:], mid, r1)
+
+    cut(np.arange(len(cen)), 0, nranks)
+    return out
+
+
+@dataclass(eq=False)
+class RankLayout:
+    nranks: int
+    cell_rank: np.ndarray     # (T,)
+    node_new: np.ndarray      # (n_un,) new velocity NODE id of the old one (rank by rank, old order inside a rank)
+    vert_new: np.ndarray      # (n_p,) the same for the pressure DoFs
+    u_ranges: np.ndarray      # (nranks + 1,) owned velocity DoF ranges in the new numbering
+    p_ranges: np.ndarray
+
+    def dof_new(self):
+        """(new velocity DoF id of old DoF, new pressure DoF id of old DoF)"""
+        nn = self.node_new
+        return np.stack([2 * nn, 2 * nn + 1], axis=1).reshape(-1), self.vert_new
+
+
+def rank_layout(sp_: SimplexSpace, nranks: int, cell_rank=None) -> RankLayout:
+    cell_rank = partition_cells(sp_, nranks) if cell_rank is None else np.asarray(cell_rank, np.int32)
+
+    def owners(ids, n):
+        own = np.full(n, nranks, np.int64)
+        np.minimum.at(own, ids.ravel(), np.repeat(cell_rank, ids.shape[1]))
+        if (own == nranks).any():
+            raise ValueError("a DoF belongs to no cell")
+        order = np.argsort(own, kind="stable")               # rank by rank, old order inside a rank
+        new = np.empty(n, np.int64)
+        new[order] = np.arange(n)
+        return new, np.concatenate([[0], np.cumsum(np.bincount(own, minlength=nranks))])
+
+    node_new, ncnt = owners(sp_.cell_u, sp_.n_un)
+    vert_new, pcnt = owners(sp_.cell_p, sp_.n_p)
+    return RankLayout(nranks, cell_rank, node_new, vert_new, 2 * ncnt, pcnt)
+
+
+def local_problem(pr, lay: RankLayout, rank: int):
+    """Rank `rank`'s rows of the one-rank hand-off `pr` (simplex.assemble) in the layout's numbering: local CSR blocks
+    with owned-first / ghost-appended column ids (ghosts ascending by global id, hence grouped by owner), the (0,1) rows
+    of the ghost velocity DoFs (aSIMPLE's SpGEMM), the ghost lists for `partition.build_halo_plan`."""
+    du, dp = lay.dof_new()
+    n_u, n_p = len(du), len(dp)
+    Pu = sp.csr_matrix((np.ones(n_u), (du, np.arange(n_u))), shape=(n_u, n_u))
+    Pp = sp.csr_matrix((np.ones(n_p), (dp, np.arange(n_p))), shape=(n_p, n_p))
+    F = (Pu @ pr.F.to_scipy() @ Pu.T).tocsr()
+    Bt = (Pu @ pr.Bt.to_scipy() @ Pp.T).tocsr()
+    B = (Pp @ pr.B.to_scipy() @ Pu.T).tocsr()
+    Mp = (Pp @ pr.Mp.to_scipy() @ Pp.T).tocsr()
+    for A in (F, Bt, B, Mp):
+        A.sort_indices()
+    u0, u1 = int(lay.u_ranges[rank]), int(lay.u_ranges[rank + 1])
+    p0, p1 = int(lay.p_ranges[rank]), int(lay.p_ranges[rank + 1])
+
+    def ghosts(cols_list, b, e):
+        c = np.unique(np.concatenate([np.asarray(x, np.int64) for x in cols_list])) if cols_list else np.zeros(0, np.int64)
+        return c[(c < b) | (c >= e)]
+
+    Fo, Bto, Bo, Mpo = F[u0:u1], Bt[u0:u1], B[p0:p1], Mp[p0:p1]
+    ghost_u = ghosts([Fo.indices, Bo.indices], u0, u1)
+    # both components of a ghost node travel together (the library's 2x2 / 1x2 node blocks need whole nodes)
+    ghost_u = np.unique(np.concatenate([ghost_u & ~1, (ghost_u & ~1) + 1])) if len(ghost_u) else ghost_u
+    Btg = Bt[ghost_u] if len(ghost_u) else Bt[0:0]
+    ghost_p = ghosts([Bto.indices, Mpo.indices, Btg.indices], p0, p1)
+
+    def localise(A, b, e, gh):
+        A = A.tocsr()
+        col = A.indices.astype(np.int64)
+        own = (col >= b) & (col < e)
+        loc = np.where(own, col - b, (e - b) + np.searchsorted(gh, col))
+        M = sp.csr_matrix((A.data, loc, A.indptr), shape=(A.shape[0], (e - b) + len(gh)))
+        M.sort_indices()
+        return P.CsrBlock(M.shape[0], M.shape[1], M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(float))
+
+    inv_u = np.empty(n_u, np.int64)
+    inv_u[du] = np.arange(n_u)
+    inv_p = np.empty(n_p, np.int64)
+    inv_p[dp] = np.arange(n_p)
+    ou, op_ = inv_u[u0:u1], inv_p[p0:p1]                      # old ids of the owned DoFs, in local order
+    info = dict(pr.info, nranks=lay.nranks, rank=rank, u_begin=u0, u_end=u1, p_begin=p0, p_end=p1,
+                n_ghost_u=len(ghost_u), n_ghost_p=len(ghost_p))
+    return P.LocalProblem(info, localise(Fo, u0, u1, ghost_u), localise(Bto, p0, p1, ghost_p), localise(Bo, u0, u1, ghost_u),
+                          localise(Mpo, p0, p1, ghost_p), localise(Btg, p0, p1, ghost_p),
+                          pr.rhs_u[ou], pr.rhs_p[op_], pr.x0_u[ou], pr.x0_p[op_], ghost_u.astype(np.int32),
+                          ghost_p.astype(np.int32), pr.dirichlet_u[ou], lay.u_ranges.astype(np.int64),
+                          lay.p_ranges.astype(np.int64), params=dict(pr.params))
+
+
+def gather_solution(lay: RankLayout, parts_u, parts_p):
+    """Rank pieces of a solution (owned DoFs, layout numbering) -> the one-rank numbering of the SimplexSpace."""
+    du, dp = lay.dof_new()
+    return np.concatenate(parts_u)[du], np.concatenate(parts_p)[dp]
+
+
+def lift_drag_rank(sp_: SimplexSpace, lay: RankLayout, rank: int, u, p, nu):
+    """This rank's share of the obstacle forces: the id-10 edges of its own cells (`compute_lift_drag` integrates over
+    locally owned cells and sums with Utilities::MPI::sum, NSSolverStationary.cpp:895-896)."""
+    a, m, b, nx_, ny_, ln, tt = sp_.obstacle
+    keep = lay.cell_rank[tt.astype(int)] == rank if len(tt) else np.zeros(0, bool)
+    sub = SimplexSpace(sp_.mesh, sp_.cell_u, sp_.cell_p, sp_.xy_u, sp_.dirichlet, sp_.grad_lam, sp_.area, sp_.outlet,
+                       tuple(np.asarray(c)[keep] for c in sp_.obstacle), sp_.n_un, sp_.n_p)
+    return lift_drag(sub, u, p, nu)

@@ -5,7 +5,7 @@ scripts/pmc_target.py.  Counters are KiB; on gfx950 FETCH_SIZE reports half of t
 reads are doubled; WRITE_SIZE is exact.
 
 usage: pmc_traffic.py FETCH.csv WRITE.csv nx ny out.json"""
-import csv, json, sys
+import csv, hashlib, json, os, sys
 from collections import defaultdict
 
 fetch_csv, write_csv, nx, ny, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
@@ -38,7 +38,12 @@ def per_dispatch(path):
 F, W = per_dispatch(fetch_csv), per_dispatch(write_csv)
 i = P.mesh_info(nx, ny)
 n_u, n_p = i["n_u_global"], i["n_p_global"]
-out_d = {"note": __doc__.split("usage")[0].strip(), "mesh": [nx, ny], "kernels": {}, "by_op": {}}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KSRC = [os.path.join(ROOT, "navier_stokes_solver_amd", "csrc", f) for f in ("nsk_kernels.hip", "nsk_tri.cpp")]
+# what the counters were taken from: bench.py quotes the traffic only while these sources are unchanged
+sha = hashlib.sha256(b"".join(open(f, "rb").read() for f in KSRC)).hexdigest()
+out_d = {"note": __doc__.split("usage")[0].strip(), "mesh": [nx, ny], "kernel_sources": [os.path.relpath(f, ROOT) for f in KSRC],
+         "kernel_sources_sha256": sha, "kernels": {}, "by_op": {}}
 for label, subs, lpu, op in CLASSES:
     if not F.get(label):
         continue

@@ -51,9 +51,10 @@ class OracleBackend(HostBackend):
     fresh preconditioner per call, warm start from the previous delta).  Used to pin what the REFERENCE algorithm does on
     the Newton systems of the time loop (restart stagnation), independent of the GPU library."""
 
-    def __init__(self, nx, ny, tol, inv_dt=0.0, U=0.1, solver=1, prec=0, variant=1, max_iter=100000, history=4096):
+    def __init__(self, nx, ny, tol, inv_dt=0.0, U=0.1, solver=1, prec=0, variant=1, max_iter=100000, history=4096, perms=None):
         super().__init__(nx, ny, tol, inv_dt, U)
         self.solver, self.prec, self.variant, self.max_iter, self.hist_cap = solver, prec, variant, max_iter, history
+        self.perms = perms or {}         # perm_F / perm_S / perm_Mp: the orderings of the triangular factors (default natural)
         self.solves = []     # per solve_system() call: dict(iters, status, final_res, history, inner_u_its, inner_p_its)
 
     def assemble(self, first, stokes, nu):
@@ -70,7 +71,7 @@ class OracleBackend(HostBackend):
 
     def solve(self):
         from oracle import oracle as O
-        op = O.OracleProblem.from_local(self.pr)
+        op = O.OracleProblem.from_local(self.pr, **self.perms)
         x, info = op.solve(self.b, self.delta, solver=self.solver, prec=self.prec, variant=self.variant, tol=self.tol,
                            max_iter=self.max_iter, history=self.hist_cap)
         self.solves.append(info)

@@ -53,16 +53,18 @@ def test_first_time_step_matches_the_oracle_driven_time_loop():
     from navier_stokes_solver_amd import solver as S
     from tests.newton_host import OracleBackend
     nx, ny, Re, tol, dt = 60, 20, 1.0, 1e-6, 0.01
-    host = OracleBackend(nx, ny, tol, inv_dt=1.0 / dt, U=0.3, solver=1, prec=0, variant=1, max_iter=100000, history=8192)
-    h_hist = N.time_loop(host, dt, dt, Re, log=lambda *_: None, max_steps=1)
     first = P.generate(nx, ny, nu=1.0, mode=0, state=0, inlet_bc=1, U=0.3)
     ls = S.LinearSolver()
     try:
-        ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_NATURAL)      # the oracle's ILU(0): one rank, natural order
+        ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)   # the library's default; the oracle gets the same permutations
         dev = N.DeviceBackend(ls, first, S.FGMRES, S.BLOCK_DIAGONAL, tol, max_iter=100000, inv_dt=1.0 / dt)
         d_hist = N.time_loop(dev, dt, dt, Re, log=lambda *_: None, max_steps=1)
+        perms = dict(perm_F=ls.tri_perm(S.TRI_VELOCITY), perm_Mp=ls.tri_perm(S.TRI_PRESSURE))
     finally:
         ls.close()
+    host = OracleBackend(nx, ny, tol, inv_dt=1.0 / dt, U=0.3, solver=1, prec=0, variant=1, max_iter=100000, history=8192,
+                         perms=perms)
+    h_hist = N.time_loop(host, dt, dt, Re, log=lambda *_: None, max_steps=1)
     dw, hw = [r for r in d_hist[0] if r[4] > 0], [r for r in h_hist[0] if r[4] > 0]
     assert len(dw) == len(hw) >= 3
     for d, h in zip(dw, hw):

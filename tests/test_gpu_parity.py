@@ -372,8 +372,8 @@ def test_amg_follows_a_second_hand_off_with_another_pattern():
     n = pr.n_u
     i = np.arange(n)
     new = 2 * (n // 2 - 1 - i // 2) + i % 2                     # nodes in reverse order, components kept together
-    Pm = sp.csr_matrix((np.ones(n), (new, i)), shape=(n, n))
-    F2 = (Pm @ F @ Pm.T).tocsr()
+    Fc = F.tocoo()                                               # (a sparse product would drop the stored zeros of Dirichlet rows)
+    F2 = sp.csr_matrix((Fc.data, (new[Fc.row], new[Fc.col])), shape=(n, n))
     F2.sort_indices()
     assert F2.nnz == F.nnz and not np.array_equal(F2.indices, F.indices)
     blk2 = SimpleNamespace(rowptr=F2.indptr, col=F2.indices, val=F2.data, rows=n, cols=n)

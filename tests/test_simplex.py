@@ -141,3 +141,55 @@ def test_device_handoff_lists_are_a_transposition_of_the_cell_lists(tmp_path):
             assert s.cell_p[code // 3, code % 3] == j
     # outlet weights: integral of phi_n . n over the outlet = its length for the sum of all shape functions (partition of unity)
     assert abs(h["outlet_w"][0::2].sum() - 0.41) < 1e-14 and abs(h["outlet_w"][1::2].sum()) < 1e-14
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_rank_layout_of_a_gmsh_mesh(nranks):
+    """Several ranks with -M: balanced coordinate bisection, every DoF owned by the lowest rank of its cells, contiguous
+    owned ranges, and the ranks' local blocks (owned rows, owned-first / ghost-appended columns) stitched back together
+    give the one-rank operators; ghost lists feed `build_halo_plan`; the ranks' obstacle forces add up."""
+    from navier_stokes_solver_amd import partition as PT
+    s = SX.build_space(G.read_msh(REF_MESH))
+    lay = SX.rank_layout(s, nranks)
+    cnt = np.bincount(lay.cell_rank, minlength=nranks)
+    assert cnt.sum() == len(s.cell_u) and cnt.max() - cnt.min() <= 1
+    rng = np.random.default_rng(3)
+    free = np.repeat(s.dirichlet == 0, 2)
+    pr = SX.assemble(s, 1.0 / 30.0, mode=1, state=(0.05 * rng.uniform(-1, 1, s.n_u) * free, rng.uniform(-1, 1, s.n_p)), inlet_bc=1)
+    parts = [SX.local_problem(pr, lay, r) for r in range(nranks)]
+    du, dp = lay.dof_new()
+    assert sorted(du.tolist()) == list(range(s.n_u)) and sorted(dp.tolist()) == list(range(s.n_p))
+    xu, xp = rng.uniform(-1, 1, s.n_u), rng.uniform(-1, 1, s.n_p)
+    xun, xpn = np.empty_like(xu), np.empty_like(xp)
+    xun[du], xpn[dp] = xu, xp
+    yu = pr.F.to_scipy() @ xu + pr.Bt.to_scipy() @ xp
+    yp = pr.B.to_scipy() @ xu
+    ym = pr.Mp.to_scipy() @ xp
+    for r, q in enumerate(parts):
+        u0, u1, p0, p1 = lay.u_ranges[r], lay.u_ranges[r + 1], lay.p_ranges[r], lay.p_ranges[r + 1]
+        assert (q.n_u, q.n_p) == (u1 - u0, p1 - p0) and np.all(np.diff(q.ghost_u) > 0) and np.all(np.diff(q.ghost_p) > 0)
+        assert not np.any((q.ghost_u >= u0) & (q.ghost_u < u1)) and len(q.ghost_u) % 2 == 0
+        lu = np.concatenate([xun[u0:u1], xun[q.ghost_u]])
+        lp = np.concatenate([xpn[p0:p1], xpn[q.ghost_p]])
+        got_u = np.empty(s.n_u); got_u[:] = np.nan
+        assert np.allclose(q.F.to_scipy() @ lu + q.Bt.to_scipy() @ lp, yu[np.argsort(du)][u0:u1], rtol=0, atol=1e-13)
+        assert np.allclose(q.B.to_scipy() @ lu, yp[np.argsort(dp)][p0:p1], rtol=0, atol=1e-13)
+        assert np.allclose(q.Mp.to_scipy() @ lp, ym[np.argsort(dp)][p0:p1], rtol=0, atol=1e-12)
+        # (0,1) rows of the ghost velocity DoFs: the rows their owners hold
+        bt = pr.Bt.to_scipy()
+        assert np.allclose(q.Bt_ghost.to_scipy() @ lp, (bt @ xp)[np.argsort(du)][q.ghost_u], rtol=0, atol=1e-13)
+    gu, gp = [q.ghost_u for q in parts], [q.ghost_p for q in parts]
+    for r in range(nranks):
+        pl = PT.build_halo_plan(r, lay.u_ranges, gu)
+        assert pl["recv_ptr"][-1] == len(gu[r]) and rank_not_in(pl["peers"], r)
+        PT.build_halo_plan(r, lay.p_ranges, gp)
+    back_u, back_p = SX.gather_solution(lay, [xun[lay.u_ranges[r]:lay.u_ranges[r + 1]] for r in range(nranks)],
+                                        [xpn[lay.p_ranges[r]:lay.p_ranges[r + 1]] for r in range(nranks)])
+    assert np.array_equal(back_u, xu) and np.array_equal(back_p, xp)
+    tot = [SX.lift_drag_rank(s, lay, r, xu, xp, 0.1) for r in range(nranks)]
+    d1, l1 = SX.lift_drag(s, xu, xp, 0.1)
+    assert abs(sum(t[0] for t in tot) - d1) <= 1e-12 * abs(d1) and abs(sum(t[1] for t in tot) - l1) <= 1e-12 * abs(d1)
+
+
+def rank_not_in(peers, r):
+    return r not in set(int(p) for p in peers)
