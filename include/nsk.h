@@ -89,6 +89,13 @@ enum {
   NSK_OPT_VELOCITY_AMG = 10,  /* stationary blockTriangular: 1 (default) precondition F with the smoothed-aggregation AMG
                                  V-cycle (the reference configures TrilinosWrappers::PreconditionAMG there,
                                  NSSolverStationary.hpp:225,231); 0: ILU(0), as the unsteady variant does */
+  NSK_OPT_TRI_LINE_GROUPS = 12 /* 1 (default): when support points were handed over (nsk_set_support_points) the multicolour
+                                 ordering colours short LINE GROUPS — neighbours on a line of constant y: pairs of velocity
+                                 nodes, triples of pressure DoFs — instead of single DoFs, and the members of a group are
+                                 solved one after the other inside a workgroup: fewer colours (12 instead of 17-18 for F,
+                                 17 instead of 29-31 for the Schur complement on the reference's lattices) at the same or
+                                 lower inner iteration counts; still ILU(0)/SGS of a symmetrically permuted matrix
+                                 (nsk_tri_get_perm).  0: colour the DoFs one by one */
 };
 
 typedef struct {
@@ -119,6 +126,11 @@ const char *nsk_last_error(nsk_handle h);
 /* Row partition of one block space: owned global range and ghost global ids (ColMap order). */
 int nsk_set_partition(nsk_handle h, int space, int64_t owned_begin, int64_t owned_end, int n_ghost,
                       const int32_t *ghost_gids);
+/* Optional: support points of the owned DoFs of one space, xy[2 d] = x, xy[2 d + 1] = y of owned DoF d — what
+ * DoFTools::map_dofs_to_support_points(mapping, dof_handler) gives the reference's caller (both velocity components of a
+ * node share their point).  Used for the ordering of the triangular factors only (NSK_OPT_TRI_LINE_GROUPS); NULL drops
+ * them.  Call after nsk_set_partition and before nsk_setup_preconditioner. */
+int nsk_set_support_points(nsk_handle h, int space, const double *xy);
 /* Halo plan of one space (what Epetra_Import holds): for neighbour k, send owned local ids
  * send_idx[send_ptr[k]..send_ptr[k+1]) and receive ghost slots [recv_ptr[k], recv_ptr[k+1]). */
 int nsk_set_halo_plan(nsk_handle h, int space, int n_neighbors, const int32_t *peer_rank, const int32_t *send_ptr,

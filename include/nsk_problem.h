@@ -110,6 +110,11 @@ const uint8_t *nsp_cell_flags(const nsp_mesh *m);
 int32_t nsp_cell_of_dof0(const nsp_mesh *m); /* local index of the cell holding global DoF 0 as its node 0, or -1 */
 void nsp_cell_tables(const nsp_mesh *m, double *out944);
 
+/* Support points of this rank's owned DoFs (what DoFTools::map_dofs_to_support_points gives the reference's caller):
+ * out_xy[2 d], out_xy[2 d + 1] = (x, y) of owned DoF d of `space` (0: velocity, both components of a node share the
+ * point; 1: pressure).  Valid after nsp_mesh_create; sizes 2 * (u_end - u_begin) and 2 * (p_end - p_begin). */
+void nsp_support_points(const nsp_mesh *m, int space, double *out_xy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,10 @@ struct nsk_handle_s {
   bool outer_fused_gs = false, cg_fused = false;
   int use_bsr = 1;
   int sync_free_fallbacks = 0;
+  // support points of the owned DoFs (nsk_set_support_points) and the line-group sizes of the triangular factors
+  std::vector<double> support[2];
+  int line_groups = 1, group_u = 2, group_p = 3;   // NSK_OPT_TRI_LINE_GROUPS, NSK_IOPT_GROUP_U / _P
+  const double *xy(int space) const { return line_groups && !support[space].empty() ? support[space].data() : nullptr; }
   int x_layout_mode = 2;   // NSK_IOPT_TRI_X_LAYOUT
   int sync_free_mode = 2;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
   int fault_inject = 0;    // NSK_IOPT_FAULT_INJECT
@@ -388,7 +392,7 @@ void H::setup(int type, int variant_, double alpha_) {
   prec_type = type;
   variant = variant_;
   alpha = alpha_;
-  const int key = tri_ordering * 100000 + subdomains;
+  const int key = ((tri_ordering * 1000 + subdomains) * 2 + (line_groups ? 1 : 0)) * 100 + group_u * 10 + group_p;
   Csr &F = blk[NSK_BLK_F];
   // kinds: blockDiagonal stationary = SSOR/SSOR, unsteady = ILU/ILU; blockTriangular = (AMG->ILU)/ILU; aSIMPLE = ILU/ILU
   const int kindF = (type == 0 && variant == 0) ? 1 : 0;
@@ -403,7 +407,8 @@ void H::setup(int type, int variant_, double alpha_) {
     amgF.clear();
     if (!tF_ok || tF_key != key) {
       Phase ph("analyse F factor (host)");
-      tF.analyze(&ctx, F, kindF, tri_ordering, sub_offsets(0), use_bsr && F.blk_ok && F.blk_R == 2 && F.blk_C == 2);
+      tF.analyze(&ctx, F, kindF, tri_ordering, sub_offsets(0), use_bsr && F.blk_ok && F.blk_R == 2 && F.blk_C == 2, xy(0),
+                 group_u);
       tF_ok = true;
       tF_key = key;
     }
@@ -431,7 +436,7 @@ void H::setup(int type, int variant_, double alpha_) {
                         S.col.p, S.val.p, S.n_rows, std::max(1, s_max_row));
     if (!tS_ok || tS_key != key) {
       Phase ph("analyse S factor (host)");
-      tS.analyze(&ctx, S, 0, tri_ordering, sub_offsets(1));
+      tS.analyze(&ctx, S, 0, tri_ordering, sub_offsets(1), false, xy(1), group_p);
       tS_ok = true;
       tS_key = key;
     }
@@ -444,7 +449,7 @@ void H::setup(int type, int variant_, double alpha_) {
     Csr &Mp = blk[NSK_BLK_MP];
     if (!Mp.present) throw Error(-45, "this preconditioner needs pressure_mass.block(1,1)");
     if (!tMp_ok || tMp_key != key) {
-      tMp.analyze(&ctx, Mp, kindP, tri_ordering, sub_offsets(1));
+      tMp.analyze(&ctx, Mp, kindP, tri_ordering, sub_offsets(1), false, xy(1), group_p);
       tMp_ok = true;
       tMp_key = key;
     }
@@ -652,6 +657,28 @@ int nsk_local_group_id(int nranks, void *out128) {
   return 0;
 }
 
+// Host-only (no handle, no GPU): the ordering TriSolve::analyze would choose for this pattern.  nsk_internal.h
+int nsk_debug_tri_ordering(int n, const int32_t *rowptr, const int32_t *col, int n_sub, const int32_t *sub_off,
+                           int want_block2, const double *xy, int group, int32_t *perm_out, int32_t *info4,
+                           uint8_t *chain_out) {
+  try {
+    std::vector<int> off;
+    if (n_sub > 1 && sub_off) off.assign(sub_off, sub_off + n_sub + 1);
+    TriOrdering O;
+    O.build(n, rowptr, col, ORDER_MULTICOLOR, off, want_block2 != 0, xy, group);
+    for (int i = 0; i < n; ++i) perm_out[i] = O.perm[i];
+    info4[0] = O.n_colors;
+    info4[1] = O.gmax;
+    info4[2] = O.block2 ? 1 : 0;
+    info4[3] = (int)O.cpos.size();
+    if (chain_out)
+      for (size_t i = 0; i < O.cpos.size(); ++i) chain_out[i] = (uint8_t)(O.cpos[i] | (O.clen[i] << 4));
+    return 0;
+  } catch (const std::exception &) {
+    return -1;
+  }
+}
+
 int nsk_local_group_id_mode(int nranks, int on_stream, void *out128) {   // nsk_internal.h
   if (nranks < 1 || !out128) return -1;
   make_local_group(nranks, out128, on_stream);
@@ -706,6 +733,17 @@ int nsk_set_partition(nsk_handle h, int space, int64_t b, int64_t e, int n_ghost
   S.gbegin = b;
   S.gend = e;
   S.ghost_gid.assign(gids, gids + n_ghost);
+  return 0;
+  NSK_CATCH(h)
+}
+
+int nsk_set_support_points(nsk_handle h, int space, const double *xy) {
+  NSK_TRY(h)
+  if (space < 0 || space > 1) throw Error(-50, "nsk_set_support_points: bad space");
+  const Space &S = h->sp[space];
+  if (xy) h->support[space].assign(xy, xy + 2 * (size_t)S.n);
+  else h->support[space].clear();
+  h->tF_ok = h->tMp_ok = h->tS_ok = false;   // the orderings of the triangular factors depend on them
   return 0;
   NSK_CATCH(h)
 }
@@ -809,6 +847,12 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
       h->tMp.sf_fault = h->tS.sf_fault = (h->fault_inject & 1) != 0;
       h->tF.sf_fault = (h->fault_inject & 2) != 0;
       h->ctx.mgs_fault = (h->fault_inject & 4) != 0;
+      break;
+    case NSK_OPT_TRI_LINE_GROUPS: h->line_groups = v != 0.0; break;
+    case NSK_IOPT_GROUP_U:
+    case NSK_IOPT_GROUP_P:
+      if (v < 1.0 || v > (double)kTriGroupMax) throw Error(-61, "line-group size: 1 .. 3");
+      (opt == NSK_IOPT_GROUP_U ? h->group_u : h->group_p) = (int)v;
       break;
     case NSK_IOPT_FUSED_MGS: h->ctx.fused_mgs = v != 0.0; break;
     case NSK_IOPT_OVERLAP_HALO: h->overlap_halo = v != 0.0; break;

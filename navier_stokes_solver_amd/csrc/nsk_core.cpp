@@ -493,7 +493,7 @@ void Ctx::spmv(Csr &A, Space &colspace, const DVec &x, double *y, int mode, cons
 }
 
 bool build_rowblocks(const int *ra, const int *rb, int n_rows, int max_nnz, const std::vector<int> *cuts,
-                     std::vector<int> &rowblk) {
+                     std::vector<int> &rowblk, const unsigned char *glue) {
   rowblk.clear();
   rowblk.push_back(0);
   size_t ci = 0;
@@ -505,6 +505,14 @@ bool build_rowblocks(const int *ra, const int *rb, int n_rows, int max_nnz, cons
     int r1 = r0 + 1;
     if (nnz_of(r0, r1) > max_nnz) return false;
     while (r1 < limit && r1 - r0 < kStreamRows && nnz_of(r0, r1 + 1) <= max_nnz) ++r1;
+    if (glue) {   // glue[r]: row r stays with row r - 1 (never the first row after a cut)
+      while (r1 < limit && r1 > r0 && glue[r1]) --r1;
+      if (r1 == r0) {   // the rows glued to r0 do not fit one run together
+        r1 = r0 + 1;
+        while (r1 < limit && glue[r1]) ++r1;
+        if (r1 - r0 > kStreamRows || nnz_of(r0, r1) > max_nnz) return false;
+      }
+    }
     rowblk.push_back(r1);
     r0 = r1;
   }

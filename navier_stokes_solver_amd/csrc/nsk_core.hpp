@@ -146,8 +146,9 @@ struct Csr {  // device CSR block with host copy of the pattern
 // Greedy runs of whole rows with at most max_nnz non-zeros (counted over rowptr_a [+ rowptr_b]);
 // `cuts` (ascending row ids, may be null) are boundaries no run may cross.  Returns false when a
 // single row exceeds max_nnz.
+// `glue` (may be null): glue[r] != 0 keeps row r in the run of row r - 1.
 bool build_rowblocks(const int *rowptr_a, const int *rowptr_b, int n_rows, int max_nnz, const std::vector<int> *cuts,
-                     std::vector<int> &rowblk);
+                     std::vector<int> &rowblk, const unsigned char *glue = nullptr);
 
 inline int pick_lpr(int64_t nnz, int n_rows) {
   const double mean = n_rows > 0 ? (double)nnz / n_rows : 0.0;

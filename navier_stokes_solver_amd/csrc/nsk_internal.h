@@ -10,6 +10,8 @@ enum {
                                 // bit 1: the blocked velocity solve walks its upper half backwards — consumers before
                                 // producers, so the bounded spins give up and the fallback has to take over;
                                 // bit 2: workgroup 0 of the one-launch Gram-Schmidt sweep withholds its first partial sum
+  NSK_IOPT_GROUP_U = 103,      // members per line group of the velocity factor (nodes; default 2) and of the scalar
+  NSK_IOPT_GROUP_P = 104,      // factors S, Mp (DoFs; default 3); 1 = plain colouring.  See NSK_OPT_TRI_LINE_GROUPS
   NSK_IOPT_TINY_BYTES = 102,    // triangular factors below this many bytes (default 4e6) are solved by ONE workgroup walking
                                 // all levels; the tests set 0 to run the streamed kernels on small meshes
   NSK_IOPT_OVERLAP_HALO = 107,  // 1 (default): several ranks — interior rows of the inner solvers' SpMVs (F, S, Mp) run on a
@@ -34,6 +36,12 @@ int nsk_debug_tri_trace(struct nsk_handle_s *h, int which, int64_t *out16, int m
  * threads only rendezvous), so the second-stream overlap of the SpMVs and the grouped exchange race as they would under
  * RCCL; on_stream = 0 is nsk_local_group_id (streams synchronised with the host around every collective). */
 int nsk_local_group_id_mode(int nranks, int on_stream, void *out128);
+/* Host-only (no handle, no GPU): the multicolour ordering the triangular-solve analysis chooses for a local pattern —
+ * perm_out[new] = old; info4 = {colours, largest line group, node structure found, items}; chain_out (may be null): per
+ * permuted item position | length << 4 in its line group.  xy: 2 doubles per row or null; group: members per group. */
+int nsk_debug_tri_ordering(int n, const int32_t *rowptr, const int32_t *col, int n_sub, const int32_t *sub_off,
+                           int want_block2, const double *xy, int group, int32_t *perm_out, int32_t *info4,
+                           uint8_t *chain_out);
 #ifdef __cplusplus
 }
 #endif

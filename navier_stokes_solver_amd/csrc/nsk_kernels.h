@@ -186,13 +186,27 @@ void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra);
 // needs no separate flag or fence).  Producers are always in lower-indexed workgroups, which the dispatcher
 // starts first; every spin is bounded and raises *err instead of hanging.
 void vec_fill_sentinel(hipStream_t s, int n, double *y);
+// Line groups (nsk_tri.hpp): the rows of a group are consecutive rows of one run and are finished one after the other
+// inside the workgroup.  chain[r] = position | length << 4; cpl holds, per row, kTriGroupMax - 1 couplings to the members
+// before it (lower half) / after it (upper half), nearest first — scalars, or 2x2 blocks (4 doubles) for the node-block
+// kernel.  gmax = 1 (chain, cpl null): no groups.
+constexpr int kTriGroupMax = 3;
+struct TriChain {
+  int gmax;
+  const unsigned char *chain;
+  const double *cpl;
+};
 void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int n_blocks, int lower, int kind, int run_nnz,
                          int wrong_order /* test hook */, const double *dinv, const int *perm, const double *rhs,
                          const double *own, double *w, double *reset /* gets the sentinel at the rows' positions */,
-                         int *err, long long *dbg = nullptr /* diagnostics: 16 int64 per workgroup */);
+                         int *err, long long *dbg = nullptr /* diagnostics: 16 int64 per workgroup */,
+                         TriChain chain = TriChain{1, nullptr, nullptr});
 void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int n_blocks, int lower, int kind, int permx,
                       int wrong_order /* test hook */, const double *intra, const int *permn, const double *rhs,
-                      const double *own, double *w, double *out, double *reset, int *err);
+                      const double *own, double *w, double *out, double *reset, int *err,
+                      TriChain chain = TriChain{1, nullptr, nullptr});
+// y[i] = idx[i] >= 0 ? x[idx[i]] : 0
+void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, double *y);
 
 
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)

@@ -471,14 +471,16 @@ __device__ __forceinline__ double sf_wait(const double *p, unsigned long long fi
   return __longlong_as_double((long long)v);
 }
 
-template <int LOWER, int KIND, int NNZ>
+template <int LOWER, int KIND, int NNZ, int GMAX>
 __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const int4 *__restrict__ desc, int nb, int wrong_order,
                                                             const double *__restrict__ dinv,
                                                             const int *__restrict__ perm,
                                                             const double *__restrict__ rhs,
                                                             const double *ownv, double *w, double *reset, int *err,
-                                                            long long *dbg) {
+                                                            long long *dbg, const unsigned char *__restrict__ chain,
+                                                            const double *__restrict__ cpl) {
   __shared__ double prod[NNZ];
+  __shared__ double xs[GMAX > 1 ? kStreamRows : 1];   // results of this run's rows (line groups: the next member reads them)
   // diagnostics (dbg != null; nsk_internal.h: nsk_debug_tri_trace): time stamps of workgroup blockIdx.x
   auto stamp = [&](int k) {
     if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 16 + k] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -496,8 +498,8 @@ __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const 
   if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 16 + 9] = (long long)__builtin_amdgcn_s_memrealtime() + (r0 & 0);   // descriptor has arrived
   const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
   const bool have = r < r1;
-  int jb = 0, je = 0, i = 0;
-  double own = 0.0, dv = 1.0;
+  int jb = 0, je = 0, i = 0, cq = 0;
+  double own = 0.0, dv = 1.0, c0 = 0.0, c1 = 0.0;
   {
     constexpr int U = NNZ / BLK;
     const bool any = k0 < k1;   // (uniform) false: rows without entries; every lane then reads valid stand-in words
@@ -527,6 +529,12 @@ __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const 
         i = perm[r];
         if (KIND == 1 || !LOWER) dv = dinv[r];
         own = LOWER ? rhs[i] : ownv[i];
+        if (GMAX > 1) {   // position in the line group, counted from the member that is solved first in this half
+          const int ch = chain[r];
+          cq = LOWER ? (ch & 15) : (ch >> 4) - 1 - (ch & 15);
+          c0 = cpl[(size_t)r * (kTriGroupMax - 1)];
+          c1 = cpl[(size_t)r * (kTriGroupMax - 1) + 1];
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -571,16 +579,28 @@ __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const 
   stamp(2);
   __syncthreads();
   stamp(3);
-  const double sum = row_sum_lds(prod, jb, je, lane);
-  if (have && lane == 0) {
-    double x;
-    if (LOWER) x = KIND == 0 ? (own - sum) : (own - sum) * dv;
-    else x = KIND == 0 ? (own - sum) * dv : own - sum * dv;
-    sf_store(w + i, x);
-    // leave the sentinel where the NEXT launch expects it (no separate fill launches): the lower half arms the
-    // upper half's result vector, the upper half re-arms the lower result it has just consumed (every other reader
-    // of that entry ran in the lower launch, which has completed)
-    reinterpret_cast<unsigned long long *>(reset)[i] = kSentinel;
+  double sum = row_sum_lds(prod, jb, je, lane);
+  // the members of a line group one after the other: member q adds its couplings to the members solved before it
+  // (their results are in xs) and publishes its own; GMAX = 1: every row at once
+#pragma unroll
+  for (int q = 0; q < GMAX; ++q) {
+    if (have && lane == 0 && cq == q) {
+      if (GMAX > 1) {
+        const int slot = r - r0;
+        if (q >= 1) sum += c0 * xs[LOWER ? slot - 1 : slot + 1];
+        if (q >= 2) sum += c1 * xs[LOWER ? slot - 2 : slot + 2];
+      }
+      double x;
+      if (LOWER) x = KIND == 0 ? (own - sum) : (own - sum) * dv;
+      else x = KIND == 0 ? (own - sum) * dv : own - sum * dv;
+      if (GMAX > 1) xs[r - r0] = x;
+      sf_store(w + i, x);
+      // leave the sentinel where the NEXT launch expects it (no separate fill launches): the lower half arms the
+      // upper half's result vector, the upper half re-arms the lower result it has just consumed (every other reader
+      // of that entry ran in the lower launch, which has completed)
+      reinterpret_cast<unsigned long long *>(reset)[i] = kSentinel;
+    }
+    if (q + 1 < GMAX) __syncthreads();
   }
   stamp(4);
   if (dbg && threadIdx.x == 0) {
@@ -593,15 +613,18 @@ __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const 
 // PERMX = 1: the working vectors (ownv, x) are in colour order (node r at 2 r) and M.col holds colour-order node
 // ids: a colour then only touches the segments of the colours it depends on.  The lower half gathers rhs through
 // permn, the upper half also writes its result to out[permn[r]] in the caller's order.
-template <int LOWER, int KIND, int PERMX>
+template <int LOWER, int KIND, int PERMX, int GMAX>
 __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int wrong_order,
                                                          const double *__restrict__ intra,
                                                          const int *__restrict__ permn,
                                                          const double *__restrict__ rhs,
                                                          const double *ownv, double *x,
-                                                         double *__restrict__ out, double *reset, int *err) {
+                                                         double *__restrict__ out, double *reset, int *err,
+                                                         const unsigned char *__restrict__ chain,
+                                                         const double *__restrict__ cpl) {
   __shared__ double p0[kBlkMax];
   __shared__ double p1[kBlkMax];
+  __shared__ double2 xs[GMAX > 1 ? kStreamRows : 1];   // results of this run's node rows (line groups)
   // M.desc is in DISPATCH order (TriSolve::sf_dispatch_order): colours in dependency order, so producers sit in
   // workgroups the dispatcher has started earlier; inside a colour (padded to a multiple of 8 with empty runs) the
   // runs are dealt so that XCD k works on the k-th eighth of every colour.  wrong_order (test hook): walk the list
@@ -613,7 +636,9 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int w
   const bool have = r < r1;
   int jb = 0, je = 0;
   size_t i = 0;
+  int cq = 0;
   double2 own = make_double2(0.0, 0.0), cf = make_double2(0.0, 0.0), di = make_double2(1.0, 1.0);
+  double2 ca0 = make_double2(0.0, 0.0), ca1 = ca0, cb0 = ca0, cb1 = ca0;   // couplings to the nearest / next member
   if (have) {
     jb = M.rowptr[r] - k0;
     je = M.rowptr[r + 1] - k0;
@@ -622,6 +647,13 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int w
     own = *reinterpret_cast<const double2 *>(LOWER ? rhs + ic : ownv + i);
     cf = *reinterpret_cast<const double2 *>(intra + 4 * (size_t)r);
     di = *reinterpret_cast<const double2 *>(intra + 4 * (size_t)r + 2);
+    if (GMAX > 1 && lane == 0) {
+      const int ch = chain[r];
+      cq = LOWER ? (ch & 15) : (ch >> 4) - 1 - (ch & 15);
+      const double *c = cpl + (size_t)r * (4 * (kTriGroupMax - 1));
+      if (cq >= 1) { ca0 = *reinterpret_cast<const double2 *>(c); ca1 = *reinterpret_cast<const double2 *>(c + 2); }
+      if (cq >= 2) { cb0 = *reinterpret_cast<const double2 *>(c + 4); cb1 = *reinterpret_cast<const double2 *>(c + 6); }
+    }
   }
   {
     constexpr int U = kBlkMax / BLK;
@@ -655,22 +687,41 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int w
     }
   }
   __syncthreads();
-  const double s0 = row_sum_lds(p0, jb, je, lane), s1 = row_sum_lds(p1, jb, je, lane);
-  if (have && lane == 0) {
-    double v0, v1;
-    if (LOWER) {
-      if (KIND == 0) { v0 = own.x - s0; v1 = own.y - s1 - cf.x * v0; }
-      else { v0 = (own.x - s0) * di.x; v1 = (own.y - s1 - cf.x * v0) * di.y; }
-    } else {
-      if (KIND == 0) { v1 = (own.y - s1) * di.y; v0 = (own.x - s0 - cf.y * v1) * di.x; }
-      else { v1 = own.y - s1 * di.y; v0 = own.x - (s0 + cf.y * v1) * di.x; }
+  double s0 = row_sum_lds(p0, jb, je, lane), s1 = row_sum_lds(p1, jb, je, lane);
+  // the members of a line group one after the other (see tri_stream_sf_kernel); GMAX = 1: every node row at once
+#pragma unroll
+  for (int q = 0; q < GMAX; ++q) {
+    if (have && lane == 0 && cq == q) {
+      if (GMAX > 1) {
+        const int slot = r - r0;
+        if (q >= 1) {
+          const double2 xa = xs[LOWER ? slot - 1 : slot + 1];
+          s0 += ca0.x * xa.x + ca0.y * xa.y;
+          s1 += ca1.x * xa.x + ca1.y * xa.y;
+        }
+        if (q >= 2) {
+          const double2 xb = xs[LOWER ? slot - 2 : slot + 2];
+          s0 += cb0.x * xb.x + cb0.y * xb.y;
+          s1 += cb1.x * xb.x + cb1.y * xb.y;
+        }
+      }
+      double v0, v1;
+      if (LOWER) {
+        if (KIND == 0) { v0 = own.x - s0; v1 = own.y - s1 - cf.x * v0; }
+        else { v0 = (own.x - s0) * di.x; v1 = (own.y - s1 - cf.x * v0) * di.y; }
+      } else {
+        if (KIND == 0) { v1 = (own.y - s1) * di.y; v0 = (own.x - s0 - cf.y * v1) * di.x; }
+        else { v1 = own.y - s1 * di.y; v0 = own.x - (s0 + cf.y * v1) * di.x; }
+      }
+      if (GMAX > 1) xs[r - r0] = make_double2(v0, v1);
+      if (PERMX && !LOWER) *reinterpret_cast<double2 *>(out + 2 * (size_t)permn[r]) = make_double2(v0, v1);
+      sf_store(x + i, v0);
+      sf_store(x + i + 1, v1);
+      // arm the vector of the next launch (see tri_stream_sf_kernel)
+      reinterpret_cast<unsigned long long *>(reset)[i] = kSentinel;
+      reinterpret_cast<unsigned long long *>(reset)[i + 1] = kSentinel;
     }
-    if (PERMX && !LOWER) *reinterpret_cast<double2 *>(out + 2 * (size_t)permn[r]) = make_double2(v0, v1);
-    sf_store(x + i, v0);
-    sf_store(x + i + 1, v1);
-    // arm the vector of the next launch (see tri_stream_sf_kernel)
-    reinterpret_cast<unsigned long long *>(reset)[i] = kSentinel;
-    reinterpret_cast<unsigned long long *>(reset)[i + 1] = kSentinel;
+    if (q + 1 < GMAX) __syncthreads();
   }
 }
 
@@ -1118,33 +1169,59 @@ void vec_fill_sentinel(hipStream_t s, int n, double *y) {
 }
 void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int kind, int run_nnz, int wrong_order,
                          const double *dinv, const int *perm, const double *rhs, const double *own, double *w,
-                         double *reset, int *err, long long *dbg) {
+                         double *reset, int *err, long long *dbg, TriChain ch) {
   if (nb <= 0) return;
-#define NSK_SF(L, K, N) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N>), dim3(nb), dim3(BLK), 0, s, M, M.desc, nb, wrong_order, dinv, perm, rhs, own, w, reset, err, dbg)
+#define NSK_SF(L, K, N, G) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N, G>), dim3(nb), dim3(BLK), 0, s, M, M.desc, nb, wrong_order, dinv, perm, rhs, own, w, reset, err, dbg, ch.chain, ch.cpl)
+#define NSK_SFG(L, K, N)                                   \
+  do {                                                     \
+    if (ch.gmax <= 1) NSK_SF(L, K, N, 1);                  \
+    else if (ch.gmax == 2) NSK_SF(L, K, N, 2);             \
+    else NSK_SF(L, K, N, 3);                               \
+  } while (0)
 #define NSK_SFN(L, K)                                      \
   do {                                                     \
-    if (run_nnz <= 512) NSK_SF(L, K, 512);                 \
-    else if (run_nnz <= 1024) NSK_SF(L, K, 1024);          \
-    else NSK_SF(L, K, 2048);                               \
+    if (run_nnz <= 512) NSK_SFG(L, K, 512);                \
+    else if (run_nnz <= 1024) NSK_SFG(L, K, 1024);         \
+    else NSK_SFG(L, K, 2048);                              \
   } while (0)
   if (lower) { if (kind == 0) NSK_SFN(1, 0); else NSK_SFN(1, 1); }
   else { if (kind == 0) NSK_SFN(0, 0); else NSK_SFN(0, 1); }
 #undef NSK_SFN
+#undef NSK_SFG
 #undef NSK_SF
 }
 void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int nb, int lower, int kind, int permx, int wrong_order,
                       const double *intra, const int *permn, const double *rhs, const double *own, double *w, double *out,
-                      double *reset, int *err) {
+                      double *reset, int *err, TriChain ch) {
   if (nb <= 0) return;
-#define NSK_SB(L, K, P) hipLaunchKernelGGL((tri_blk_sf_kernel<L, K, P>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, intra, permn, rhs, own, w, out, reset, err)
+#define NSK_SB(L, K, P, G) hipLaunchKernelGGL((tri_blk_sf_kernel<L, K, P, G>), dim3(nb), dim3(BLK), 0, s, M, nb, wrong_order, intra, permn, rhs, own, w, out, reset, err, ch.chain, ch.cpl)
+#define NSK_SBG(L, K, P)                                   \
+  do {                                                     \
+    if (ch.gmax <= 1) NSK_SB(L, K, P, 1);                  \
+    else if (ch.gmax == 2) NSK_SB(L, K, P, 2);             \
+    else NSK_SB(L, K, P, 3);                               \
+  } while (0)
   if (permx) {
-    if (lower) { if (kind == 0) NSK_SB(1, 0, 1); else NSK_SB(1, 1, 1); }
-    else { if (kind == 0) NSK_SB(0, 0, 1); else NSK_SB(0, 1, 1); }
+    if (lower) { if (kind == 0) NSK_SBG(1, 0, 1); else NSK_SBG(1, 1, 1); }
+    else { if (kind == 0) NSK_SBG(0, 0, 1); else NSK_SBG(0, 1, 1); }
   } else {
-    if (lower) { if (kind == 0) NSK_SB(1, 0, 0); else NSK_SB(1, 1, 0); }
-    else { if (kind == 0) NSK_SB(0, 0, 0); else NSK_SB(0, 1, 0); }
+    if (lower) { if (kind == 0) NSK_SBG(1, 0, 0); else NSK_SBG(1, 1, 0); }
+    else { if (kind == 0) NSK_SBG(0, 0, 0); else NSK_SBG(0, 1, 0); }
   }
+#undef NSK_SBG
 #undef NSK_SB
+}
+__global__ __launch_bounds__(BLK) void gather_or_zero_kernel(long n, const int *__restrict__ idx,
+                                                            const double *__restrict__ x, double *__restrict__ y) {
+  for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+    const int k = idx[i];
+    y[i] = k >= 0 ? x[k] : 0.0;
+  }
+}
+void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, double *y) {
+  if (n <= 0) return;
+  const int grid = (int)std::min<long>(65535 * 8, (n + BLK * 4 - 1) / (BLK * 4));
+  hipLaunchKernelGGL(gather_or_zero_kernel, dim3(grid), dim3(BLK), 0, s, n, idx, x, y);
 }
 void invert_node_diagonals(hipStream_t s, int n_nodes, double *intra) {
   const int n = n_nodes;

@@ -69,6 +69,81 @@ int greedy_color(int nv, const std::vector<int> &grp, const std::vector<int> &gc
   return ncol;
 }
 
+// Line groups: up to g items (rows, or velocity nodes) that follow each other on a line of constant y of their support
+// points, each a graph neighbour of the one before, never across emulated sub-domains.  A group is coloured as ONE vertex
+// (its members are solved one after the other inside a workgroup), which needs fewer colours than colouring the items:
+// on the reference's lattices 12 instead of 17-18 node colours for F (pairs) and 17 instead of 29-31 for the Schur
+// complement (triples) at the same or lower inner iteration counts (CPU study in DESIGN.md) — the flow runs along x,
+// and so does the natural ordering the ILU quality comes from.  Without support points, or on meshes without such
+// lines, every group has one member and this is the plain greedy colouring.
+// Output: members of group q are grp_items[grp_ptr[q] .. grp_ptr[q+1]) in +x order; groups ordered by first member.
+static void line_groups(int ni, const std::vector<int> &irp, const std::vector<int> &icol, const double *xy, int xy_stride,
+                        const int *shard_of_item, int g, std::vector<int> &grp_ptr, std::vector<int> &grp_items) {
+  grp_ptr.clear();
+  grp_items.clear();
+  std::vector<int> grp_of((size_t)ni, -1), nxt((size_t)ni, -1);   // nxt: the following member of an item's group
+  std::vector<char> head((size_t)ni, 1);
+  if (g > 1 && xy && ni > 1) {
+    double ymin = xy[1], ymax = xy[1];
+    for (int i = 1; i < ni; ++i) {
+      const double y = xy[(size_t)i * xy_stride + 1];
+      ymin = std::min(ymin, y);
+      ymax = std::max(ymax, y);
+    }
+    const double q = (ymax - ymin) * 1e-7 + 1e-300;
+    std::vector<std::pair<std::pair<int64_t, double>, int>> key((size_t)ni);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < ni; ++i)
+      key[i] = {{(int64_t)std::llround((xy[(size_t)i * xy_stride + 1] - ymin) / q), xy[(size_t)i * xy_stride]}, i};
+    std::sort(key.begin(), key.end());
+    // column rank of every item: index of its x among the distinct x values.  Groups are cut at multiples of g of this
+    // rank, so that the groups of neighbouring lines sit on top of each other (lines that start behind the obstacle would
+    // otherwise pair with the other parity, and the ILU of such a brick pattern is measurably worse)
+    std::vector<int> xrank((size_t)ni);
+    {
+      double xmin = xy[0], xmax = xy[0];
+      for (int i = 1; i < ni; ++i) {
+        xmin = std::min(xmin, xy[(size_t)i * xy_stride]);
+        xmax = std::max(xmax, xy[(size_t)i * xy_stride]);
+      }
+      const double qx = (xmax - xmin) * 1e-7 + 1e-300;
+      std::vector<std::pair<int64_t, int>> xs((size_t)ni);
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < ni; ++i) xs[i] = {(int64_t)std::llround((xy[(size_t)i * xy_stride] - xmin) / qx), i};
+      std::sort(xs.begin(), xs.end());
+      int rank = 0;
+      for (int k = 0; k < ni; ++k) {
+        if (k > 0 && xs[k].first != xs[k - 1].first) ++rank;
+        xrank[xs[k].second] = rank;
+      }
+    }
+    auto adjacent = [&](int a, int b) {
+      for (int k = irp[a]; k < irp[a + 1]; ++k)
+        if (icol[k] == b) return true;
+      return false;
+    };
+    int len = 1;
+    for (int k = 1; k < ni; ++k) {
+      const int a = key[k - 1].second, b = key[k].second;
+      const bool same_line = key[k].first.first == key[k - 1].first.first;
+      const bool same_shard = !shard_of_item || shard_of_item[a] == shard_of_item[b];
+      const bool same_cell = xrank[b] == xrank[a] + 1 && xrank[b] / g == xrank[a] / g;
+      if (same_line && same_shard && same_cell && len < g && adjacent(a, b) && adjacent(b, a)) {
+        nxt[a] = b;
+        head[b] = 0;
+        ++len;
+      } else len = 1;
+    }
+  }
+  // groups in the order of their first member's index: the order the greedy colouring visits them in
+  grp_ptr.push_back(0);
+  for (int i = 0; i < ni; ++i) {
+    if (!head[i]) continue;
+    for (int m = i; m >= 0; m = nxt[m]) grp_items.push_back(m);
+    grp_ptr.push_back((int)grp_items.size());
+  }
+}
+
 // Dispatch order for the single-launch (sync-free) kernels.  Workgroup b of a grid lands on XCD b % 8 and
 // workgroups start in index order.  Colours follow each other in dependency order (ascending for the lower
 // half, descending for the upper half), each padded with empty runs to a multiple of 8, and inside a colour
@@ -91,18 +166,13 @@ static std::vector<int4> sf_dispatch_order(const std::vector<int4> &desc, const 
   return out;
 }
 
-void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off,
-                       bool want_block2) {
-  ctx = c;
-  n = A.n_rows;
-  kind = kind_;
-  ordering = ordering_;
-  const std::vector<int> &rp = A.h_rowptr, &cl = A.h_col;
-  if ((int)rp.size() != n + 1) throw Error(-30, "TriSolve::analyze: host pattern missing");
+// Host-only part of the analysis: restricted pattern, node structure, line groups, colouring, permutation.
+void TriOrdering::build(int n, const int *rp, const int *cl, int ordering, const std::vector<int> &sub_off, bool want_block2,
+                        const double *xy, int group) {
 
   // emulated-rank id of every row (additive Schwarz, overlap 0, inside this GPU)
-  std::vector<int> shard;
-  const bool sharded = sub_off.size() > 2;
+  shard.clear();
+  sharded = sub_off.size() > 2;
   if (sharded) {
     shard.resize(n);
     for (size_t s = 0; s + 1 < sub_off.size(); ++s)
@@ -111,7 +181,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   auto keep = [&](int i, int cc) { return cc < n && (!sharded || shard[cc] == shard[i]); };
 
   // restricted pattern R (local square block, cross-shard couplings dropped) and where each entry sits in A
-  std::vector<int> rrp(n + 1, 0);
+  rrp.assign(n + 1, 0);
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     int cnt = 0;
@@ -120,7 +190,8 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   }
   for (int i = 0; i < n; ++i) rrp[i + 1] += rrp[i];
   nnz = rrp[n];
-  std::vector<int> rcol((size_t)nnz), rpos((size_t)nnz);
+  rcol.resize((size_t)nnz);
+  rpos.resize((size_t)nnz);
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) {
     int w = rrp[i];
@@ -129,11 +200,11 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   }
 
   perm.clear();
-  std::vector<int> pcolor;
+  pcolor.clear();
   n_colors = 0;
   // 2x2 node structure of the restricted pattern (both velocity components of a node share their columns,
   // columns come in aligned pairs): colour NODES instead of DoFs, keep the two rows of a node adjacent
-  bool block2 = want_block2 && ordering == ORDER_MULTICOLOR && n > 0 && n % 2 == 0;
+  block2 = want_block2 && ordering == ORDER_MULTICOLOR && n > 0 && n % 2 == 0;
   if (block2) {
     bool ok = true;
 #pragma omp parallel for schedule(static) reduction(&& : ok)
@@ -148,32 +219,114 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     }
     block2 = ok;
   }
+  // chain position / length of every permuted ITEM (row, or velocity node when block2) inside its line group
+  cpos.clear();
+  clen.clear();
+  gmax = 1;
   if (ordering == ORDER_MULTICOLOR) {
-    std::vector<int> color;
+    // item graph: velocity nodes (block2) or rows
+    const int ni = block2 ? n / 2 : n;
+    std::vector<int> irp, icol_own;
+    const std::vector<int> *icolp = &rcol;
     if (block2) {
-      const int nn = n / 2;
-      std::vector<int> nrp(nn + 1, 0);
-      for (int r = 0; r < nn; ++r) nrp[r + 1] = nrp[r] + (rrp[2 * r + 1] - rrp[2 * r]) / 2;
-      std::vector<int> ncol((size_t)nrp[nn]);
+      irp.assign(ni + 1, 0);
+      for (int r = 0; r < ni; ++r) irp[r + 1] = irp[r] + (rrp[2 * r + 1] - rrp[2 * r]) / 2;
+      icol_own.resize((size_t)irp[ni]);
 #pragma omp parallel for schedule(static)
-      for (int r = 0; r < nn; ++r)
-        for (int k = 0; k < nrp[r + 1] - nrp[r]; ++k) ncol[(size_t)nrp[r] + k] = rcol[rrp[2 * r] + 2 * k] / 2;
-      std::vector<int> ncolor;
-      n_colors = greedy_color(nn, nrp, ncol, ncolor);
-      color.resize(n);
-      for (int i = 0; i < n; ++i) color[i] = ncolor[i / 2];
-    } else {
-      std::vector<int> rrp32(rrp.begin(), rrp.end());
-      n_colors = greedy_color(n, rrp32, rcol, color);
+      for (int r = 0; r < ni; ++r)
+        for (int k = 0; k < irp[r + 1] - irp[r]; ++k) icol_own[(size_t)irp[r] + k] = rcol[rrp[2 * r] + 2 * k] / 2;
+      icolp = &icol_own;
+    } else irp.assign(rrp.begin(), rrp.end());
+    const std::vector<int> &icol = *icolp;
+    std::vector<int> ishard;
+    if (sharded) {
+      ishard.resize(ni);
+      for (int r = 0; r < ni; ++r) ishard[r] = shard[block2 ? 2 * r : r];
     }
-    // perm: colours ascending, natural order inside a colour (counting sort, stable; a node's two rows stay adjacent)
+    // line groups (one member each without support points or with group == 1)
+    std::vector<int> gptr, gitems;
+    line_groups(ni, irp, icol, xy, block2 ? 4 : 2, sharded ? ishard.data() : nullptr, std::max(1, std::min(group, kTriGroupMax)),
+                gptr, gitems);
+    const int ng = (int)gptr.size() - 1;
+    std::vector<int> gcolor;
+    if (ng == ni) {
+      n_colors = greedy_color(ni, irp, icol, gcolor);   // gitems is the identity then
+    } else {
+      // quotient graph: groups adjacent when any of their members are
+      std::vector<int> gof((size_t)ni);
+      for (int q = 0; q < ng; ++q)
+        for (int k = gptr[q]; k < gptr[q + 1]; ++k) gof[gitems[k]] = q;
+      std::vector<int> qrp(ng + 1, 0);
+      std::vector<std::vector<int>> qrows((size_t)ng);
+#pragma omp parallel for schedule(dynamic, 1024)
+      for (int q = 0; q < ng; ++q) {
+        std::vector<int> &v = qrows[q];
+        for (int k = gptr[q]; k < gptr[q + 1]; ++k) {
+          const int it = gitems[k];
+          for (int e = irp[it]; e < irp[it + 1]; ++e)
+            if (gof[icol[e]] != q) v.push_back(gof[icol[e]]);
+        }
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+      }
+      for (int q = 0; q < ng; ++q) qrp[q + 1] = qrp[q] + (int)qrows[q].size();
+      std::vector<int> qcol((size_t)qrp[ng]);
+#pragma omp parallel for schedule(static)
+      for (int q = 0; q < ng; ++q) std::copy(qrows[q].begin(), qrows[q].end(), qcol.begin() + qrp[q]);
+      std::vector<std::vector<int>>().swap(qrows);
+      n_colors = greedy_color(ng, qrp, qcol, gcolor);
+    }
+    // perm: colours ascending; inside a colour the groups in their order, members in +x order; a node's two rows adjacent
     std::vector<int> cptr(n_colors + 1, 0);
-    for (int i = 0; i < n; ++i) ++cptr[color[i] + 1];
+    for (int q = 0; q < ng; ++q) cptr[gcolor[q] + 1] += gptr[q + 1] - gptr[q];
     for (int q = 0; q < n_colors; ++q) cptr[q + 1] += cptr[q];
+    std::vector<int> iperm_item((size_t)ni);   // permuted position -> item
+    cpos.resize(ni);
+    clen.resize(ni);
+    for (int q = 0; q < ng; ++q) {
+      const int len = gptr[q + 1] - gptr[q];
+      gmax = std::max(gmax, len);
+      for (int k = 0; k < len; ++k) {
+        const int w = cptr[gcolor[q]]++;
+        iperm_item[w] = gitems[gptr[q] + k];
+        cpos[w] = (unsigned char)k;
+        clen[w] = (unsigned char)len;
+      }
+    }
     perm.resize(n);
     pcolor.resize(n);
-    for (int i = 0; i < n; ++i) { const int w = cptr[color[i]]++; perm[w] = i; pcolor[w] = color[i]; }
+    {
+      std::vector<int> color_of_item((size_t)ni);
+      for (int q = 0; q < ng; ++q)
+        for (int k = gptr[q]; k < gptr[q + 1]; ++k) color_of_item[gitems[k]] = gcolor[q];
+      for (int w = 0; w < ni; ++w) {
+        const int it = iperm_item[w];
+        if (block2) {
+          perm[2 * w] = 2 * it; perm[2 * w + 1] = 2 * it + 1;
+          pcolor[2 * w] = pcolor[2 * w + 1] = color_of_item[it];
+        } else { perm[w] = it; pcolor[w] = color_of_item[it]; }
+      }
+    }
   }
+}
+
+void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off,
+                       bool want_block2, const double *xy, int group) {
+  ctx = c;
+  n = A.n_rows;
+  kind = kind_;
+  ordering = ordering_;
+  if ((int)A.h_rowptr.size() != n + 1) throw Error(-30, "TriSolve::analyze: host pattern missing");
+  TriOrdering O;
+  O.build(n, A.h_rowptr.data(), A.h_col.data(), ordering, sub_off, want_block2, xy, group);
+  nnz = O.nnz;
+  n_colors = O.n_colors;
+  gmax = O.gmax;
+  grouped = gmax > 1;
+  perm = O.perm;
+  const std::vector<int> &rrp = O.rrp, &rcol = O.rcol, &rpos = O.rpos, &pcolor = O.pcolor;
+  const std::vector<unsigned char> &cpos = O.cpos, &clen = O.clen;
+  const bool block2 = O.block2;
 
   // permuted CSR (sorted columns), source position of every entry, diagonal positions
   std::vector<int> iperm;
@@ -224,17 +377,22 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   std::vector<int> levL(n, 0), levU(n, 0);
   n_levels_L = n_levels_U = 0;
   if (!perm.empty() && block2) {
-    // node colours: the second row of a node depends on the first (lower) / the first on the second (upper)
+    // node colours: inside a colour the members of a line group follow each other (chain position), and the second
+    // row of a node depends on the first (lower) / the first on the second (upper)
     for (int i = 0; i < n; ++i) {
-      levL[i] = 2 * pcolor[i] + (i & 1);
-      levU[i] = 2 * (n_colors - 1 - pcolor[i]) + (1 - (i & 1));
+      const int q = cpos[i / 2], len = clen[i / 2];
+      levL[i] = 2 * (pcolor[i] * gmax + q) + (i & 1);
+      levU[i] = 2 * ((n_colors - 1 - pcolor[i]) * gmax + (len - 1 - q)) + (1 - (i & 1));
     }
-    n_levels_L = n_levels_U = 2 * n_colors;
+    n_levels_L = n_levels_U = 2 * n_colors * gmax;
   } else if (!perm.empty()) {
-    // colour classes are independent sets: level = colour is a valid schedule for both DAGs
-    // and keeps every level one contiguous run of rows
-    for (int i = 0; i < n; ++i) { levL[i] = pcolor[i]; levU[i] = n_colors - 1 - pcolor[i]; }
-    n_levels_L = n_levels_U = n_colors;
+    // colour classes are independent sets of line groups: level = (colour, chain position) is a valid schedule for
+    // both DAGs
+    for (int i = 0; i < n; ++i) {
+      levL[i] = pcolor[i] * gmax + cpos[i];
+      levU[i] = (n_colors - 1 - pcolor[i]) * gmax + (clen[i] - 1 - cpos[i]);
+    }
+    n_levels_L = n_levels_U = n_colors * gmax;
   } else
   for (int i = 0; i < n; ++i) {
     int l = 0;
@@ -267,11 +425,15 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     // node rows in colour order; 2x2 blocks towards earlier (L) / later (U) colours, column ids = caller-order node ids
     const int nn = n / 2;
     std::vector<int> lrp(nn + 1, 0), urp(nn + 1, 0);
+    // (blocks towards the other members of the node's own line group are not part of the streamed lists: the kernels
+    //  apply them from `cpl` once the member before has been solved)
+    auto own_group = [&](int r, int m) { return m >= r - (int)cpos[r] && m <= r + ((int)clen[r] - 1 - (int)cpos[r]); };
     for (int r = 0; r < nn; ++r) {
       int nl = 0, nu = 0;
       for (int k = prp[2 * r]; k < prp[2 * r + 1]; k += 2) {
         const int m = pcol[k] / 2;
-        if (m < r) ++nl; else if (m > r) ++nu;
+        if (own_group(r, m)) continue;
+        if (m < r) ++nl; else ++nu;
       }
       lrp[r + 1] = lrp[r] + nl;
       urp[r + 1] = urp[r] + nu;
@@ -280,6 +442,11 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     nnzU = (int64_t)urp[nn] * 4;
     std::vector<int> lcol((size_t)lrp[nn]), lsrc((size_t)lrp[nn] * 4), ucol((size_t)urp[nn]), usrc((size_t)urp[nn] * 4);
     std::vector<int> hpermn(nn), isrc((size_t)nn * 4);  // per node row: positions of l10, u01, d0, d1
+    // couplings inside a line group: per node row and half up to kTriGroupMax - 1 blocks (nearest member first), -1: none
+    constexpr int CW = (kTriGroupMax - 1) * 4;
+    std::vector<int> lcs((size_t)nn * CW, -1), ucs((size_t)nn * CW, -1);
+    std::vector<unsigned char> hchain((size_t)nn);
+    for (int r = 0; r < nn; ++r) hchain[r] = (unsigned char)(cpos[r] | (clen[r] << 4));
 #pragma omp parallel
     {
       std::vector<std::pair<int, int>> bl, bu;  // (caller-order node id, k offset inside the row)
@@ -291,6 +458,12 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
         bu.clear();
         for (int k = 0; k < prp[i0 + 1] - a0; k += 2) {
           const int m = pcol[a0 + k] / 2;
+          if (m != r && own_group(r, m)) {   // coupling to another member of the line group
+            const int t = (m < r ? r - m : m - r) - 1;
+            int *dst = (m < r ? lcs.data() : ucs.data()) + (size_t)r * CW + 4 * t;
+            dst[0] = a0 + k; dst[1] = a0 + k + 1; dst[2] = a1 + k; dst[3] = a1 + k + 1;
+            continue;
+          }
           // block-column id: caller-order node id, or the colour-order one for the colour-ordered working vector
           if (m < r) bl.emplace_back(x_layout ? m : perm[pcol[a0 + k]] / 2, k);
           else if (m > r) bu.emplace_back(x_layout ? m : perm[pcol[a0 + k]] / 2, k);
@@ -325,8 +498,10 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     for (int c = 1; c < n_colors; ++c) ncuts.push_back(cstart[c]);
     ncuts.push_back(nn);
     std::vector<int> lb, ub;
-    if (build_rowblocks(lrp.data(), nullptr, nn, kBlkMax, &ncuts, lb) &&
-        build_rowblocks(urp.data(), nullptr, nn, kBlkMax, &ncuts, ub)) {
+    std::vector<unsigned char> glue((size_t)nn);   // a run never splits a line group
+    for (int r = 0; r < nn; ++r) glue[r] = cpos[r] > 0;
+    if (build_rowblocks(lrp.data(), nullptr, nn, kBlkMax, &ncuts, lb, grouped ? glue.data() : nullptr) &&
+        build_rowblocks(urp.data(), nullptr, nn, kBlkMax, &ncuts, ub, grouped ? glue.data() : nullptr)) {
       auto first_block_of = [&](const std::vector<int> &blk, std::vector<int> &out) {
         out.assign(n_colors + 1, 0);
         size_t b = 0;
@@ -354,6 +529,11 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       Lval.alloc((size_t)nnzL);
       Uval.alloc((size_t)nnzU);
       intra.alloc((size_t)nn * 4);
+      if (grouped) {
+        chain.upload(hchain, s);
+        Lcpl_src.upload(lcs, s); Ucpl_src.upload(ucs, s);
+        Lcpl.alloc(lcs.size()); Ucpl.alloc(ucs.size());
+      }
       ctx->sync();
       block2_ready = true;
     }
@@ -361,10 +541,25 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   if (!perm.empty() && !block2) {
     // strict-lower / strict-upper CSR halves with every colour a contiguous run of rows
     std::vector<int> lrp(n + 1, 0), urp(n + 1, 0);
+    // (entries towards the other members of the row's own line group: applied from `cpl`, not streamed)
+    auto own_group = [&](int r, int m) { return m >= r - (int)cpos[r] && m <= r + ((int)clen[r] - 1 - (int)cpos[r]); };
+    constexpr int CW = kTriGroupMax - 1;
+    std::vector<int> lcs((size_t)n * CW, -1), ucs((size_t)n * CW, -1);
+    std::vector<unsigned char> hchain((size_t)n);
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) {
-      lrp[i + 1] = lrp[i] + (pdiag[i] - prp[i]);
-      urp[i + 1] = urp[i] + (prp[i + 1] - pdiag[i] - 1);
+      hchain[i] = (unsigned char)(cpos[i] | (clen[i] << 4));
+      int nl = 0, nu = 0;
+      for (int k = prp[i]; k < prp[i + 1]; ++k) {
+        const int m = pcol[k];
+        if (m == i) continue;
+        if (own_group(i, m)) { (m < i ? lcs : ucs)[(size_t)i * CW + ((m < i ? i - m : m - i) - 1)] = k; continue; }
+        if (m < i) ++nl; else ++nu;
+      }
+      lrp[i + 1] = nl;
+      urp[i + 1] = nu;
     }
+    for (int i = 0; i < n; ++i) { lrp[i + 1] += lrp[i]; urp[i + 1] += urp[i]; }
     nnzL = lrp[n];
     nnzU = urp[n];
     std::vector<int> lcol((size_t)nnzL), lsrc((size_t)nnzL), ucol((size_t)nnzU), usrc((size_t)nnzU);
@@ -375,26 +570,34 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
 #pragma omp for schedule(static)
       for (int i = 0; i < n; ++i) {
         buf.clear();
-        for (int k = prp[i]; k < pdiag[i]; ++k) buf.emplace_back(perm[pcol[k]], k);
+        for (int k = prp[i]; k < pdiag[i]; ++k)
+          if (!own_group(i, pcol[k])) buf.emplace_back(perm[pcol[k]], k);
         std::sort(buf.begin(), buf.end());
         int w = lrp[i];
         for (auto &e : buf) { lcol[w] = e.first; lsrc[w] = e.second; ++w; }
         buf.clear();
-        for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k) buf.emplace_back(perm[pcol[k]], k);
+        for (int k = pdiag[i] + 1; k < prp[i + 1]; ++k)
+          if (!own_group(i, pcol[k])) buf.emplace_back(perm[pcol[k]], k);
         std::sort(buf.begin(), buf.end());
         w = urp[i];
         for (auto &e : buf) { ucol[w] = e.first; usrc[w] = e.second; ++w; }
       }
     }
-    std::vector<int> cuts(hLp.begin() + 1, hLp.end());  // colour boundaries (levL = colour, rows ascending)
+    // colour boundaries (the rows are sorted by colour)
+    std::vector<int> cfirst(n_colors + 1, n), cuts;
+    for (int i = n - 1; i >= 0; --i) cfirst[pcolor[i]] = i;
+    for (int c = n_colors - 1; c >= 0; --c) cfirst[c] = std::min(cfirst[c], cfirst[c + 1]);
+    for (int c = 1; c <= n_colors; ++c) cuts.push_back(cfirst[c]);
     std::vector<int> lb, ub;
-    if (build_rowblocks(lrp.data(), nullptr, n, kStreamNnz, &cuts, lb) &&
-        build_rowblocks(urp.data(), nullptr, n, kStreamNnz, &cuts, ub)) {
+    std::vector<unsigned char> glue((size_t)n);   // a run never splits a line group
+    for (int i = 0; i < n; ++i) glue[i] = cpos[i] > 0;
+    if (build_rowblocks(lrp.data(), nullptr, n, kStreamNnz, &cuts, lb, grouped ? glue.data() : nullptr) &&
+        build_rowblocks(urp.data(), nullptr, n, kStreamNnz, &cuts, ub, grouped ? glue.data() : nullptr)) {
       auto first_block_of = [&](const std::vector<int> &blk, std::vector<int> &out) {
         out.assign(n_colors + 1, 0);
         size_t b = 0;
         for (int c = 0; c <= n_colors; ++c) {
-          const int row = c < n_colors ? hLp[c] : n;
+          const int row = c < n_colors ? cfirst[c] : n;
           while (b + 1 < blk.size() && blk[b] < row) ++b;
           out[c] = (int)b;
         }
@@ -415,6 +618,11 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       Lval.alloc((size_t)nnzL);
       Uval.alloc((size_t)nnzU);
       dinv.alloc((size_t)n);
+      if (grouped) {
+        chain.upload(hchain, s);
+        Lcpl_src.upload(lcs, s); Ucpl_src.upload(ucs, s);
+        Lcpl.alloc(lcs.size()); Ucpl.alloc(ucs.size());
+      }
       ctx->sync();
       stream_ready = true;
     }
@@ -463,6 +671,10 @@ void TriSolve::numeric(const double *a_val_dev) {
     vec_gather(s, n, diag.p, val.p, dinv.p);
     vec_recip(s, n, dinv.p, dinv.p);
   }
+  if (grouped && (block2_ready || stream_ready)) {
+    vec_gather_or_zero(s, (long)Lcpl.n, Lcpl_src.p, val.p, Lcpl.p);
+    vec_gather_or_zero(s, (long)Ucpl.n, Ucpl_src.p, val.p, Ucpl.p);
+  }
 }
 
 void TriSolve::apply(const double *b, double *x) {
@@ -481,14 +693,15 @@ void TriSolve::apply(const double *b, double *x) {
     const TriHalf L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
     // the lower half arms x for the upper half, the upper half re-arms y for the next call: no fill launches
     if (!sf_armed) { vec_fill_sentinel(s, n, y.p); sf_armed = true; }
-    tri_stream_syncfree(s, L, n_Lsf, 1, kind, kStreamNnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, x, sf_err.p, sf_dbg);
+    const TriChain cl{gmax, chain.p, Lcpl.p}, cu{gmax, chain.p, Ucpl.p};
+    tri_stream_syncfree(s, L, n_Lsf, 1, kind, kStreamNnz, 0, dinv.p, d_perm.p, b, nullptr, y.p, x, sf_err.p, sf_dbg, cl);
     tri_stream_syncfree(s, U, n_Usf, 0, kind, kStreamNnz, sf_fault ? 1 : 0, dinv.p, d_perm.p, nullptr, y.p, x, y.p, sf_err.p,
-                        sf_dbg ? sf_dbg + (size_t)n_Lsf * 16 : nullptr);
+                        sf_dbg ? sf_dbg + (size_t)n_Lsf * 16 : nullptr, cu);
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
     return;
   }
-  if (stream_ready && use_stream && !tiny) {
+  if (stream_ready && use_stream && !tiny && !grouped) {   // (line groups: the per-colour kernels do not know them)
     // x doubles as the intermediate vector: rows not yet solved hold L^-1 b, solved rows hold the result
     const TriHalf L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
     for (int c = 0; c < n_colors; ++c) tri_stream_level(s, L, LB[c], LB[c + 1], 1, kind, kStreamNnz, dinv.p, d_perm.p, b, x);
@@ -506,21 +719,22 @@ void TriSolve::apply(const double *b, double *x) {
     // vector with the sentinel, the upper half re-arms y for the next call: no fill launches
     if (!sf_armed) { vec_fill_sentinel(s, n, y.p); sf_armed = true; }
     const TriBlk L{Lrp.p, Lcol.p, Lval.p, Lsf.p}, U{Urp.p, Ucol.p, Uval.p, Usf.p};
+    const TriChain cl{gmax, chain.p, Lcpl.p}, cu{gmax, chain.p, Ucpl.p};
     if (x_layout) {  // colour-ordered working vectors y, xc; the upper half also writes the caller-order result
       if (xc.n != (size_t)n + 1) xc.alloc((size_t)n + 1);
-      tri_blk_syncfree(s, L, n_Lsf, 1, kind, 1, 0, intra.p, permn.p, b, nullptr, y.p, nullptr, xc.p, sf_err.p);
-      tri_blk_syncfree(s, U, n_Usf, 0, kind, 1, sf_fault ? 1 : 0, intra.p, permn.p, nullptr, y.p, xc.p, x, y.p, sf_err.p);
+      tri_blk_syncfree(s, L, n_Lsf, 1, kind, 1, 0, intra.p, permn.p, b, nullptr, y.p, nullptr, xc.p, sf_err.p, cl);
+      tri_blk_syncfree(s, U, n_Usf, 0, kind, 1, sf_fault ? 1 : 0, intra.p, permn.p, nullptr, y.p, xc.p, x, y.p, sf_err.p, cu);
     } else {
-      tri_blk_syncfree(s, L, n_Lsf, 1, kind, 0, 0, intra.p, permn.p, b, nullptr, y.p, nullptr, x, sf_err.p);
-      tri_blk_syncfree(s, U, n_Usf, 0, kind, 0, sf_fault ? 1 : 0, intra.p, permn.p, nullptr, y.p, x, nullptr, y.p, sf_err.p);
+      tri_blk_syncfree(s, L, n_Lsf, 1, kind, 0, 0, intra.p, permn.p, b, nullptr, y.p, nullptr, x, sf_err.p, cl);
+      tri_blk_syncfree(s, U, n_Usf, 0, kind, 0, sf_fault ? 1 : 0, intra.p, permn.p, nullptr, y.p, x, nullptr, y.p, sf_err.p, cu);
     }
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
     return;
   }
-  if (block2_ready && x_layout && use_stream && !tiny)
+  if (block2_ready && x_layout && use_stream && !tiny && !grouped)
     throw Error(-33, "the colour-ordered layout of the blocked factor needs the single-launch solves");
-  if (block2_ready && use_stream && !tiny) {
+  if (block2_ready && use_stream && !tiny && !grouped) {
     const TriBlk L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
     for (int c = 0; c < n_colors; ++c) tri_blk_level(s, L, LB[c], LB[c + 1], 1, kind, intra.p, permn.p, b, x);
     for (int c = n_colors - 1; c >= 0; --c) tri_blk_level(s, U, UB[c], UB[c + 1], 0, kind, intra.p, permn.p, nullptr, x);

@@ -23,6 +23,18 @@ enum { ORDER_NATURAL = 0, ORDER_MULTICOLOR = 1 };
 // returns the number of colours
 int greedy_color(int nv, const std::vector<int> &grp, const std::vector<int> &gcol, std::vector<int> &color);
 
+// Host-only analysis of one factor's ordering (no device work: also behind nsk_debug_tri_ordering for the CPU tests)
+struct TriOrdering {
+  int64_t nnz = 0;
+  int n_colors = 0, gmax = 1;
+  bool block2 = false, sharded = false;
+  std::vector<int> shard, rrp, rcol, rpos;      // restricted pattern (ghost / cross-shard columns dropped), positions in A
+  std::vector<int> perm, pcolor;                // perm[new] = old (empty: natural order); colour of every permuted row
+  std::vector<unsigned char> cpos, clen;        // per permuted item (row, or node when block2): position / length in its group
+  void build(int n, const int *rowptr, const int *col, int ordering, const std::vector<int> &sub_off, bool want_block2,
+             const double *xy, int group);
+};
+
 struct TriSolve {
   Ctx *ctx = nullptr;
   int n = 0;
@@ -65,11 +77,20 @@ struct TriSolve {
   bool block2_ready = false;
   DBuf<int> permn, intra_src;
   DBuf<double> intra;
+  // line groups (analyze: xy, group): members of a group are consecutive rows / node rows of one colour, solved one after
+  // the other inside a workgroup.  chain[r] = position | length << 4; cpl: per row and half kTriGroupMax - 1 couplings
+  // (scalars, or 2x2 blocks) to the members before (lower) / after (upper), nearest first.
+  int gmax = 1;
+  bool grouped = false;
+  DBuf<unsigned char> chain;
+  DBuf<int> Lcpl_src, Ucpl_src;
+  DBuf<double> Lcpl, Ucpl;
 
   // A: host pattern of the local block (columns >= A.n_rows, i.e. ghosts, are dropped);
   // sub_off: optional n_sub+1 offsets of emulated MPI ranks inside this GPU (block Jacobi)
+  // xy: support points of the rows (2 doubles per row) or null; group: members per line group (1: none)
   void analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std::vector<int> &sub_off,
-               bool want_block2 = false);
+               bool want_block2 = false, const double *xy = nullptr, int group = 1);
   void numeric(const double *a_val_dev);           // refresh values (+ factorise for ILU)
   void apply(const double *b, double *x);          // x = M^{-1} b, caller's ordering
   TriView view() const { return TriView{n, rowptr.p, diag.p, col.p, val.p, perm.empty() ? nullptr : d_perm.p}; }

@@ -851,6 +851,44 @@ const int32_t *nsp_cell_u_nodes(const nsp_mesh *m) { return m->cell_u_nodes.data
 const int32_t *nsp_cell_p_dofs(const nsp_mesh *m) { return m->cell_p_dofs.data(); }
 const uint8_t *nsp_cell_flags(const nsp_mesh *m) { return m->cell_flags.data(); }
 int32_t nsp_cell_of_dof0(const nsp_mesh *m) { return m->cell_of_dof0; }
+
+// Support points of this rank's owned DoFs (DoFTools::map_dofs_to_support_points): out_xy[2 d], out_xy[2 d + 1] for
+// owned DoF d of the space (0 velocity: both components of a node share the point; 1 pressure).
+void nsp_support_points(const nsp_mesh *m, int space, double *out_xy) {
+  const nsp_mesh &M = *m;
+  const Tables &T = M.T;
+  if (space == 0) {
+    const int64_t u0 = M.urange[M.rank], u1 = M.urange[M.rank + 1];
+    const int ixa = (int)(std::lower_bound(M.ucol.begin(), M.ucol.end(), u0 / 2) - M.ucol.begin());
+    const int ixb = (int)(std::lower_bound(M.ucol.begin(), M.ucol.end(), u1 / 2) - M.ucol.begin());
+#pragma omp parallel for schedule(static)
+    for (int ix = ixa; ix < ixb; ++ix) {
+      int ci = ix / 3, a = ix % 3;
+      if (ci == M.nx) { ci = M.nx - 1; a = 3; }
+      const double x = (ci + T.gll[a]) * M.hx;
+      for (int iy = 0; iy < M.NY3; ++iy) {
+        const int32_t id = M.uid[(size_t)ix * M.NY3 + iy];
+        if (id < 0) continue;
+        const int64_t r = 2 * (int64_t)id - u0;
+        const double y = M.node_y3(iy);
+        out_xy[2 * r] = out_xy[2 * r + 2] = x;
+        out_xy[2 * r + 1] = out_xy[2 * r + 3] = y;
+      }
+    }
+  } else {
+    const int64_t p0 = M.prange[M.rank], p1 = M.prange[M.rank + 1];
+    const int jxa = (int)(std::lower_bound(M.pcol.begin(), M.pcol.end(), p0) - M.pcol.begin());
+    const int jxb = (int)(std::lower_bound(M.pcol.begin(), M.pcol.end(), p1) - M.pcol.begin());
+#pragma omp parallel for schedule(static)
+    for (int jx = jxa; jx < jxb; ++jx)
+      for (int jy = 0; jy < M.NY2; ++jy) {
+        const int32_t id = M.pid[(size_t)jx * M.NY2 + jy];
+        if (id < 0) continue;
+        out_xy[2 * (size_t)(id - p0)] = 0.5 * jx * M.hx;
+        out_xy[2 * (size_t)(id - p0) + 1] = 0.5 * jy * M.hy;
+      }
+  }
+}
 void nsp_cell_tables(const nsp_mesh *m, double *out) {
   const Tables &T = m->T;
   std::memcpy(out, T.phi, sizeof(T.phi)); out += 256;

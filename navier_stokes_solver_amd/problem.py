@@ -124,6 +124,8 @@ class LocalProblem:
     cell_of_dof0: int = -1
     cell_tables: np.ndarray = None    # 944 doubles, see nsk_problem.h
     simplex: dict = None              # P2/P1 triangles instead (simplex.device_handoff): nsk_assembly_set_simplex
+    support_u: np.ndarray = None      # [n_u, 2] support points of the owned velocity DoFs (map_dofs_to_support_points)
+    support_p: np.ndarray = None      # [n_p, 2]
 
     @property
     def n_u(self) -> int:
@@ -234,6 +236,11 @@ def generate(nx: int, ny: int, *, nu: float, mode: int = 1, state=1, inlet_bc: i
         tab = np.empty(944)
         L.nsp_cell_tables(h, tab.ctypes.data)
         out.cell_tables = tab
+        L.nsp_support_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.nsp_support_points.restype = None
+        out.support_u, out.support_p = np.empty((n_u, 2)), np.empty((n_p, 2))
+        L.nsp_support_points(h, 0, out.support_u.ctypes.data)
+        L.nsp_support_points(h, 1, out.support_p.ctypes.data)
         return out
     finally:
         L.nsp_mesh_destroy(h)

@@ -394,14 +394,15 @@ def local_problem(pr, lay: RankLayout, rank: int):
     of the ghost velocity DoFs (aSIMPLE's SpGEMM), the ghost lists for `partition.build_halo_plan`."""
     du, dp = lay.dof_new()
     n_u, n_p = len(du), len(dp)
-    Pu = sp.csr_matrix((np.ones(n_u), (du, np.arange(n_u))), shape=(n_u, n_u))
-    Pp = sp.csr_matrix((np.ones(n_p), (dp, np.arange(n_p))), shape=(n_p, n_p))
-    F = (Pu @ pr.F.to_scipy() @ Pu.T).tocsr()
-    Bt = (Pu @ pr.Bt.to_scipy() @ Pp.T).tocsr()
-    B = (Pp @ pr.B.to_scipy() @ Pu.T).tocsr()
-    Mp = (Pp @ pr.Mp.to_scipy() @ Pp.T).tocsr()
-    for A in (F, Bt, B, Mp):
-        A.sort_indices()
+
+    def renumber(A, rows_new, cols_new):
+        # entry by entry: a sparse product would drop the STORED zeros (cleared Dirichlet rows), and with them the
+        # common pattern of a node's two rows that the library's 2x2 / 2x1 / 1x2 node blocks rely on
+        c = A.to_scipy().tocoo()
+        M = sp.csr_matrix((c.data, (rows_new[c.row], cols_new[c.col])), shape=c.shape)
+        M.sort_indices()
+        return M
+    F, Bt, B, Mp = renumber(pr.F, du, du), renumber(pr.Bt, du, dp), renumber(pr.B, dp, du), renumber(pr.Mp, dp, dp)
     u0, u1 = int(lay.u_ranges[rank]), int(lay.u_ranges[rank + 1])
     p0, p1 = int(lay.p_ranges[rank]), int(lay.p_ranges[rank + 1])
 

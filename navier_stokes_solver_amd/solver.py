@@ -30,11 +30,13 @@ OPT_VELOCITY_AMG = 10
 OPT_CG_SINGLE_REDUCTION = 11
 # not part of the public ABI (csrc/nsk_internal.h): study switches and the fault-injection hook of the tests
 IOPT_TRI_X_LAYOUT, IOPT_FAULT_INJECT, IOPT_TINY_BYTES = 6, 100, 102
+OPT_TRI_LINE_GROUPS, IOPT_GROUP_U, IOPT_GROUP_P = 12, 103, 104
 IOPT_FUSED_MGS, IOPT_OVERLAP_HALO = 106, 107
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
 
 EXPORTS = [
     "nsk_get_unique_id", "nsk_local_group_id", "nsk_create", "nsk_destroy", "nsk_last_error", "nsk_set_partition", "nsk_set_halo_plan",
+    "nsk_set_support_points",
     "nsk_set_block_csr", "nsk_update_values", "nsk_set_option", "nsk_setup_preconditioner", "nsk_solve",
     "nsk_upload_system", "nsk_solve_resident", "nsk_download_solution", "nsk_spmv", "nsk_jacobian_vmult", "nsk_dot", "nsk_vec_op",
     "nsk_tri_apply", "nsk_amg_info", "nsk_tri_get_perm", "nsk_precond_vmult", "nsk_block_nnz", "nsk_get_block", "nsk_get_stats",
@@ -92,6 +94,7 @@ def lib() -> C.CDLL:
         L.nsk_last_error.argtypes = [vp]
         L.nsk_set_partition.argtypes = [vp, C.c_int, C.c_int64, C.c_int64, C.c_int, i32p]
         L.nsk_set_halo_plan.argtypes = [vp, C.c_int, C.c_int, i32p, i32p, i32p, i32p]
+        L.nsk_set_support_points.argtypes = [vp, C.c_int, vp]
         L.nsk_set_block_csr.argtypes = [vp, C.c_int, C.c_int, C.c_int, i32p, i32p, f64p]
         L.nsk_update_values.argtypes = [vp, C.c_int, f64p]
         L.nsk_set_option.argtypes = [vp, C.c_int, C.c_double]
@@ -153,6 +156,27 @@ def get_unique_id() -> bytes:
     return buf.raw
 
 
+def tri_ordering_host(csr, xy=None, group=1, want_block2=False, sub_off=None):
+    """Host-only: the multicolour ordering (with line groups when `xy` is given) the library's triangular-solve analysis
+    chooses for the square block `csr` — (perm[new] = old, n_colors, largest group, node structure found, chain)."""
+    L = lib()
+    n = int(csr.rows)
+    rp, col = _i32(csr.rowptr), _i32(csr.col)
+    perm = np.empty(n, np.int32)
+    info = np.zeros(4, np.int32)
+    chain = np.zeros(n, np.uint8)
+    a = None if xy is None else np.ascontiguousarray(xy, dtype=np.float64)
+    so = None if sub_off is None else _i32(sub_off)
+    L.nsk_debug_tri_ordering.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.nsk_debug_tri_ordering(n, rp.ctypes.data, col.ctypes.data, 0 if so is None else len(so) - 1,
+                                  None if so is None else so.ctypes.data, int(want_block2), None if a is None else a.ctypes.data,
+                                  int(group), perm.ctypes.data, info.ctypes.data, chain.ctypes.data)
+    if rc != 0:
+        raise RuntimeError("nsk_debug_tri_ordering failed")
+    return perm, int(info[0]), int(info[1]), bool(info[2]), chain[:int(info[3])]
+
+
 def local_group_id(nranks: int, on_stream: bool = False) -> bytes:
     """Pseudo unique id for `nranks` handles living in threads of this process (test transport).  on_stream: the
     collectives stay on the ranks' streams (events across streams, no host synchronisation), see nsk_internal.h."""
@@ -206,6 +230,17 @@ class LinearSolver:
         self._ck(self.L.nsk_set_halo_plan(self.h, space, len(p), p.ctypes.data, sp_.ctypes.data, si.ctypes.data,
                                           rp.ctypes.data))
 
+    def set_support_points(self, space, xy):
+        """Support points of the owned DoFs of `space` ([n, 2]; None drops them): see nsk_set_support_points."""
+        if xy is None:
+            self._ck(self.L.nsk_set_support_points(self.h, space, None))
+            return
+        a = np.ascontiguousarray(xy, dtype=np.float64)
+        n = self.n_u if space == SPACE_U else self.n_p
+        if a.shape != (n, 2):
+            raise ValueError(f"support points of space {space}: expected shape ({n}, 2), got {a.shape}")
+        self._ck(self.L.nsk_set_support_points(self.h, space, a.ctypes.data))
+
     def set_block(self, blk, csr):
         rp, col, val = _i32(csr.rowptr), _i32(csr.col), _f64(csr.val)
         self._ck(self.L.nsk_set_block_csr(self.h, blk, int(csr.rows), int(csr.cols), rp.ctypes.data, col.ctypes.data,
@@ -225,6 +260,9 @@ class LinearSolver:
             for space in (SPACE_U, SPACE_P):
                 pl = plan[space]
                 self.set_halo_plan(space, pl["peers"], pl["send_ptr"], pl["send_idx"], pl["recv_ptr"])
+        if getattr(pr, "support_u", None) is not None and getattr(pr, "support_p", None) is not None:
+            self.set_support_points(SPACE_U, pr.support_u)      # map_dofs_to_support_points: ordering hint only
+            self.set_support_points(SPACE_P, pr.support_p)
         self.set_block(BLK_F, pr.F)
         self.set_block(BLK_BT, pr.Bt)
         self.set_block(BLK_B, pr.B)

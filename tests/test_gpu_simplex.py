@@ -202,3 +202,79 @@ def test_cli_reads_a_mesh_file_on_three_ranks(tmp_path):
     for key in ("Lift coefficient:", "Drag coefficient:"):
         a, b = coef(outs[0], key), coef(outs[1], key)
         assert abs(a - b) <= 1e-5 * max(abs(a), abs(coef(outs[0], "Drag coefficient:")))
+
+
+@pytest.mark.parametrize("nranks,prec,bsr", [(2, 2, 1), (3, 2, 1), (2, 0, 1), (2, 2, 0)])
+def test_multi_rank_operators_on_a_gmsh_partition(nranks, prec, bsr):
+    """The library's multi-rank path on a partition that is NOT a stack of x-strips: J x, one preconditioner application
+    and a converged solve on the rank pieces of the reference's coarse gmsh mesh, against the one-rank operators and the
+    oracle with the ranks as block-Jacobi shards (same rank-local permutations)."""
+    import threading
+
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    from navier_stokes_solver_amd import partition as PT
+    from navier_stokes_solver_amd import solver as S
+    from oracle import oracle as O
+    s = SX.build_space(G.read_msh(REF_MESH))
+    lay = SX.rank_layout(s, nranks)
+    rng = np.random.default_rng(11)
+    free = np.repeat(s.dirichlet == 0, 2)
+    pr = SX.assemble(s, 1.0 / 30.0, mode=1, state=(0.05 * rng.uniform(-1, 1, s.n_u) * free, np.zeros(s.n_p)), inlet_bc=1)
+    parts = [SX.local_problem(pr, lay, r) for r in range(nranks)]
+    plans = [{S.SPACE_U: PT.build_halo_plan(r, lay.u_ranges, [q.ghost_u for q in parts]),
+              S.SPACE_P: PT.build_halo_plan(r, lay.p_ranges, [q.ghost_p for q in parts])} for r in range(nranks)]
+    du, dp = lay.dof_new()
+    n_u, n_p = s.n_u, s.n_p
+    xu, xp = rng.uniform(-1, 1, n_u), rng.uniform(-1, 1, n_p)          # layout numbering
+    ur, prg = lay.u_ranges, lay.p_ranges
+    uid = S.local_group_id(nranks, on_stream=True)
+    res, errs = [None] * nranks, []
+
+    def run(r):
+        try:
+            ls = S.LinearSolver(r, nranks, 0, uid)
+            q = parts[r]
+            ls.set_option(S.OPT_TRI_ORDERING, 1)
+            ls.set_option(S.IOPT_TINY_BYTES, 0)
+            ls.set_option(S.OPT_BSR_VELOCITY, bsr)          # 0: the scalar CSR kernels on the same partition
+            ls.set_problem(q, plans[r])
+            yu, yp = ls.jacobian_vmult(xu[ur[r]:ur[r + 1]], xp[prg[r]:prg[r + 1]])
+            ls.setup_preconditioner(prec, S.STATIONARY, 0.5)
+            perm_u, perm_p = ls.tri_perm(S.TRI_VELOCITY), ls.tri_perm(S.TRI_PRESSURE)
+            d_u, d_p, rc = ls.precond_vmult(xu[ur[r]:ur[r + 1]], xp[prg[r]:prg[r + 1]])
+            ls.setup_preconditioner(prec, S.STATIONARY, 0.5)
+            su, sp_, its, fres, src = ls.solve(S.FGMRES, 1e-10, 20000, q.rhs_u, q.rhs_p, q.x0_u, q.x0_p)
+            res[r] = dict(yu=yu, yp=yp, du=d_u, dp=d_p, rc=rc, su=su, sp=sp_, its=its, src=src, perm_u=perm_u, perm_p=perm_p)
+            ls.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join(600) for t in th]
+    assert not errs, errs
+
+    def permuted(A, L, R_):
+        c = A.to_scipy().tocoo()
+        M = sp.csr_matrix((c.data, (L[c.row], R_[c.col])), shape=c.shape)
+        M.sort_indices()
+        return M
+    F, Bt, B, Mp = permuted(pr.F, du, du), permuted(pr.Bt, du, dp), permuted(pr.B, dp, du), permuted(pr.Mp, dp, dp)
+    J = sp.bmat([[F, Bt], [B, None]], format="csc")
+    cat = lambda k: np.concatenate([r[k] for r in res])  # noqa: E731
+    x = np.concatenate([xu, xp])
+    assert rel_err(np.concatenate([cat("yu"), cat("yp")]), J @ x) <= 1e-13
+    kw = dict(u_shard_off=ur, p_shard_off=prg, perm_F=np.concatenate([r["perm_u"] + ur[k] for k, r in enumerate(res)]))
+    kw["perm_S" if prec == 2 else "perm_Mp"] = np.concatenate([r["perm_p"] + prg[k] for k, r in enumerate(res)])
+    op = O.OracleProblem(O.CsrHolder.from_scipy(F), O.CsrHolder.from_scipy(Bt), O.CsrHolder.from_scipy(B),
+                         O.CsrHolder.from_scipy(Mp), **kw)
+    dst, rc = op.prec_apply(x, prec=prec, variant=0, alpha=0.5)
+    assert rc == 0 and all(r["rc"] == 0 for r in res)
+    assert rel_err(np.concatenate([cat("du"), cat("dp")]), dst) <= 1e-7
+    b = np.empty(n_u + n_p)
+    b[du], b[n_u + dp] = pr.rhs_u, pr.rhs_p
+    sol = np.concatenate([cat("su"), cat("sp")])
+    assert all(r["src"] == 0 for r in res) and len({r["its"] for r in res}) == 1
+    assert np.linalg.norm(b - J @ sol) <= 1.05e-10
+    assert rel_err(sol, spl.splu(J).solve(b)) <= 1e-7
