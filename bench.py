@@ -83,6 +83,9 @@ def parse():
     ap.add_argument("--inner-gs", type=int, default=-1,
                     help="Gram-Schmidt of the inner FGMRES: 0 modified, 1 fused classical (default on one GPU), 2 fused classical "
                          "with one reduction per iteration (default for N > 1)")
+    ap.add_argument("--line-groups", type=int, default=2,
+                    help="NSK_OPT_TRI_LINE_GROUPS: 1 colour pairs of velocity nodes / triples of pressure DoFs along the lattice "
+                         "lines in the triangular factors' orderings (fewer colours), 0 colour single DoFs, 2 (default) by size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mesh", type=str, default="300,100")
     ap.add_argument("--cpu-steps", type=int, default=12)
@@ -136,6 +139,7 @@ def make_solver(S, PT, P, dist, args, nx, ny, nu, inv_dt, world, rank, local_ran
     ls.set_option(S.OPT_TRI_ORDERING, args.ordering)
     ls.set_option(S.OPT_SUBDOMAINS, args.subdomains)
     ls.set_option(S.OPT_TRI_SYNC_FREE, args.sync_free)
+    ls.set_option(S.OPT_TRI_LINE_GROUPS, args.line_groups)
     ls.set_option(S.OPT_CG_SINGLE_REDUCTION, int(args.cg_single_reduction if args.cg_single_reduction >= 0 else world > 1))
     ls.set_option(S.OPT_INNER_FUSED_GS, int(args.inner_gs if args.inner_gs >= 0 else (2 if world > 1 else 1)))
     t0 = time.time()
@@ -332,6 +336,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     st = ls.stats()
+    free_b, total_b = torch.cuda.mem_get_info()       # everything of this solve is still resident
+    dev_bytes = int(total_b - free_b)
     assert its == args.steps, (its, args.steps)
     n_u_local, n_p_local, nnz_F_local = pr.n_u, pr.n_p, pr.F.nnz
     ls.close()
@@ -413,7 +419,8 @@ def main():
                 "K": args.steps, "restart": 30, "tolerance": 0.0,
                 "dofs": n_global, "n_u_local": n_u_local, "n_p_local": n_p_local, "nnz_F_local": nnz_F_local,
                 "nnz_S_local": st["nnz_s"], "partition": f"x-strips x{world}",
-                "tri_ordering": ["natural", "multicolor"][args.ordering], "colors_u": st["n_colors_u"],
+                "tri_ordering": ["natural", "multicolor"][args.ordering], "line_groups": bool(args.line_groups),
+                "colors_u": st["n_colors_u"],
                 "colors_p": st["n_colors_p"], "subdomains_per_gpu": args.subdomains,
                 "inner_F_its_per_step": st["inner_u_its"] / max(1, st["prec_applies"]),
                 "inner_S_its_per_step": st["inner_p_its"] / max(1, st["prec_applies"]),
@@ -442,6 +449,7 @@ def main():
                 "sync_free_fallbacks": st["sync_free_fallbacks"],
                 "spmvs_overlapped_with_halo_per_step": st["overlapped_spmvs"] / args.steps,
                 "dof_iters_per_s_incl_setup": n_global * args.steps / (dt + t_setup),
+                "device_bytes_in_use": dev_bytes, "device_KB_per_dof": dev_bytes / 1e3 / (n_u_local + n_p_local),
             },
         }
         if conv:

@@ -89,13 +89,21 @@ enum {
   NSK_OPT_VELOCITY_AMG = 10,  /* stationary blockTriangular: 1 (default) precondition F with the smoothed-aggregation AMG
                                  V-cycle (the reference configures TrilinosWrappers::PreconditionAMG there,
                                  NSSolverStationary.hpp:225,231); 0: ILU(0), as the unsteady variant does */
-  NSK_OPT_TRI_LINE_GROUPS = 12 /* 1 (default): when support points were handed over (nsk_set_support_points) the multicolour
+  NSK_OPT_TRI_LINE_GROUPS = 12, /* 2 (default): as 1 for factors small enough to be bound by the chain of colour hand-offs
+                                 (velocity block <= 4 M rows, pressure blocks <= 1 M rows per rank: where it was measured to
+                                 pay), as 0 for larger ones.  1: when support points were handed over (nsk_set_support_points) the multicolour
                                  ordering colours short LINE GROUPS — neighbours on a line of constant y: pairs of velocity
                                  nodes, triples of pressure DoFs — instead of single DoFs, and the members of a group are
                                  solved one after the other inside a workgroup: fewer colours (12 instead of 17-18 for F,
                                  17 instead of 29-31 for the Schur complement on the reference's lattices) at the same or
                                  lower inner iteration counts; still ILU(0)/SGS of a symmetrically permuted matrix
                                  (nsk_tri_get_perm).  0: colour the DoFs one by one */
+  NSK_OPT_MASS_ORDERING = 13   /* ordering of the pressure-mass factor alone: -1 (default) as NSK_OPT_TRI_ORDERING, 0 the
+                                 caller's order, 1 multicolour.  In the unsteady block-diagonal preconditioner the pressure
+                                 block is about ONE ILU(M_p)-preconditioned CG step (absolute tolerance 1e-1,
+                                 NSSolver.hpp:155-176), and whether restarted FGMRES converges there hangs on the quality of
+                                 that one application: 0 reproduces the factor one MPI rank of the
+                                 reference builds, at O(nx + ny) dependent levels per application */
 };
 
 typedef struct {

@@ -296,6 +296,17 @@ int main(int argc, char *argv[]) {
       const int n_u = (int)nsp_block_rows(mesh, NSP_BLK_F), n_p = (int)nsp_block_rows(mesh, NSP_BLK_B);
       check(h, nsk_set_partition(h, NSK_SPACE_U, 0, n_u, 0, nullptr), "nsk_set_partition");
       check(h, nsk_set_partition(h, NSK_SPACE_P, 0, n_p, 0, nullptr), "nsk_set_partition");
+      {   // ordering hint for the triangular factors (DoFTools::map_dofs_to_support_points on the reference's side)
+        std::vector<double> xy(2 * (size_t)std::max(n_u, n_p));
+        nsp_support_points(mesh, 0, xy.data());
+        check(h, nsk_set_support_points(h, NSK_SPACE_U, xy.data()), "nsk_set_support_points");
+        nsp_support_points(mesh, 1, xy.data());
+        check(h, nsk_set_support_points(h, NSK_SPACE_P, xy.data()), "nsk_set_support_points");
+      }
+      // NSK_TRI_ORDERING=0: the caller's (lattice) order in the triangular factors — what one MPI rank of the reference
+      // factorises, O(nx + ny) dependent levels; default 1: the library's multicolour ordering
+      if (const char *e = std::getenv("NSK_TRI_ORDERING")) check(h, nsk_set_option(h, NSK_OPT_TRI_ORDERING, std::atof(e)), "nsk_set_option");
+      if (const char *e = std::getenv("NSK_MASS_ORDERING")) check(h, nsk_set_option(h, NSK_OPT_MASS_ORDERING, std::atof(e)), "nsk_set_option");
       const int blks[4] = {NSP_BLK_F, NSP_BLK_BT, NSP_BLK_B, NSP_BLK_MP};
       for (int b : blks)
         check(h, nsk_set_block_csr(h, b, (int)nsp_block_rows(mesh, b), (int)nsp_block_cols(mesh, b),

@@ -99,6 +99,7 @@ struct nsk_handle_s {
   // support points of the owned DoFs (nsk_set_support_points) and the line-group sizes of the triangular factors
   std::vector<double> support[2];
   int line_groups = 1, group_u = 2, group_p = 3;   // NSK_OPT_TRI_LINE_GROUPS, NSK_IOPT_GROUP_U / _P
+  int mp_ordering = -1;                            // NSK_OPT_MASS_ORDERING: -1 follow NSK_OPT_TRI_ORDERING, 0 natural, 1 multicolour
   const double *xy(int space) const { return line_groups && !support[space].empty() ? support[space].data() : nullptr; }
   int x_layout_mode = 2;   // NSK_IOPT_TRI_X_LAYOUT
   int sync_free_mode = 2;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
@@ -392,7 +393,8 @@ void H::setup(int type, int variant_, double alpha_) {
   prec_type = type;
   variant = variant_;
   alpha = alpha_;
-  const int key = ((tri_ordering * 1000 + subdomains) * 2 + (line_groups ? 1 : 0)) * 100 + group_u * 10 + group_p;
+  const int key = ((((tri_ordering * 1000 + subdomains) * 2 + (xy(0) ? 1 : 0)) * 2 + (xy(1) ? 1 : 0)) * 100 + group_u * 10 + group_p) * 3 +
+                  (mp_ordering + 1);
   Csr &F = blk[NSK_BLK_F];
   // kinds: blockDiagonal stationary = SSOR/SSOR, unsteady = ILU/ILU; blockTriangular = (AMG->ILU)/ILU; aSIMPLE = ILU/ILU
   const int kindF = (type == 0 && variant == 0) ? 1 : 0;
@@ -449,7 +451,7 @@ void H::setup(int type, int variant_, double alpha_) {
     Csr &Mp = blk[NSK_BLK_MP];
     if (!Mp.present) throw Error(-45, "this preconditioner needs pressure_mass.block(1,1)");
     if (!tMp_ok || tMp_key != key) {
-      tMp.analyze(&ctx, Mp, kindP, tri_ordering, sub_offsets(1), false, xy(1), group_p);
+      tMp.analyze(&ctx, Mp, kindP, mp_ordering >= 0 ? mp_ordering : tri_ordering, sub_offsets(1), false, xy(1), group_p);
       tMp_ok = true;
       tMp_key = key;
     }
@@ -848,7 +850,14 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
       h->tF.sf_fault = (h->fault_inject & 2) != 0;
       h->ctx.mgs_fault = (h->fault_inject & 4) != 0;
       break;
-    case NSK_OPT_TRI_LINE_GROUPS: h->line_groups = v != 0.0; break;
+    case NSK_OPT_TRI_LINE_GROUPS:
+      if (v != 0.0 && v != 1.0 && v != 2.0) throw Error(-61, "NSK_OPT_TRI_LINE_GROUPS: 0, 1 or 2");
+      h->line_groups = (int)v;
+      break;
+    case NSK_OPT_MASS_ORDERING:
+      if (v != -1.0 && v != 0.0 && v != 1.0) throw Error(-61, "NSK_OPT_MASS_ORDERING: -1, 0 or 1");
+      h->mp_ordering = (int)v;
+      break;
     case NSK_IOPT_GROUP_U:
     case NSK_IOPT_GROUP_P:
       if (v < 1.0 || v > (double)kTriGroupMax) throw Error(-61, "line-group size: 1 .. 3");

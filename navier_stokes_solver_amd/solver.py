@@ -31,6 +31,7 @@ OPT_CG_SINGLE_REDUCTION = 11
 # not part of the public ABI (csrc/nsk_internal.h): study switches and the fault-injection hook of the tests
 IOPT_TRI_X_LAYOUT, IOPT_FAULT_INJECT, IOPT_TINY_BYTES = 6, 100, 102
 OPT_TRI_LINE_GROUPS, IOPT_GROUP_U, IOPT_GROUP_P = 12, 103, 104
+OPT_MASS_ORDERING = 13
 IOPT_FUSED_MGS, IOPT_OVERLAP_HALO = 106, 107
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
 

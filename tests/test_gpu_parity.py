@@ -113,8 +113,10 @@ def test_ilu_apply(handles, name, ordering, subdomains):
         assert rel_err(ls.tri_apply(which, b), tri.apply(b)) <= 1e-11, (name, ordering, subdomains, which)
     st = ls.stats()
     if ordering:
-        # DoF colouring: one level per colour; node colouring (2x2 blocks): two dependent rows per node
-        assert 0 < st["n_colors_u"] <= 64 and st["n_levels_u"] in (st["n_colors_u"], 2 * st["n_colors_u"])
+        # DoF colouring: one level per colour; node colouring (2x2 blocks): two dependent rows per node; line groups: the
+        # members of a group (<= 3) one after the other inside a colour
+        c = st["n_colors_u"]
+        assert 0 < c <= 64 and st["n_levels_u"] in (c, 2 * c, 3 * c, 4 * c, 6 * c)
 
 
 @pytest.mark.parametrize("ordering", [0, 1])
