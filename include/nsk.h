@@ -98,12 +98,13 @@ enum {
                                  17 instead of 29-31 for the Schur complement on the reference's lattices) at the same or
                                  lower inner iteration counts; still ILU(0)/SGS of a symmetrically permuted matrix
                                  (nsk_tri_get_perm).  0: colour the DoFs one by one */
-  NSK_OPT_MASS_ORDERING = 13   /* ordering of the pressure-mass factor alone: -1 (default) as NSK_OPT_TRI_ORDERING, 0 the
-                                 caller's order, 1 multicolour.  In the unsteady block-diagonal preconditioner the pressure
-                                 block is about ONE ILU(M_p)-preconditioned CG step (absolute tolerance 1e-1,
-                                 NSSolver.hpp:155-176), and whether restarted FGMRES converges there hangs on the quality of
-                                 that one application: 0 reproduces the factor one MPI rank of the
-                                 reference builds, at O(nx + ny) dependent levels per application */
+  NSK_OPT_MASS_ORDERING = 13   /* ordering of the pressure-mass factor alone: 0 the caller's order, 1 multicolour, -1 (default)
+                                 the caller's order in the UNSTEADY block-diagonal preconditioner and NSK_OPT_TRI_ORDERING
+                                 everywhere else.  There the pressure block is about ONE ILU(M_p)-preconditioned CG step
+                                 (absolute tolerance 1e-1, NSSolver.hpp:155-176) and whether restarted FGMRES converges hangs
+                                 on the quality of that one application: the caller's order reproduces
+                                 the factor one MPI rank of the reference builds (same iteration counts as the CPU
+                                 restatement: 241 / 403 at 100x70), at O(nx + ny) dependent levels per application */
 };
 
 typedef struct {

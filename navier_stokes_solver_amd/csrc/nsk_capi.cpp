@@ -99,7 +99,16 @@ struct nsk_handle_s {
   // support points of the owned DoFs (nsk_set_support_points) and the line-group sizes of the triangular factors
   std::vector<double> support[2];
   int line_groups = 1, group_u = 2, group_p = 3;   // NSK_OPT_TRI_LINE_GROUPS, NSK_IOPT_GROUP_U / _P
-  int mp_ordering = -1;                            // NSK_OPT_MASS_ORDERING: -1 follow NSK_OPT_TRI_ORDERING, 0 natural, 1 multicolour
+  int mp_ordering = -1;                            // NSK_OPT_MASS_ORDERING: -1 by preconditioner (see mass_ordering), 0 natural, 1 multicolour
+  // Ordering of the pressure-mass factor.  In the UNSTEADY block-diagonal preconditioner the pressure block is about one
+  // ILU(M_p)-preconditioned CG step (absolute tolerance 1e-1 against unit-norm Krylov vectors, NSSolver.hpp:155-176), and
+  // whether restarted FGMRES(30) converges hangs on that one application: with a multicolour M_p factor it stalls from
+  // 100x70 upwards (the CPU restatement stalls the same way given the same permutation), with the caller's order it takes
+  // the reference's 241 / 403 / 432 iterations.  So that factor keeps the caller's order there.
+  int mass_ordering(int type, int variant_) const {
+    if (mp_ordering >= 0) return mp_ordering;
+    return (type == 0 && variant_ == 1) ? (int)ORDER_NATURAL : tri_ordering;
+  }
   const double *xy(int space) const { return line_groups && !support[space].empty() ? support[space].data() : nullptr; }
   int x_layout_mode = 2;   // NSK_IOPT_TRI_X_LAYOUT
   int sync_free_mode = 2;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
@@ -393,8 +402,8 @@ void H::setup(int type, int variant_, double alpha_) {
   prec_type = type;
   variant = variant_;
   alpha = alpha_;
-  const int key = ((((tri_ordering * 1000 + subdomains) * 2 + (xy(0) ? 1 : 0)) * 2 + (xy(1) ? 1 : 0)) * 100 + group_u * 10 + group_p) * 3 +
-                  (mp_ordering + 1);
+  const int key = ((((tri_ordering * 1000 + subdomains) * 2 + (xy(0) ? 1 : 0)) * 2 + (xy(1) ? 1 : 0)) * 100 + group_u * 10 + group_p) * 2 +
+                  mass_ordering(type, variant_);
   Csr &F = blk[NSK_BLK_F];
   // kinds: blockDiagonal stationary = SSOR/SSOR, unsteady = ILU/ILU; blockTriangular = (AMG->ILU)/ILU; aSIMPLE = ILU/ILU
   const int kindF = (type == 0 && variant == 0) ? 1 : 0;
@@ -451,7 +460,7 @@ void H::setup(int type, int variant_, double alpha_) {
     Csr &Mp = blk[NSK_BLK_MP];
     if (!Mp.present) throw Error(-45, "this preconditioner needs pressure_mass.block(1,1)");
     if (!tMp_ok || tMp_key != key) {
-      tMp.analyze(&ctx, Mp, kindP, mp_ordering >= 0 ? mp_ordering : tri_ordering, sub_offsets(1), false, xy(1), group_p);
+      tMp.analyze(&ctx, Mp, kindP, mass_ordering(type, variant), sub_offsets(1), false, xy(1), group_p);
       tMp_ok = true;
       tMp_key = key;
     }

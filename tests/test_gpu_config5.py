@@ -74,3 +74,32 @@ def test_first_time_step_matches_the_oracle_driven_time_loop():
         # the iteration (last-bit differences move the step at which 1e-6 is crossed)
         assert abs(d[4] - h[4]) <= max(5, 0.15 * h[4]), (d, h)
     assert all(info["status"] == 0 for info in host.solves)
+
+
+def test_first_time_step_at_100x70_takes_the_reference_algorithms_iterations():
+    """The size from which a multicolour pressure-mass factor stalls restarted FGMRES: with the
+    library's defaults — multicolour ILU(F), ILU(M_p) in the caller's order for this preconditioner — the first three
+    solve_system() calls converge, in about the iterations the oracle needs with both factors in the caller's order
+    (golden: 241 / 403 / 432, tests/golden/make_time_loop_100x70.py; the GPU with NSK_OPT_TRI_ORDERING = 0 takes exactly
+    241 / 403, profiles/r03_cli_time_loop_orderings.log — too slow for this suite)."""
+    import json
+    import os
+    from navier_stokes_solver_amd import solver as S
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "time_loop_100x70_blockdiagonal.json")))
+    nx, ny, Re, tol, dt = 100, 70, 1.0, 1e-6, 0.01
+    first = P.generate(nx, ny, nu=1.0, mode=0, state=0, inlet_bc=1, U=0.3)
+    ls = S.LinearSolver()
+    try:
+        dev = N.DeviceBackend(ls, first, S.FGMRES, S.BLOCK_DIAGONAL, tol, max_iter=100000, inv_dt=1.0 / dt)
+        hist = N.time_loop(dev, dt, dt, Re, log=lambda *_: None, max_steps=1)
+        assert ls.stats()["n_colors_p"] == 0                    # the pressure-mass factor kept the caller's order
+    finally:
+        ls.close()
+    work = [r for r in hist[0] if r[4] > 0]
+    assert len(work) == len(gold["solves"]) == 3
+    for r, g in zip(work, gold["solves"]):
+        assert g["status"] == 0 and 0.8 * g["iters"] <= r[4] <= 1.25 * g["iters"], (r, g["iters"])
+    # Newton residuals in front of the solves: the same path
+    for r, line in zip(work, gold["newton_log"]):
+        ref = float(line.split("||r|| =")[1].split()[0])
+        assert abs(r[3] - ref) <= 2e-3 * ref + 1e-6, (r[3], ref)
