@@ -98,7 +98,7 @@ struct nsk_handle_s {
   int sync_free_fallbacks = 0;
   // support points of the owned DoFs (nsk_set_support_points) and the line-group sizes of the triangular factors
   std::vector<double> support[2];
-  int line_groups = 1, group_u = 2, group_p = 3;   // NSK_OPT_TRI_LINE_GROUPS, NSK_IOPT_GROUP_U / _P
+  int line_groups = 2, group_u = 2, group_p = 3;   // NSK_OPT_TRI_LINE_GROUPS (2 = by size), NSK_IOPT_GROUP_U / _P
   int mp_ordering = -1;                            // NSK_OPT_MASS_ORDERING: -1 by preconditioner (see mass_ordering), 0 natural, 1 multicolour
   // Ordering of the pressure-mass factor.  In the UNSTEADY block-diagonal preconditioner the pressure block is about one
   // ILU(M_p)-preconditioned CG step (absolute tolerance 1e-1 against unit-norm Krylov vectors, NSSolver.hpp:155-176), and
@@ -109,7 +109,14 @@ struct nsk_handle_s {
     if (mp_ordering >= 0) return mp_ordering;
     return (type == 0 && variant_ == 1) ? (int)ORDER_NATURAL : tri_ordering;
   }
-  const double *xy(int space) const { return line_groups && !support[space].empty() ? support[space].data() : nullptr; }
+  // Measured on MI355X: the groups pay where a colour does not fill the GPU and the solve is a chain of
+  // hand-offs (600x200: ILU(S) apply -30 %, ILU(F) -7 %), and cost where it is bandwidth-bound (1200x400: ILU(F) +8 %)
+  static constexpr int kGroupRowsU = 4000000, kGroupRowsP = 1000000;
+  const double *xy(int space) const {
+    if (!line_groups || support[space].empty()) return nullptr;
+    if (line_groups == 2 && sp[space].n > (space == 0 ? kGroupRowsU : kGroupRowsP)) return nullptr;
+    return support[space].data();
+  }
   int x_layout_mode = 2;   // NSK_IOPT_TRI_X_LAYOUT
   int sync_free_mode = 2;  // 0 off, 1 scalar factors (S, Mp), 2 also the 2x2-blocked velocity factor
   int fault_inject = 0;    // NSK_IOPT_FAULT_INJECT

@@ -24,6 +24,21 @@ __device__ __forceinline__ double sval(const SRef &s) {
   return v;
 }
 
+// matrix values of the node-block kernels are streamed once per pass; NSK_NT_VALUES=1 (study build) loads them
+// non-temporally so that they do not displace the gathered vector lines in L2 / Infinity Cache
+#ifndef NSK_NT_VALUES
+#define NSK_NT_VALUES 0
+#endif
+typedef double dvec2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld_val2(const double *p) {
+#if NSK_NT_VALUES
+  const dvec2_t v = __builtin_nontemporal_load(reinterpret_cast<const dvec2_t *>(p));
+  return make_double2(v.x, v.y);
+#else
+  return *reinterpret_cast<const double2 *>(p);
+#endif
+}
+
 template <int W>
 __device__ __forceinline__ double subwave_sum(double v) {
 #pragma unroll
@@ -219,8 +234,8 @@ __device__ __forceinline__ void blk_products(const BlkView &A, int k0, int k1, c
     const bool ok = k < k1;
     m[u] = ok ? __builtin_nontemporal_load(A.col + k) : 0;
     const double *v = A.val + (size_t)(R * C) * (ok ? k : k0);
-    if (R * C == 4) { a0[u] = *reinterpret_cast<const double2 *>(v); a1[u] = *reinterpret_cast<const double2 *>(v + 2); }
-    else if (R * C == 2) { a0[u] = *reinterpret_cast<const double2 *>(v); a1[u] = make_double2(0.0, 0.0); }
+    if (R * C == 4) { a0[u] = ld_val2(v); a1[u] = ld_val2(v + 2); }
+    else if (R * C == 2) { a0[u] = ld_val2(v); a1[u] = make_double2(0.0, 0.0); }
     else { a0[u] = make_double2(v[0], 0.0); a1[u] = make_double2(0.0, 0.0); }
   }
 #pragma unroll
@@ -402,8 +417,8 @@ __global__ __launch_bounds__(BLK) void tri_blk_kernel(TriBlk M, int b0, int nb, 
       const bool ok = k < k1;
       m[u] = ok ? __builtin_nontemporal_load(M.col + k) : 0;
       const double *v = M.val + 4 * (size_t)(ok ? k : k0);
-      a0[u] = *reinterpret_cast<const double2 *>(v);
-      a1[u] = *reinterpret_cast<const double2 *>(v + 2);
+      a0[u] = ld_val2(v);
+      a1[u] = ld_val2(v + 2);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const double2 *>(x + 2 * (size_t)m[u]);
@@ -666,8 +681,8 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int w
       const bool ok = k < k1;
       m[u] = ok ? __builtin_nontemporal_load(M.col + k) : -1;
       const double *v = M.val + 4 * (size_t)(ok ? k : k0);
-      a0[u] = *reinterpret_cast<const double2 *>(v);
-      a1[u] = *reinterpret_cast<const double2 *>(v + 2);
+      a0[u] = ld_val2(v);
+      a1[u] = ld_val2(v + 2);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
