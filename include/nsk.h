@@ -117,6 +117,7 @@ typedef struct {
   int64_t cur_outer_iters;     /* progress of the running / last outer solve: iterations done ... */
   double cur_residual;         /* ... and the residual SolverControl saw last (readable from another thread) */
   int64_t overlapped_spmvs;    /* SpMVs whose interior rows ran while the halo exchange was in flight (nranks > 1) */
+  int64_t ring_applies;        /* triangular applies in the caller's order that went through the LDS-ring kernel */
 } nsk_stats;
 
 /* 128-byte RCCL unique id, produced on rank 0 and distributed by the caller (e.g. MPI_Bcast). */

@@ -1537,6 +1537,7 @@ int nsk_get_stats(nsk_handle h, nsk_stats *o) {
   o->cur_outer_iters = h->progress_step;
   o->cur_residual = h->progress_value;
   o->overlapped_spmvs = h->overlapped_spmvs;
+  o->ring_applies = h->ctx.st.ring_applies;
   return 0;
   NSK_CATCH(h)
 }

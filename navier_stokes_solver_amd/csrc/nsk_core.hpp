@@ -202,7 +202,7 @@ int make_local_group(int nranks, void *out128, int on_stream = 0);
 struct Stats {
   double setup_ms = 0, solve_ms = 0;
   long outer_iters = 0, inner_u_its = 0, inner_p_its = 0, prec_applies = 0, spmv_calls = 0, tri_applies = 0,
-       reductions = 0, host_syncs = 0;
+       reductions = 0, host_syncs = 0, ring_applies = 0;
   double spmv_bytes = 0, tri_bytes = 0, blas1_bytes = 0;
 };
 

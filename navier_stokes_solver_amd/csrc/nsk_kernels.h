@@ -209,6 +209,26 @@ void tri_blk_syncfree(hipStream_t s, const TriBlk &M, int n_blocks, int lower, i
 void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, double *y);
 
 
+// ---- natural-order ("caller's order") triangular solve through an LDS ring ----
+// A factor in the caller's order has O(nx + ny) dependent levels of a few hundred rows: nothing to spread over a GPU,
+// and one workgroup walking the levels pays a trip to memory per level.  Here ONE 1024-thread workgroup walks PASSES
+// (at most kRingRows independent rows each, 8 lanes per row) whose data sits in padded per-pass records (one coalesced
+// load per thread, issued kRingDepth passes ahead), and the results the following passes need live in an LDS ring
+// indexed by the row's position in the pass order: the critical path of a pass is LDS + one barrier, not a trip to HBM.
+// Requirements (checked by the analysis): at most 8 * kRingE entries per row and half, and every dependency at most
+// kRingSlots - 2 * kRingRows positions back.
+constexpr int kRingThreads = 1024, kRingRows = 128, kRingE = 2, kRingSlots = 4096, kRingDepth = 8;
+struct RingHalf {
+  int n_pass;
+  const int *pass_base;   // [n_pass] position (in pass order) of the pass's first row
+  const int *rowid;       // [n_pass * kRingRows] row of (pass, slot) or -1
+  const double *rdinv;    // [n_pass * kRingRows] 1 / diagonal of that row
+  const int *epos;        // [n_pass * kRingThreads * kRingE] position of the entry's column row (0 for padding)
+  const double *eval;     // [n_pass * kRingThreads * kRingE] value (0 for padding)
+};
+// lower: y[i] = kind ? (rhs[i] - s) * dinv : rhs[i] - s ; upper: out[i] = kind ? y[i] - s * dinv : (y[i] - s) * dinv
+void tri_ring(hipStream_t s, const RingHalf &R, int lower, int kind, const double *own, double *dst);
+
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,
                        const int *col, double *val, int max_row_nnz);

@@ -24,21 +24,6 @@ __device__ __forceinline__ double sval(const SRef &s) {
   return v;
 }
 
-// matrix values of the node-block kernels are streamed once per pass; NSK_NT_VALUES=1 (study build) loads them
-// non-temporally so that they do not displace the gathered vector lines in L2 / Infinity Cache
-#ifndef NSK_NT_VALUES
-#define NSK_NT_VALUES 0
-#endif
-typedef double dvec2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2 ld_val2(const double *p) {
-#if NSK_NT_VALUES
-  const dvec2_t v = __builtin_nontemporal_load(reinterpret_cast<const dvec2_t *>(p));
-  return make_double2(v.x, v.y);
-#else
-  return *reinterpret_cast<const double2 *>(p);
-#endif
-}
-
 template <int W>
 __device__ __forceinline__ double subwave_sum(double v) {
 #pragma unroll
@@ -234,8 +219,8 @@ __device__ __forceinline__ void blk_products(const BlkView &A, int k0, int k1, c
     const bool ok = k < k1;
     m[u] = ok ? __builtin_nontemporal_load(A.col + k) : 0;
     const double *v = A.val + (size_t)(R * C) * (ok ? k : k0);
-    if (R * C == 4) { a0[u] = ld_val2(v); a1[u] = ld_val2(v + 2); }
-    else if (R * C == 2) { a0[u] = ld_val2(v); a1[u] = make_double2(0.0, 0.0); }
+    if (R * C == 4) { a0[u] = *reinterpret_cast<const double2 *>(v); a1[u] = *reinterpret_cast<const double2 *>(v + 2); }
+    else if (R * C == 2) { a0[u] = *reinterpret_cast<const double2 *>(v); a1[u] = make_double2(0.0, 0.0); }
     else { a0[u] = make_double2(v[0], 0.0); a1[u] = make_double2(0.0, 0.0); }
   }
 #pragma unroll
@@ -417,8 +402,8 @@ __global__ __launch_bounds__(BLK) void tri_blk_kernel(TriBlk M, int b0, int nb, 
       const bool ok = k < k1;
       m[u] = ok ? __builtin_nontemporal_load(M.col + k) : 0;
       const double *v = M.val + 4 * (size_t)(ok ? k : k0);
-      a0[u] = ld_val2(v);
-      a1[u] = ld_val2(v + 2);
+      a0[u] = *reinterpret_cast<const double2 *>(v);
+      a1[u] = *reinterpret_cast<const double2 *>(v + 2);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const double2 *>(x + 2 * (size_t)m[u]);
@@ -628,8 +613,11 @@ __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const 
 // PERMX = 1: the working vectors (ownv, x) are in colour order (node r at 2 r) and M.col holds colour-order node
 // ids: a colour then only touches the segments of the colours it depends on.  The lower half gathers rhs through
 // permn, the upper half also writes its result to out[permn[r]] in the caller's order.
+#ifndef NSK_BLK_SF_WG
+#define NSK_BLK_SF_WG 1   // (study builds: 7 asks the compiler for seven workgroups per CU — the upper half sits at 73 VGPRs)
+#endif
 template <int LOWER, int KIND, int PERMX, int GMAX>
-__global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int wrong_order,
+__global__ __launch_bounds__(BLK, GMAX == 1 ? NSK_BLK_SF_WG : 1) void tri_blk_sf_kernel(TriBlk M, int nb, int wrong_order,
                                                          const double *__restrict__ intra,
                                                          const int *__restrict__ permn,
                                                          const double *__restrict__ rhs,
@@ -650,7 +638,7 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int w
   const int r = r0 + (int)threadIdx.x / RG, lane = threadIdx.x % RG;
   const bool have = r < r1;
   int jb = 0, je = 0;
-  size_t i = 0;
+  unsigned i = 0;   // position of the node row's first entry in the working vector (< 2^31 entries per rank)
   int cq = 0;
   double2 own = make_double2(0.0, 0.0), cf = make_double2(0.0, 0.0), di = make_double2(1.0, 1.0);
   double2 ca0 = make_double2(0.0, 0.0), ca1 = ca0, cb0 = ca0, cb1 = ca0;   // couplings to the nearest / next member
@@ -658,7 +646,7 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int w
     jb = M.rowptr[r] - k0;
     je = M.rowptr[r + 1] - k0;
     const size_t ic = 2 * (size_t)permn[r];   // caller-order position
-    i = PERMX ? 2 * (size_t)r : ic;
+    i = PERMX ? 2u * (unsigned)r : (unsigned)ic;
     own = *reinterpret_cast<const double2 *>(LOWER ? rhs + ic : ownv + i);
     cf = *reinterpret_cast<const double2 *>(intra + 4 * (size_t)r);
     di = *reinterpret_cast<const double2 *>(intra + 4 * (size_t)r + 2);
@@ -681,8 +669,8 @@ __global__ __launch_bounds__(BLK) void tri_blk_sf_kernel(TriBlk M, int nb, int w
       const bool ok = k < k1;
       m[u] = ok ? __builtin_nontemporal_load(M.col + k) : -1;
       const double *v = M.val + 4 * (size_t)(ok ? k : k0);
-      a0[u] = ld_val2(v);
-      a1[u] = ld_val2(v + 2);
+      a0[u] = *reinterpret_cast<const double2 *>(v);
+      a1[u] = *reinterpret_cast<const double2 *>(v + 2);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -895,6 +883,58 @@ __global__ __launch_bounds__(SERIAL_BLK) void tri_serial_kernel(TriView T, const
     for (int r = b + sub; r < e; r += SERIAL_BLK / LPR) tri_row<LPR, KIND, LOWER>(T, rows[r], lane, rhs, y, out);
     __threadfence_block();
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ natural-order solve through an LDS ring
+template <int KIND, bool LOWER>
+__global__ __launch_bounds__(kRingThreads) void tri_ring_kernel(RingHalf R, const double *__restrict__ own_src,
+                                                                double *__restrict__ dst) {
+  __shared__ double ring[kRingSlots];
+  constexpr int D = kRingDepth, E = kRingE, MASK = kRingSlots - 1;
+  const int t = threadIdx.x, sub = t >> 3, lane = t & 7;
+  for (int k = t; k < kRingSlots; k += kRingThreads) ring[k] = 0.0;
+  int rid[D], bs[D], ps[D][E];
+  double dv[D], vl[D][E], ow[D];
+  // (the records are padded to a multiple of kRingDepth passes plus kRingDepth empty ones, so that every load below is
+  //  unconditional: with branches around them the compiler waits for ALL outstanding loads at every join, i.e. pays the
+  //  trip to memory in every pass — measured: 3 us per pass instead of 0.4)
+  auto load_a = [&](int slot, int q) {   // the pass's padded record: no load depends on another
+    rid[slot] = R.rowid[(size_t)q * kRingRows + sub];
+    bs[slot] = R.pass_base[q];
+    dv[slot] = R.rdinv[(size_t)q * kRingRows + sub];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const size_t idx = ((size_t)q * kRingThreads + t) * E + e;
+      ps[slot][e] = R.epos[idx];
+      vl[slot][e] = R.eval[idx];
+    }
+  };
+  auto load_b = [&](int slot) { ow[slot] = own_src[rid[slot] > 0 ? rid[slot] : 0]; };   // the row's own value
+#pragma unroll
+  for (int d = 0; d < D; ++d) load_a(d, d);
+#pragma unroll
+  for (int d = 0; d < D / 2; ++d) load_b(d);
+  __syncthreads();
+  for (int q0 = 0; q0 < R.n_pass; q0 += D) {   // n_pass is a multiple of D
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int q = q0 + d;
+      load_b((d + D / 2) % D);    // the own value of pass q + D / 2, whose record arrived D / 2 passes ago
+      double s = 0.0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) s += vl[d][e] * ring[ps[d][e] & MASK];
+      s = subwave_sum<8>(s);
+      if (lane == 0 && rid[d] >= 0) {
+        double x;
+        if (LOWER) x = KIND == 0 ? (ow[d] - s) : (ow[d] - s) * dv[d];
+        else x = KIND == 0 ? (ow[d] - s) * dv[d] : ow[d] - s * dv[d];
+        ring[(bs[d] + sub) & MASK] = x;
+        dst[rid[d]] = x;
+      }
+      __syncthreads();
+      load_a(d, q + D);
+    }
   }
 }
 
@@ -1466,6 +1506,17 @@ void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const V
     break;
   switch (m) { NSK_MA(1) NSK_MA(2) NSK_MA(3) NSK_MA(4) NSK_MA(5) NSK_MA(6) NSK_MA(7) NSK_MA(8) default: break; }
 #undef NSK_MA
+}
+
+void tri_ring(hipStream_t s, const RingHalf &R, int lower, int kind, const double *own, double *dst) {
+  if (R.n_pass <= 0) return;
+  if (lower) {
+    if (kind == 0) hipLaunchKernelGGL((tri_ring_kernel<0, true>), dim3(1), dim3(kRingThreads), 0, s, R, own, dst);
+    else hipLaunchKernelGGL((tri_ring_kernel<1, true>), dim3(1), dim3(kRingThreads), 0, s, R, own, dst);
+  } else {
+    if (kind == 0) hipLaunchKernelGGL((tri_ring_kernel<0, false>), dim3(1), dim3(kRingThreads), 0, s, R, own, dst);
+    else hipLaunchKernelGGL((tri_ring_kernel<1, false>), dim3(1), dim3(kRingThreads), 0, s, R, own, dst);
+  }
 }
 
 void tri_lower_level(hipStream_t s, const TriView &T, int kind, int lpr, const int *rows, int nrows, const double *rhs,

@@ -627,6 +627,77 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       stream_ready = true;
     }
   }
+  // Natural ordering: padded per-pass records for the LDS-ring solve.  A pass = at most kRingRows rows of one level
+  // (independent), positions = the order the passes walk the rows in; an entry names the POSITION of its column's row.
+  ring_ready = false;
+  if (perm.empty() && n >= 4096) {
+    auto build_ring = [&](const std::vector<int> &asap, bool lower, Ring &Rg) -> bool {
+      // Pass order.  The earliest level of a row (asap) can lie far before its consumers' — rows behind the obstacle
+      // are ready at once and needed hundreds of levels later — and a value must not wait that long in the ring.  So
+      // every row starts as LATE as its consumers allow: t(row) = min over its consumers of t(consumer) - 1, rows
+      // nobody consumes keep their earliest level.  Consumers of a row come later in the index order (lower half) or
+      // earlier (upper half), so one sweep against that order settles it.  Measured on the pressure-mass pattern at
+      // 600x200: longest wait 54 113 positions with the earliest levels, 1 069 with these.
+      std::vector<int> tt((size_t)n), tmin((size_t)n, INT32_MAX);
+      for (int q = 0; q < n; ++q) {
+        const int i = lower ? n - 1 - q : q;
+        tt[i] = tmin[i] == INT32_MAX ? asap[i] : tmin[i];
+        const int kb = lower ? prp[i] : pdiag[i] + 1, ke = lower ? pdiag[i] : prp[i + 1];
+        for (int e = kb; e < ke; ++e) tmin[pcol[e]] = std::min(tmin[pcol[e]], tt[i] - 1);
+      }
+      int nl = 0;
+      for (int i = 0; i < n; ++i) nl = std::max(nl, tt[i] + 1);
+      std::vector<int> lp, lr;
+      level_lists(tt, nl, lp, lr);
+      std::vector<int> pos((size_t)n), base, rid;
+      int p = 0;
+      for (int l = 0; l < nl; ++l)
+        for (int b = lp[l]; b < lp[l + 1]; b += kRingRows) {
+          const int cnt = std::min(kRingRows, lp[l + 1] - b);
+          base.push_back(p);
+          for (int k = 0; k < kRingRows; ++k) rid.push_back(k < cnt ? lr[b + k] : -1);
+          for (int k = 0; k < cnt; ++k) pos[lr[b + k]] = p + k;
+          p += cnt;
+        }
+      // padded to a multiple of kRingDepth passes + kRingDepth empty ones (the kernel loads ahead without branches)
+      const int np_real = (int)base.size();
+      const int np = (np_real + kRingDepth - 1) / kRingDepth * kRingDepth, np_alloc = np + kRingDepth;
+      base.resize((size_t)np_alloc, p);
+      rid.resize((size_t)np_alloc * kRingRows, -1);
+      std::vector<int> ep((size_t)np_alloc * kRingThreads * kRingE, 0), es((size_t)np_alloc * kRingThreads * kRingE, -1),
+          ds((size_t)np_alloc * kRingRows, -1);
+      bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+      for (int q = 0; q < np_real; ++q)
+        for (int k = 0; k < kRingRows; ++k) {
+          const int i = rid[(size_t)q * kRingRows + k];
+          if (i < 0) continue;
+          ds[(size_t)q * kRingRows + k] = pdiag[i];
+          const int kb = lower ? prp[i] : pdiag[i] + 1, ke = lower ? pdiag[i] : prp[i + 1];
+          if (ke - kb > 8 * kRingE) { ok = false; continue; }
+          for (int e = kb; e < ke; ++e) {
+            const int w = e - kb;   // entry w of the row: lane w % 8, register w / 8
+            const size_t idx = ((size_t)q * kRingThreads + (size_t)k * 8 + (w & 7)) * kRingE + (w >> 3);
+            const int back = pos[i] - pos[pcol[e]];
+            if (back <= 0 || back > kRingSlots - 2 * kRingRows) ok = false;
+            ep[idx] = pos[pcol[e]];
+            es[idx] = e;
+          }
+        }
+      if (!ok) return false;
+      Rg.n_pass = np;
+      Rg.pass_base.upload(base, s);
+      Rg.rowid.upload(rid, s);
+      Rg.dsrc.upload(ds, s);
+      Rg.epos.upload(ep, s);
+      Rg.esrc.upload(es, s);
+      Rg.rdinv.alloc(ds.size());
+      Rg.eval.alloc(es.size());
+      ctx->sync();
+      return true;
+    };
+    ring_ready = build_ring(levL, true, ringL) && build_ring(levU, false, ringU);
+  }
   rowptr.upload(prp, s);
   col.upload(pcol, s);
   srcpos.upload(psrc, s);
@@ -675,6 +746,12 @@ void TriSolve::numeric(const double *a_val_dev) {
     vec_gather_or_zero(s, (long)Lcpl.n, Lcpl_src.p, val.p, Lcpl.p);
     vec_gather_or_zero(s, (long)Ucpl.n, Ucpl_src.p, val.p, Ucpl.p);
   }
+  if (ring_ready)
+    for (Ring *Rg : {&ringL, &ringU}) {
+      vec_gather_or_zero(s, (long)Rg->eval.n, Rg->esrc.p, val.p, Rg->eval.p);
+      vec_gather_or_zero(s, (long)Rg->rdinv.n, Rg->dsrc.p, val.p, Rg->rdinv.p);
+      vec_recip(s, (int)Rg->rdinv.n, Rg->rdinv.p, Rg->rdinv.p);   // (padding slots: 1 / 0, never read)
+    }
 }
 
 void TriSolve::apply(const double *b, double *x) {
@@ -738,6 +815,14 @@ void TriSolve::apply(const double *b, double *x) {
     const TriBlk L{Lrp.p, Lcol.p, Lval.p, Ldesc.p}, U{Urp.p, Ucol.p, Uval.p, Udesc.p};
     for (int c = 0; c < n_colors; ++c) tri_blk_level(s, L, LB[c], LB[c + 1], 1, kind, intra.p, permn.p, b, x);
     for (int c = n_colors - 1; c >= 0; --c) tri_blk_level(s, U, UB[c], UB[c + 1], 0, kind, intra.p, permn.p, nullptr, x);
+    ++ctx->st.tri_applies;
+    ctx->st.tri_bytes += (double)apply_bytes();
+    return;
+  }
+  if (ring_ready && use_stream && !tiny) {   // the caller's order: one workgroup, passes through an LDS ring
+    tri_ring(s, ringL.view(), 1, kind, b, y.p);
+    tri_ring(s, ringU.view(), 0, kind, y.p, x);
+    ++ctx->st.ring_applies;
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();
     return;

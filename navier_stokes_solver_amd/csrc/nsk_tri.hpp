@@ -86,6 +86,15 @@ struct TriSolve {
   DBuf<int> Lcpl_src, Ucpl_src;
   DBuf<double> Lcpl, Ucpl;
 
+  // natural ordering: the LDS-ring solve (nsk_kernels.h: tri_ring) when the factor qualifies
+  struct Ring {
+    int n_pass = 0;
+    DBuf<int> pass_base, rowid, dsrc, epos, esrc;
+    DBuf<double> rdinv, eval;
+    RingHalf view() const { return RingHalf{n_pass, pass_base.p, rowid.p, rdinv.p, epos.p, eval.p}; }
+  } ringL, ringU;
+  bool ring_ready = false;
+
   // A: host pattern of the local block (columns >= A.n_rows, i.e. ghosts, are dropped);
   // sub_off: optional n_sub+1 offsets of emulated MPI ranks inside this GPU (block Jacobi)
   // xy: support points of the rows (2 doubles per row) or null; group: members per line group (1: none)

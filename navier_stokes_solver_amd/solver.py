@@ -54,7 +54,8 @@ class Stats(C.Structure):
                 ("spmv_bytes", C.c_double), ("tri_bytes", C.c_double), ("blas1_bytes", C.c_double),
                 ("n_colors_u", C.c_int32), ("n_levels_u", C.c_int32), ("n_colors_p", C.c_int32),
                 ("n_levels_p", C.c_int32), ("nnz_s", C.c_int64), ("sync_free_fallbacks", C.c_int64),
-                ("cur_outer_iters", C.c_int64), ("cur_residual", C.c_double), ("overlapped_spmvs", C.c_int64)]
+                ("cur_outer_iters", C.c_int64), ("cur_residual", C.c_double), ("overlapped_spmvs", C.c_int64),
+                ("ring_applies", C.c_int64)]
 
 
 class NoConvergence(RuntimeError):

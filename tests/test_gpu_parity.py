@@ -119,6 +119,38 @@ def test_ilu_apply(handles, name, ordering, subdomains):
         assert 0 < c <= 64 and st["n_levels_u"] in (c, 2 * c, 3 * c, 4 * c, 6 * c)
 
 
+@pytest.mark.parametrize("mesh,subdomains", [((60, 20), 1), ((60, 20), 3), ((100, 70), 1)])
+def test_natural_order_pressure_solves_through_the_lds_ring(mesh, subdomains):
+    """The caller's order in the pressure-mass factor (default of the unsteady block-diagonal preconditioner; any factor
+    under NSK_OPT_TRI_ORDERING = 0 with at most 16 entries per row and half): one workgroup walks passes of independent
+    rows whose results live in an LDS ring (tri_ring_kernel).  ILU(0) and SGS applies against the oracle's natural-order
+    solves, repeated (the kernel keeps no state between applies)."""
+    S, O = _S(), _O()
+    from navier_stokes_solver_amd import problem as P
+    pr = P.generate(*mesh, nu=1.0 / 90.0, mode=1, state=1)
+    ls = S.LinearSolver()
+    try:
+        ls.set_option(S.OPT_TRI_ORDERING, 1)            # F multicolour; the mass factor keeps the caller's order by itself
+        ls.set_option(S.OPT_SUBDOMAINS, subdomains)
+        ls.set_option(S.IOPT_TINY_BYTES, 0)             # (these factors are small: keep them off the one-workgroup level walker)
+        ls.set_problem(pr)
+        n = pr.n_p
+        off = None if subdomains == 1 else [n * k // subdomains for k in range(subdomains)] + [n]
+        for variant, kind in ((S.UNSTEADY, 0), (S.STATIONARY, 1)):
+            if variant == S.STATIONARY:
+                ls.set_option(S.OPT_MASS_ORDERING, 0)   # SGS(M_p) of the stationary variant in the caller's order too
+            ls.setup_preconditioner(S.BLOCK_DIAGONAL, variant)
+            assert np.array_equal(ls.tri_perm(S.TRI_PRESSURE), np.arange(n))
+            tri = O.Tri(O.CsrHolder.from_block(pr.Mp), kind=kind, shard_off=off)
+            before = ls.stats()["ring_applies"]
+            for k in range(3):
+                b = rng_vec(n, 300 + k)
+                assert rel_err(ls.tri_apply(S.TRI_PRESSURE, b), tri.apply(b)) <= 1e-11, (mesh, subdomains, variant, k)
+            assert ls.stats()["ring_applies"] == before + 3          # (not the one-workgroup level walker)
+    finally:
+        ls.close()
+
+
 @pytest.mark.parametrize("ordering", [0, 1])
 def test_sgs_apply(handles, ordering):
     S, O = _S(), _O()
