@@ -217,15 +217,23 @@ void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, 
 // indexed by the row's position in the pass order: the critical path of a pass is LDS + one barrier, not a trip to HBM.
 // Requirements (checked by the analysis): at most 8 * kRingE entries per row and half, and every dependency at most
 // kRingSlots - 2 * kRingRows positions back.
-constexpr int kRingThreads = 1024, kRingRows = 128, kRingE = 2, kRingSlots = 4096, kRingDepth = 8;
+// Shape: 8 lanes per row, 2 entries per lane (rows of <= 16 entries per half), 128 rows per pass, 8 passes ahead — the
+// lane decomposition, the order of the row sums and the DIVISION by the diagonal of the level walker (tri_row<8>), so
+// that both give the same bits.  (4 lanes x 3 entries, 256 rows per pass = one pass per level on the reference's
+// lattices, measured 9.5 against 10.9 ms per application at 600x200; its other summation order tipped the third Newton
+// system of config 5 from 1 363 iterations into a stall — DESIGN.md 5d.1 — and it was not kept.)
+constexpr int kRingThreads = 1024, kRingSlots = 8192;   // (the ring: 64 KB of LDS)
 struct RingHalf {
-  int n_pass;
-  const int *pass_base;   // [n_pass] position (in pass order) of the pass's first row
-  const int *rowid;       // [n_pass * kRingRows] row of (pass, slot) or -1
-  const double *rdinv;    // [n_pass * kRingRows] 1 / diagonal of that row
-  const int *epos;        // [n_pass * kRingThreads * kRingE] position of the entry's column row (0 for padding)
-  const double *eval;     // [n_pass * kRingThreads * kRingE] value (0 for padding)
+  int n_pass;             // a multiple of the shape's look-ahead depth; the records hold `depth` empty passes more
+  int lpr;                // lanes per row: 8 (E = 2, depth 8)
+  const int *pass_base;   // [passes] position (in pass order) of the pass's first row
+  const int *rowid;       // [passes * rows_per_pass] row of (pass, slot) or -1
+  const double *rdiag;    // [passes * rows_per_pass] diagonal of that row
+  const int *epos;        // [passes * kRingThreads * E] position of the entry's column row (0 for padding)
+  const double *eval;     // [passes * kRingThreads * E] value (0 for padding)
 };
+constexpr int ring_entries(int lpr) { return lpr == 8 ? 2 : 3; }
+constexpr int ring_depth(int lpr) { return lpr == 8 ? 8 : 6; }
 // lower: y[i] = kind ? (rhs[i] - s) * dinv : rhs[i] - s ; upper: out[i] = kind ? y[i] - s * dinv : (y[i] - s) * dinv
 void tri_ring(hipStream_t s, const RingHalf &R, int lower, int kind, const double *own, double *dst);
 

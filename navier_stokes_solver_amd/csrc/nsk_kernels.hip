@@ -887,12 +887,12 @@ __global__ __launch_bounds__(SERIAL_BLK) void tri_serial_kernel(TriView T, const
 }
 
 // ------------------------------------------------------------------ natural-order solve through an LDS ring
-template <int KIND, bool LOWER>
+template <int KIND, bool LOWER, int LPR>
 __global__ __launch_bounds__(kRingThreads) void tri_ring_kernel(RingHalf R, const double *__restrict__ own_src,
                                                                 double *__restrict__ dst) {
   __shared__ double ring[kRingSlots];
-  constexpr int D = kRingDepth, E = kRingE, MASK = kRingSlots - 1;
-  const int t = threadIdx.x, sub = t >> 3, lane = t & 7;
+  constexpr int D = ring_depth(LPR), E = ring_entries(LPR), MASK = kRingSlots - 1, kRingRows = kRingThreads / LPR;
+  const int t = threadIdx.x, sub = t / LPR, lane = t % LPR;
   for (int k = t; k < kRingSlots; k += kRingThreads) ring[k] = 0.0;
   int rid[D], bs[D], ps[D][E];
   double dv[D], vl[D][E], ow[D];
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(kRingThreads) void tri_ring_kernel(RingHalf R, cons
   auto load_a = [&](int slot, int q) {   // the pass's padded record: no load depends on another
     rid[slot] = R.rowid[(size_t)q * kRingRows + sub];
     bs[slot] = R.pass_base[q];
-    dv[slot] = R.rdinv[(size_t)q * kRingRows + sub];
+    dv[slot] = R.rdiag[(size_t)q * kRingRows + sub];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const size_t idx = ((size_t)q * kRingThreads + t) * E + e;
@@ -924,11 +924,11 @@ __global__ __launch_bounds__(kRingThreads) void tri_ring_kernel(RingHalf R, cons
       double s = 0.0;
 #pragma unroll
       for (int e = 0; e < E; ++e) s += vl[d][e] * ring[ps[d][e] & MASK];
-      s = subwave_sum<8>(s);
+      s = subwave_sum<LPR>(s);
       if (lane == 0 && rid[d] >= 0) {
         double x;
-        if (LOWER) x = KIND == 0 ? (ow[d] - s) : (ow[d] - s) * dv[d];
-        else x = KIND == 0 ? (ow[d] - s) * dv[d] : ow[d] - s * dv[d];
+        if (LOWER) x = KIND == 0 ? (ow[d] - s) : (ow[d] - s) / dv[d];      // (divisions, as tri_row: same bits)
+        else x = KIND == 0 ? (ow[d] - s) / dv[d] : ow[d] - s / dv[d];
         ring[(bs[d] + sub) & MASK] = x;
         dst[rid[d]] = x;
       }
@@ -1510,13 +1510,10 @@ void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const V
 
 void tri_ring(hipStream_t s, const RingHalf &R, int lower, int kind, const double *own, double *dst) {
   if (R.n_pass <= 0) return;
-  if (lower) {
-    if (kind == 0) hipLaunchKernelGGL((tri_ring_kernel<0, true>), dim3(1), dim3(kRingThreads), 0, s, R, own, dst);
-    else hipLaunchKernelGGL((tri_ring_kernel<1, true>), dim3(1), dim3(kRingThreads), 0, s, R, own, dst);
-  } else {
-    if (kind == 0) hipLaunchKernelGGL((tri_ring_kernel<0, false>), dim3(1), dim3(kRingThreads), 0, s, R, own, dst);
-    else hipLaunchKernelGGL((tri_ring_kernel<1, false>), dim3(1), dim3(kRingThreads), 0, s, R, own, dst);
-  }
+#define NSK_RING(K, L, W) hipLaunchKernelGGL((tri_ring_kernel<K, L, W>), dim3(1), dim3(kRingThreads), 0, s, R, own, dst)
+  if (lower) { if (kind == 0) NSK_RING(0, true, 8); else NSK_RING(1, true, 8); }
+  else { if (kind == 0) NSK_RING(0, false, 8); else NSK_RING(1, false, 8); }
+#undef NSK_RING
 }
 
 void tri_lower_level(hipStream_t s, const TriView &T, int kind, int lpr, const int *rows, int nrows, const double *rhs,

@@ -631,7 +631,8 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   // (independent), positions = the order the passes walk the rows in; an entry names the POSITION of its column's row.
   ring_ready = false;
   if (perm.empty() && n >= 4096) {
-    auto build_ring = [&](const std::vector<int> &asap, bool lower, Ring &Rg) -> bool {
+    auto build_ring = [&](const std::vector<int> &asap, bool lower, int lpr, Ring &Rg) -> bool {
+      const int kRingRows = kRingThreads / lpr, kRingE = ring_entries(lpr), kRingDepth = ring_depth(lpr);
       // Pass order.  The earliest level of a row (asap) can lie far before its consumers' — rows behind the obstacle
       // are ready at once and needed hundreds of levels later — and a value must not wait that long in the ring.  So
       // every row starts as LATE as its consumers allow: t(row) = min over its consumers of t(consumer) - 1, rows
@@ -674,10 +675,10 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
           if (i < 0) continue;
           ds[(size_t)q * kRingRows + k] = pdiag[i];
           const int kb = lower ? prp[i] : pdiag[i] + 1, ke = lower ? pdiag[i] : prp[i + 1];
-          if (ke - kb > 8 * kRingE) { ok = false; continue; }
+          if (ke - kb > lpr * kRingE) { ok = false; continue; }
           for (int e = kb; e < ke; ++e) {
-            const int w = e - kb;   // entry w of the row: lane w % 8, register w / 8
-            const size_t idx = ((size_t)q * kRingThreads + (size_t)k * 8 + (w & 7)) * kRingE + (w >> 3);
+            const int w = e - kb;   // entry w of the row: lane w % lpr, register w / lpr
+            const size_t idx = ((size_t)q * kRingThreads + (size_t)k * lpr + (w % lpr)) * kRingE + (w / lpr);
             const int back = pos[i] - pos[pcol[e]];
             if (back <= 0 || back > kRingSlots - 2 * kRingRows) ok = false;
             ep[idx] = pos[pcol[e]];
@@ -686,17 +687,19 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
         }
       if (!ok) return false;
       Rg.n_pass = np;
+      Rg.lpr = lpr;
       Rg.pass_base.upload(base, s);
       Rg.rowid.upload(rid, s);
       Rg.dsrc.upload(ds, s);
       Rg.epos.upload(ep, s);
       Rg.esrc.upload(es, s);
-      Rg.rdinv.alloc(ds.size());
+      Rg.rdiag.alloc(ds.size());
       Rg.eval.alloc(es.size());
       ctx->sync();
       return true;
     };
-    ring_ready = build_ring(levL, true, ringL) && build_ring(levU, false, ringU);
+    const int lpr_ring = 8;
+    ring_ready = build_ring(levL, true, lpr_ring, ringL) && build_ring(levU, false, lpr_ring, ringU);
   }
   rowptr.upload(prp, s);
   col.upload(pcol, s);
@@ -749,8 +752,7 @@ void TriSolve::numeric(const double *a_val_dev) {
   if (ring_ready)
     for (Ring *Rg : {&ringL, &ringU}) {
       vec_gather_or_zero(s, (long)Rg->eval.n, Rg->esrc.p, val.p, Rg->eval.p);
-      vec_gather_or_zero(s, (long)Rg->rdinv.n, Rg->dsrc.p, val.p, Rg->rdinv.p);
-      vec_recip(s, (int)Rg->rdinv.n, Rg->rdinv.p, Rg->rdinv.p);   // (padding slots: 1 / 0, never read)
+      vec_gather_or_zero(s, (long)Rg->rdiag.n, Rg->dsrc.p, val.p, Rg->rdiag.p);   // (padding slots: 0, never used)
     }
 }
 

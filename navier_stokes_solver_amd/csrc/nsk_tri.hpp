@@ -88,10 +88,10 @@ struct TriSolve {
 
   // natural ordering: the LDS-ring solve (nsk_kernels.h: tri_ring) when the factor qualifies
   struct Ring {
-    int n_pass = 0;
+    int n_pass = 0, lpr = 8;
     DBuf<int> pass_base, rowid, dsrc, epos, esrc;
-    DBuf<double> rdinv, eval;
-    RingHalf view() const { return RingHalf{n_pass, pass_base.p, rowid.p, rdinv.p, epos.p, eval.p}; }
+    DBuf<double> rdiag, eval;
+    RingHalf view() const { return RingHalf{n_pass, lpr, pass_base.p, rowid.p, rdiag.p, epos.p, eval.p}; }
   } ringL, ringU;
   bool ring_ready = false;
 

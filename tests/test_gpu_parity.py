@@ -147,6 +147,12 @@ def test_natural_order_pressure_solves_through_the_lds_ring(mesh, subdomains):
                 b = rng_vec(n, 300 + k)
                 assert rel_err(ls.tri_apply(S.TRI_PRESSURE, b), tri.apply(b)) <= 1e-11, (mesh, subdomains, variant, k)
             assert ls.stats()["ring_applies"] == before + 3          # (not the one-workgroup level walker)
+            # the walker (NSK_OPT_STREAM_KERNELS = 0) sums and divides in the same order: same bits
+            x_ring = ls.tri_apply(S.TRI_PRESSURE, b)
+            ls.set_option(S.OPT_STREAM_KERNELS, 0)
+            x_walk = ls.tri_apply(S.TRI_PRESSURE, b)
+            ls.set_option(S.OPT_STREAM_KERNELS, 1)
+            assert ls.stats()["ring_applies"] == before + 4 and np.array_equal(x_ring, x_walk)
     finally:
         ls.close()
 

@@ -96,9 +96,10 @@ def test_multi_rank_path_over_gloo(world):
     # and the grouped two-space exchange race as they would under RCCL)
     (2, 2, 1, 0, "unsteady16+onstream"), (3, 2, 1, 1, "unsteady16+onstream"), (2, 2, 0, 1, "ns16+onstream"),
     (2, 0, 0, 0, "ns16+onstream"), (2, 1, 0, 1, "ns16+onstream"),
-    (2, 2, 0, 1, "ns16_re200+onstream"),   # north_star / BASELINE configs[3]: FGMRES + aSIMPLE at nu = 1/190, row-partitioned
     (2, 2, 0, 1, "ns16+cg1+onstream"),     # the same with the single-reduction inner CG (NSK_OPT_CG_SINGLE_REDUCTION)
-    (3, 2, 0, 1, "ns16_re200+cg1+gs2+onstream"),   # what bench.py --gpus N runs: plus one reduction per inner FGMRES iteration
+    # north_star / BASELINE configs[3]: FGMRES + aSIMPLE at nu = 1/190, row-partitioned, with what bench.py --gpus N runs:
+    # single-reduction inner CG and one reduction per inner FGMRES iteration
+    (3, 2, 0, 1, "ns16_re200+cg1+gs2+onstream"),
     (2, 2, 0, 1, "ns16+noovl+onstream"),   # halo exchange first, then one SpMV launch (default: interior rows overlap it)
 ])
 def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name):
