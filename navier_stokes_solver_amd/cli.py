@@ -219,6 +219,97 @@ def run_gmsh(cfg, unsteady: bool) -> int:
     return 0
 
 
+def run_ranks(cfg, unsteady: bool, nranks: int) -> int:
+    """`mpirun -n N StationaryNSSolver / NSSolver -m X,Y` (NSSolverStationary.cpp:226-242: DoFs distributed by mesh
+    partition): N ranks own x-strips of the mesh, each with its own handle, device-resident state and the SAME driver
+    loop — assembly, halo exchanges, global reductions and the rank-local preconditioners are the library's multi-rank
+    path.  The ranks are threads of this process joined by the in-process transport (one GPU each when the process sees
+    several, else sharing the one there is): what `NSK_RANKS=N` selects.  Every rank writes its VTU piece, rank 0 the
+    .pvtu record; lift / drag are summed over the ranks' shares (Utilities::MPI::sum, .cpp:895-896)."""
+    import threading
+
+    import numpy as np
+    import torch
+
+    from . import newton as N
+    from . import partition as PT
+    from . import postprocess as PP
+    from . import problem as P
+    from . import solver as S
+    nx, ny = cfg["mx"], cfg["my"]
+    if nranks > nx:
+        raise ValueError("more ranks than cell columns")
+    ndev = max(1, torch.cuda.device_count())
+    uid = S.local_group_id(nranks, on_stream=(ndev == 1))
+    U = 0.3 if unsteady else 0.1
+    nu0 = 1.0 if unsteady else 0.1
+    firsts = [P.generate(nx, ny, nu=nu0, mode=0, state=0, inlet_bc=1, U=U, nranks=nranks, rank=r) for r in range(nranks)]
+    ur, prg = firsts[0].u_ranges, firsts[0].p_ranges
+    plans = [{S.SPACE_U: PT.build_halo_plan(r, ur, [q.ghost_u for q in firsts]),
+              S.SPACE_P: PT.build_halo_plan(r, prg, [q.ghost_p for q in firsts])} for r in range(nranks)]
+    n_u, n_p = int(ur[-1]), int(prg[-1])
+    meet = threading.Barrier(nranks)
+    shared = {"u": [None] * nranks, "p": [None] * nranks, "f": [None] * nranks, "stats": [None] * nranks}
+    errs = []
+
+    def rank_main(r):
+        say = print if r == 0 else (lambda *_a, **_k: None)
+        ls = None
+        try:
+            ls = S.LinearSolver(r, nranks, r % ndev, uid)
+            ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
+            backend = N.DeviceBackend(ls, firsts[r], cfg["solver"], cfg["prec"], cfg["tol"],
+                                      max_iter=100000 if unsteady else 20000, inv_dt=1.0 / cfg["dt"] if unsteady else 0.0,
+                                      plan=plans[r])
+
+            def report(nu, inlet_u, name, counter, n_digits):
+                # the ranks' owned pieces side by side are the global vectors (x-strips own contiguous ranges)
+                shared["u"][r], shared["p"][r] = backend.solution()
+                meet.wait()
+                u, p = np.concatenate(shared["u"]), np.concatenate(shared["p"])
+                say("===============================================")
+                PP.write_vtu(os.environ.get("NSK_OUTPUT_DIR", "./"), name, counter, nx, ny, u, p, n_digits=n_digits, rank=r,
+                             nranks=nranks)
+                say("Output written to output-stokes")
+                say("===============================================")
+                say("===============================================\nComputing lift and drag forces")
+                shared["f"][r] = PP.lift_drag(nx, ny, u, p, nu, rank=r, nranks=nranks)
+                meet.wait()
+                drag, lift = sum(f[0] for f in shared["f"]), sum(f[1] for f in shared["f"])
+                cd, cl = PP.coefficients(drag, lift, inlet_u)
+                say(f"===============================================\nLift coefficient: {cl:g}")
+                say(f"===============================================\nDrag coefficient: {cd:g}")
+                meet.wait()
+
+            t0 = time.time()
+            if unsteady:
+                nu_last = 1.0 / max(_levels(1.0, 10.0, cfg["Re"]))
+                N.time_loop(backend, cfg["T"], cfg["dt"], cfg["Re"], log=say,
+                            after_step=lambda step: report(nu_last, 0.3, "output", step, 3))
+            else:
+                N.solve_newton(backend, cfg["Re"], log=say)
+                report(1.0 / max(_levels(10.0, 20.0, cfg["Re"])), 1.0, "output-stokes", 0, None)
+            dt = time.time() - t0
+            its = backend.total_linear_iterations
+            say(f"[nsk] {nranks} ranks, {backend.assemblies} assemblies, {its} outer iterations of solve_system(), {dt:.3f} s in "
+                f"{'the time loop' if unsteady else 'solve_newton'} -> {(n_u + n_p) * its / max(dt, 1e-12):.4g} DoF*iters/s")
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+            meet.abort()
+        finally:
+            if ls is not None:
+                ls.close()
+
+    print(f"  Number of ranks            = {nranks} (cell columns per rank: "
+          f"{' '.join(str(b - a) for a, b in zip(PP.cell_columns(nx, nranks)[:-1], PP.cell_columns(nx, nranks)[1:]))})")
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errs:
+        raise RuntimeError(f"rank failures: {errs}")
+    return 0
+
+
 def run(cfg, unsteady: bool) -> int:
     from . import problem as P
     from . import solver as S
@@ -235,6 +326,8 @@ def run(cfg, unsteady: bool) -> int:
     print(f"    velocity = {info['n_u_global']}\n    pressure = {info['n_p_global']}\n"
           f"    total    = {info['n_u_global'] + info['n_p_global']}")
     print("-----------------------------------------------")
+    if int(os.environ.get("NSK_RANKS", "1")) > 1:
+        return run_ranks(cfg, unsteady, int(os.environ["NSK_RANKS"]))
     if not unsteady:
         # the reference's solve_newton() over device-resident state: assembly, linear solves and updates on the GPU
         from . import newton as N

@@ -181,7 +181,9 @@ class DeviceBackend:
     """Everything resident on the GPU.  `pr` is the hand-off of the first assembly (pattern, constant blocks at
     viscosity `pr.params['nu']`, Stokes signs, inhomogeneous inlet values in x0_u)."""
 
-    def __init__(self, ls, pr, solver, preconditioner, tolerance, max_iter=20000, alpha=0.5, inv_dt=0.0):
+    def __init__(self, ls, pr, solver, preconditioner, tolerance, max_iter=20000, alpha=0.5, inv_dt=0.0, plan=None):
+        """`plan`: the rank's halo plans when `ls` is one rank of several (`pr` then holds that rank's rows); every rank
+        runs the same driver loop over its own backend — the norms and iteration counts the loop decides on are global."""
         from . import solver as S
         self.S, self.ls = S, ls
         self.inv_dt = inv_dt                  # 0: stationary driver; 1/delta_t: unsteady driver (NSSolver)
@@ -191,7 +193,7 @@ class DeviceBackend:
         self.nu_mp = pr.params["nu"]          # pressure_mass currently holds 1/nu_mp * M
         self.stokes_signs = True
         self.p_out = pr.params["p_out"]
-        ls.set_problem(pr)
+        ls.set_problem(pr, plan)
         ls.set_assembly(pr, bc_u=pr.x0_u)     # x0_u: inlet profile on the inlet DoFs, 0 elsewhere
         import numpy as np
         ls.state_set(np.zeros(pr.n_u), np.zeros(pr.n_p))     # solution = 0 (setup(), .cpp:308-311)

@@ -152,3 +152,39 @@ def test_cpp_unsteady_driver_runs():
     # two time steps, continuation 1 and 11 inside each, device assemblies
     assert "n =   1" in out.stdout and "n =   2" in out.stdout and "Solving for Re = 0.22" in out.stdout
     assert "[nsk]" in out.stdout and "the time loop" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("driver,args", [("StationaryNSSolver", ["-m", "16,10", "-r", "30", "-s", "1", "-p", "2", "-t", "1e-10"]),
+                                         ("NSSolver", ["-T", "0.02,0.01", "-m", "16,10", "-r", "1", "-s", "1", "-p", "2", "-t", "1e-10"])])
+def test_drivers_on_two_ranks_follow_the_one_rank_run(tmp_path, monkeypatch, driver, args):
+    """`mpirun -n 2 StationaryNSSolver / NSSolver` (NSK_RANKS = 2: rank threads, one handle and one x-strip each, device
+    assembly + solves on the library's multi-rank path): the Newton residuals line by line, the coefficients and the
+    rank pieces against the one-rank run of the same command."""
+    import os
+    import re
+    texts = []
+    for n in (1, 2):
+        d = tmp_path / f"r{n}"
+        d.mkdir()
+        monkeypatch.setenv("NSK_OUTPUT_DIR", str(d))
+        monkeypatch.setenv("NSK_RANKS", str(n))
+        out = io.StringIO()
+        with redirect_stdout(out):
+            assert cli.main([driver] + args) == 0
+        texts.append(out.getvalue())
+    monkeypatch.delenv("NSK_RANKS")
+    assert "Number of ranks            = 2" in texts[1]
+    res = [[float(v) for v in re.findall(r"Newton iteration \d+/\d+ - \|\|r\|\| = ([0-9.e+-]+)", t)] for t in texts]
+    assert len(res[0]) == len(res[1]) >= 3
+    for a, b in zip(*res):
+        assert abs(a - b) <= 1e-6 * a + 1e-9, (a, b)            # same Newton path (solves to 1e-10)
+    coef = lambda t, key: [float(v) for v in re.findall(key + r" ([0-9.e+-]+)", t)]  # noqa: E731
+    for key in ("Lift coefficient:", "Drag coefficient:"):
+        a, b = coef(texts[0], key), coef(texts[1], key)
+        assert len(a) == len(b) >= 1
+        scale = max(abs(v) for v in coef(texts[0], "Drag coefficient:"))
+        assert all(abs(x - y) <= 1e-6 * scale for x, y in zip(a, b)), (key, a, b)
+    stem = "output-stokes_0" if driver == "StationaryNSSolver" else "output_001"
+    assert all(os.path.exists(tmp_path / "r2" / f"{stem}.{r}.vtu") for r in range(2))
+    assert os.path.exists(tmp_path / "r2" / f"{stem}.pvtu")
