@@ -119,6 +119,46 @@ def test_ilu_apply(handles, name, ordering, subdomains):
         assert 0 < c <= 64 and st["n_levels_u"] in (c, 2 * c, 3 * c, 4 * c, 6 * c)
 
 
+@pytest.mark.parametrize("group_u,group_p,subdomains", [(2, 3, 1), (3, 2, 1), (1, 3, 1), (2, 1, 1), (2, 3, 3)])
+def test_line_group_sizes_in_the_single_launch_solves(group_u, group_p, subdomains):
+    """Every chain length of the single-launch kernels (tri_blk_sf_kernel / tri_stream_sf_kernel<..., GMAX = 1, 2, 3>):
+    pairs / triples of velocity nodes, pairs / triples of pressure DoFs, with emulated sub-domains (no group across a cut);
+    ILU(F), ILU(S) and SGS(M_p) applies against the oracle given the library's permutation, repeated applies."""
+    S, O = _S(), _O()
+    import scipy.sparse as sp
+    pr = problem("ns60")
+    ls = S.LinearSolver()
+    try:
+        ls.set_option(S.OPT_TRI_ORDERING, 1)
+        ls.set_option(S.OPT_TRI_LINE_GROUPS, 1)
+        ls.set_option(S.IOPT_GROUP_U, group_u)
+        ls.set_option(S.IOPT_GROUP_P, group_p)
+        ls.set_option(S.OPT_SUBDOMAINS, subdomains)
+        ls.set_option(S.IOPT_TINY_BYTES, 0)
+        ls.set_problem(pr)
+        ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+        offu = None if subdomains == 1 else [(pr.n_u * k // subdomains) & ~1 for k in range(subdomains)] + [pr.n_u]
+        offp = None if subdomains == 1 else [pr.n_p * k // subdomains for k in range(subdomains)] + [pr.n_p]
+        rp, col, val = ls.get_block(S.BLK_S)
+        Sm = sp.csr_matrix((val, col, rp), shape=(pr.n_p, pr.n_p))
+        triF = O.Tri(O.CsrHolder.from_block(pr.F), kind=0, shard_off=offu, perm=ls.tri_perm(S.TRI_VELOCITY))
+        triS = O.Tri(O.CsrHolder.from_scipy(Sm), kind=0, shard_off=offp, perm=ls.tri_perm(S.TRI_PRESSURE))
+        st = ls.stats()
+        assert st["n_colors_u"] <= (13 if group_u > 1 else 18) and st["n_colors_p"] <= (22 if group_p > 1 else 32)
+        for k in range(3):
+            bu, bp = rng_vec(pr.n_u, 400 + k), rng_vec(pr.n_p, 500 + k)
+            assert rel_err(ls.tri_apply(S.TRI_VELOCITY, bu), triF.apply(bu)) <= 1e-11, (group_u, k)
+            assert rel_err(ls.tri_apply(S.TRI_PRESSURE, bp), triS.apply(bp)) <= 1e-11, (group_p, k)
+        ls.setup_preconditioner(S.BLOCK_DIAGONAL, S.STATIONARY)          # SGS on F and on the pressure mass matrix
+        triM = O.Tri(O.CsrHolder.from_block(pr.Mp), kind=1, shard_off=offp, perm=ls.tri_perm(S.TRI_PRESSURE))
+        triG = O.Tri(O.CsrHolder.from_block(pr.F), kind=1, shard_off=offu, perm=ls.tri_perm(S.TRI_VELOCITY))
+        bu, bp = rng_vec(pr.n_u, 600), rng_vec(pr.n_p, 601)
+        assert rel_err(ls.tri_apply(S.TRI_PRESSURE, bp), triM.apply(bp)) <= 1e-11
+        assert rel_err(ls.tri_apply(S.TRI_VELOCITY, bu), triG.apply(bu)) <= 1e-11
+    finally:
+        ls.close()
+
+
 @pytest.mark.parametrize("mesh,subdomains", [((60, 20), 1), ((60, 20), 3), ((100, 70), 1)])
 def test_natural_order_pressure_solves_through_the_lds_ring(mesh, subdomains):
     """The caller's order in the pressure-mass factor (default of the unsteady block-diagonal preconditioner; any factor
