@@ -1,7 +1,6 @@
 // nsk_amg.cpp — see nsk_amg.hpp
 #include "nsk_amg.hpp"
 
-#include <omp.h>
 #include <memory>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +8,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+
+#include "nsk_amg_kernels.h"
 
 namespace nsk {
 namespace {
@@ -22,227 +23,11 @@ constexpr int kEigIts = 10;
 constexpr double kEigBoost = 1.1;
 constexpr double kChebyAlpha = 20.0;
 
-void host_mv(const HostCsr &A, const std::vector<double> &x, std::vector<double> &y) {
-#pragma omp parallel for schedule(static)
-  for (int i = 0; i < A.n_rows; ++i) {
-    double s = 0.0;
-    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) s += A.val[k] * x[A.col[k]];
-    y[i] = s;
-  }
-}
-
-// start vector of the power iteration: an integer hash of the row index, in [-0.5, 0.5)
-inline double start_entry(int i) {
-  const uint32_t h = (uint32_t)i * 2654435761u;
-  return (double)((h >> 8) & 0xffffu) / 65536.0 - 0.5;
-}
-
-double estimate_lambda(const HostCsr &A, const std::vector<double> &dinv) {
-  const int n = A.n_rows;
-  std::vector<double> x((size_t)n), y((size_t)n);
-  double nrm = 0.0;
-  for (int i = 0; i < n; ++i) { x[i] = start_entry(i); nrm += x[i] * x[i]; }
-  nrm = std::sqrt(nrm);
-  double lam = 1.0;
-  if (nrm > 0.0) {
-    for (int i = 0; i < n; ++i) x[i] /= nrm;
-    for (int it = 0; it < kEigIts; ++it) {
-      host_mv(A, x, y);
-      double s = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : s)
-      for (int i = 0; i < n; ++i) { y[i] *= dinv[i]; s += y[i] * y[i]; }
-      s = std::sqrt(s);
-      if (!(s > 0.0)) break;
-      lam = s;
-#pragma omp parallel for schedule(static)
-      for (int i = 0; i < n; ++i) x[i] = y[i] / s;
-    }
-  }
-  return kEigBoost * lam;
-}
-
-// agg[i] >= 0 aggregate id, -2 = no strong connection (not aggregated, empty prolongator row)
-int aggregate(const HostCsr &A, std::vector<int> &agg) {
-  const int n = A.n_rows;
-  std::vector<double> ad((size_t)n, 0.0);
-#pragma omp parallel for schedule(static)
-  for (int i = 0; i < n; ++i)
-    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
-      if (A.col[k] == i) ad[i] = std::fabs(A.val[k]);
-  const double t2 = kThreshold * kThreshold;
-  auto strong = [&](int i, int k) { return A.col[k] != i && A.val[k] * A.val[k] > t2 * ad[i] * ad[A.col[k]]; };
-  agg.assign((size_t)n, -1);
-#pragma omp parallel for schedule(static)
-  for (int i = 0; i < n; ++i) {
-    bool any = false;
-    for (int k = A.rp[i]; k < A.rp[i + 1] && !any; ++k) any = strong(i, k);
-    if (!any) agg[i] = -2;
-  }
-  int na = 0;
-  for (int i = 0; i < n; ++i) {  // phase 1 (order dependent by definition)
-    if (agg[i] != -1) continue;
-    bool free_nb = true;
-    for (int k = A.rp[i]; k < A.rp[i + 1] && free_nb; ++k)
-      if (strong(i, k) && agg[A.col[k]] >= 0) free_nb = false;
-    if (!free_nb) continue;
-    agg[i] = na;
-    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
-      if (strong(i, k) && agg[A.col[k]] == -1) agg[A.col[k]] = na;
-    ++na;
-  }
-  std::vector<int> join((size_t)n, -1);  // phase 2 on a snapshot of the phase-1 aggregates
-#pragma omp parallel for schedule(static)
-  for (int i = 0; i < n; ++i) {
-    if (agg[i] != -1) continue;
-    double best = -1.0;
-    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) {
-      const int j = A.col[k];
-      if (strong(i, k) && agg[j] >= 0 && std::fabs(A.val[k]) > best) { best = std::fabs(A.val[k]); join[i] = agg[j]; }
-    }
-  }
-  for (int i = 0; i < n; ++i)
-    if (join[i] >= 0) agg[i] = join[i];
-  for (int i = 0; i < n; ++i) {  // phase 3
-    if (agg[i] != -1) continue;
-    agg[i] = na;
-    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
-      if (strong(i, k) && agg[A.col[k]] == -1) agg[A.col[k]] = na;
-    ++na;
-  }
-  return na;
-}
-
-// Rows of C are produced independently by row(i, mark, acc, cols): it lists the row's columns in `cols`, leaves
-// their values in `acc` and restores `mark` to -1.  Two passes (count, then fill with sorted columns).
-template <class RowFn>
-HostCsr build_rows(int n_rows, int n_cols, RowFn row) {
-  HostCsr C;
-  C.n_rows = n_rows;
-  C.n_cols = n_cols;
-  C.rp.assign((size_t)n_rows + 1, 0);
-#pragma omp parallel
-  {
-    std::vector<int> mark((size_t)std::max(1, n_cols), -1), cols;
-    std::vector<double> acc((size_t)std::max(1, n_cols), 0.0);
-#pragma omp for schedule(dynamic, 512)
-    for (int i = 0; i < n_rows; ++i) {
-      cols.clear();
-      row(i, mark, acc, cols);
-      C.rp[i + 1] = (int)cols.size();
-    }
-  }
-  int64_t total = 0;
-  for (int i = 0; i < n_rows; ++i) {
-    total += C.rp[i + 1];
-    if (total > 2147483000LL) throw Error(-80, "AMG: level operator too large for 32-bit indices");
-    C.rp[i + 1] = (int)total;
-  }
-  C.col.resize((size_t)total);
-  C.val.resize((size_t)total);
-#pragma omp parallel
-  {
-    std::vector<int> mark((size_t)std::max(1, n_cols), -1), cols;
-    std::vector<double> acc((size_t)std::max(1, n_cols), 0.0);
-#pragma omp for schedule(dynamic, 512)
-    for (int i = 0; i < n_rows; ++i) {
-      cols.clear();
-      row(i, mark, acc, cols);
-      std::sort(cols.begin(), cols.end());
-      int w = C.rp[i];
-      for (int c : cols) { C.col[w] = c; C.val[w] = acc[c]; ++w; }
-    }
-  }
-  return C;
-}
-
-HostCsr smoothed_prolongator(const HostCsr &A, const std::vector<int> &agg, int nc, const std::vector<double> &dinv,
-                             double lam) {
-  std::vector<double> pw((size_t)nc, 0.0);
-  for (int i = 0; i < A.n_rows; ++i)
-    if (agg[i] >= 0) pw[agg[i]] += 1.0;
-  for (int a = 0; a < nc; ++a) pw[a] = 1.0 / std::sqrt(pw[a]);
-  const double c = kOmega / lam;
-  return build_rows(A.n_rows, nc, [&](int i, std::vector<int> &mark, std::vector<double> &acc, std::vector<int> &cols) {
-    if (agg[i] >= 0) { mark[agg[i]] = i; acc[agg[i]] = pw[agg[i]]; cols.push_back(agg[i]); }
-    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) {
-      const int a = agg[A.col[k]];
-      if (a < 0) continue;
-      if (mark[a] != i) { mark[a] = i; acc[a] = 0.0; cols.push_back(a); }
-      acc[a] -= c * dinv[i] * A.val[k] * pw[a];
-    }
-    for (int a : cols) mark[a] = -1;  // the same callback runs in both passes of build_rows
-  });
-}
-
-// stable counting sort by column, row chunks in parallel (per-thread column histograms)
-HostCsr transpose(const HostCsr &A) {
-  HostCsr T;
-  T.n_rows = A.n_cols;
-  T.n_cols = A.n_rows;
-  const size_t nnz = A.col.size();
-  const int nc = A.n_cols;
-  T.rp.assign((size_t)nc + 1, 0);
-  T.col.resize(nnz);
-  T.val.resize(nnz);
-  const int nt = std::max(1, omp_get_max_threads());
-  std::vector<std::vector<int>> cnt((size_t)nt);
-  int team_used = 1;
-#pragma omp parallel num_threads(nt)
-  {
-    const int t = omp_get_thread_num(), team = omp_get_num_threads();
-    if (t == 0) team_used = team;
-    const int r0 = (int)((int64_t)A.n_rows * t / team), r1 = (int)((int64_t)A.n_rows * (t + 1) / team);
-    std::vector<int> &c = cnt[t];
-    c.assign((size_t)nc, 0);
-    for (int k = A.rp[r0]; k < A.rp[r1]; ++k) ++c[A.col[k]];
-  }
-  // position of (column j, thread t)'s first entry: columns in order, inside a column the threads (= row chunks) in order
-  int64_t run = 0;
-  for (int j = 0; j < nc; ++j) {
-    T.rp[j] = (int)run;
-    for (int t = 0; t < nt; ++t) {
-      if (cnt[t].empty()) continue;
-      const int c = cnt[t][j];
-      cnt[t][j] = (int)run;
-      run += c;
-    }
-  }
-  T.rp[nc] = (int)run;
-#pragma omp parallel for schedule(static, 1) num_threads(team_used)
-  for (int t = 0; t < team_used; ++t) {   // the same row chunks as above, whoever runs them
-    const int team = team_used;
-    const int r0 = (int)((int64_t)A.n_rows * t / team), r1 = (int)((int64_t)A.n_rows * (t + 1) / team);
-    std::vector<int> &w = cnt[t];
-    for (int i = r0; i < r1; ++i)
-      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) {
-        const int p = w[A.col[k]]++;
-        T.col[p] = i;
-        T.val[p] = A.val[k];
-      }
-  }
-  return T;
-}
-
-HostCsr spgemm(const HostCsr &A, const HostCsr &B) {
-  return build_rows(A.n_rows, B.n_cols, [&](int i, std::vector<int> &mark, std::vector<double> &acc, std::vector<int> &cols) {
-    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) {
-      const int j = A.col[k];
-      const double a = A.val[k];
-      for (int q = B.rp[j]; q < B.rp[j + 1]; ++q) {
-        const int cc = B.col[q];
-        if (mark[cc] != i) { mark[cc] = i; acc[cc] = 0.0; cols.push_back(cc); }
-        acc[cc] += a * B.val[q];
-      }
-    }
-    for (int cidx : cols) mark[cidx] = -1;
-  });
-}
-
-std::vector<double> dense_inverse(const HostCsr &A) {
-  const int n = A.n_rows;
+// dense inverse of the coarsest level (the reference's "Amesos-KLU" direct solve, on the host there too)
+std::vector<double> dense_inverse(int n, const std::vector<int> &rp, const std::vector<int> &col, const std::vector<double> &val) {
   std::vector<double> M((size_t)n * n, 0.0), I((size_t)n * n, 0.0);
   for (int i = 0; i < n; ++i) {
-    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) M[(size_t)i * n + A.col[k]] += A.val[k];
+    for (int k = rp[i]; k < rp[i + 1]; ++k) M[(size_t)i * n + col[k]] += val[k];
     I[(size_t)i * n + i] = 1.0;
   }
   for (int c = 0; c < n; ++c) {
@@ -266,22 +51,183 @@ std::vector<double> dense_inverse(const HostCsr &A) {
   return I;
 }
 
-void upload_csr(Ctx *ctx, const HostCsr &A, Csr &D) {
-  hipStream_t s = ctx->stream;
-  D.n_rows = A.n_rows;
-  D.n_cols = D.n_own_cols = A.n_cols;
-  D.nnz = (int64_t)A.col.size();
-  D.h_rowptr = A.rp;
-  D.rowptr.upload(A.rp, s);
-  D.col.upload(A.col, s);
-  D.val.upload(A.val, s);
-  D.lpr = pick_lpr(D.nnz, D.n_rows);
-  D.present = true;
-  D.build_stream_plan(s);
-}
-
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+amgk::Mat mat(const Csr &A) { return amgk::Mat{A.n_rows, A.n_cols, A.rowptr.p, A.col.p, A.val.p}; }
+
+// Scratch of the set-up.  Work arrays of a level come from an arena that lives across set-ups (a Newton run rebuilds
+// the hierarchy before every solve, NSSolverStationary.cpp:621-626, always with the same sizes): the first set-up
+// allocates what it needs piece by piece and records the largest level's total, the following ones take slices.
+struct Scratch {
+  Ctx *ctx;
+  DBuf<char> &arena;
+  size_t &want;
+  size_t top = 0, level_total = 0;
+  std::vector<DBuf<char>> spill;
+  DBuf<long long> total;
+  DBuf<int> counters;   // [0] undecided rows, [1] error word of the row products
+  int rounds = 0;       // independent-set rounds so far (NSK_AMG_TIMING)
+  Scratch(Ctx *c, DBuf<char> &arena_, size_t &want_) : ctx(c), arena(arena_), want(want_) {
+    total.alloc(1);
+    counters.alloc(2);
+  }
+  template <class T>
+  T *take(size_t count) {
+    const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255;
+    level_total += bytes;
+    if (top + bytes <= arena.n) {
+      T *p = reinterpret_cast<T *>(arena.p + top);
+      top += bytes;
+      return p;
+    }
+    spill.emplace_back();
+    spill.back().alloc(bytes);
+    return reinterpret_cast<T *>(spill.back().p);
+  }
+  void end_level() {   // (the caller has synchronised: nothing in flight reads the level's scratch any more)
+    want = std::max(want, level_total);
+    spill.clear();
+    top = level_total = 0;
+  }
+  // out[0..n] = exclusive prefix sums of in[0..n); returns the total (one host sync)
+  int64_t scan(int n, const int *in, int *out) {
+    long long *tmp = take<long long>(amgk::scan_tmp_words(n));
+    amgk::scan_exclusive(ctx->stream, n, in, out, tmp, total.p);
+    long long t = 0;
+    NSK_HIP(hipMemcpyAsync(&t, total.p, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    if (t > 2147483000LL) throw Error(-80, "AMG: level operator too large for 32-bit indices");
+    return (int64_t)t;
+  }
+  int read_counter(int which) {
+    int v = 0;
+    NSK_HIP(hipMemcpyAsync(&v, counters.p + which, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    return v;
+  }
+  void zero_counter(int which) { NSK_HIP(hipMemsetAsync(counters.p + which, 0, sizeof(int), ctx->stream)); }
+};
+
+// what a device-built matrix still needs before the SpMV kernels can take it: the row pointers on the host for the
+// row-run plan (n + 1 ints; the pattern itself stays on the device)
+void finish_csr(Ctx *ctx, Csr &D, int n_rows, int n_cols, int64_t nnz) {
+  D.n_rows = n_rows;
+  D.n_cols = D.n_own_cols = n_cols;
+  D.nnz = nnz;
+  D.h_rowptr.resize((size_t)n_rows + 1);
+  NSK_HIP(hipMemcpyAsync(D.h_rowptr.data(), D.rowptr.p, sizeof(int) * ((size_t)n_rows + 1), hipMemcpyDeviceToHost, ctx->stream));
+  ctx->sync();
+  D.lpr = pick_lpr(D.nnz, D.n_rows);
+  D.present = true;
+  D.build_stream_plan(ctx->stream);
+}
+
+// C = A B (product 0) or C = (I - c D^-1 A) Phat (product 1): count and prefix sum (row pointers into rp, n + 1 ints),
+// then fill; 16 lanes per row first, 64 when a row holds more distinct columns than the narrow hash set takes
+struct ProductPlan {
+  int wide;
+  int64_t nnz;
+};
+ProductPlan product_rows(Scratch &S, const amgk::RowProduct &P, int product, int *rp) {
+  hipStream_t s = S.ctx->stream;
+  const int n = P.A.n_rows;
+  int *len = S.take<int>((size_t)n + 1);
+  int wide = std::getenv("NSK_AMG_WIDE_ROWS") ? 1 : 0;   // test hook: start with the 64-lane kernels
+  for (;; ++wide) {
+    S.zero_counter(1);
+    amgk::product_count(s, P, product, wide, len, S.counters.p + 1);
+    if (S.read_counter(1) == 0) break;
+    if (wide) throw Error(-81, "AMG set-up: a row of a level operator has more than 512 distinct columns");
+  }
+  return ProductPlan{wide, S.scan(n, len, rp)};
+}
+void row_product(Scratch &S, const amgk::RowProduct &P, int product, int n_cols, Csr &C) {
+  const int n = P.A.n_rows;
+  C.rowptr.alloc((size_t)n + 1);
+  const ProductPlan pl = product_rows(S, P, product, C.rowptr.p);
+  C.col.alloc((size_t)std::max<int64_t>(pl.nnz, 1));
+  C.val.alloc((size_t)std::max<int64_t>(pl.nnz, 1));
+  amgk::product_fill(S.ctx->stream, P, product, pl.wide, C.rowptr.p, C.col.p, C.val.p, S.counters.p + 1);
+  finish_csr(S.ctx, C, n, n_cols, pl.nnz);
+}
+// the same into scratch: an intermediate product that is never multiplied with a vector
+amgk::Mat row_product_scratch(Scratch &S, const amgk::RowProduct &P, int product, int n_cols) {
+  const int n = P.A.n_rows;
+  int *rp = S.take<int>((size_t)n + 1);
+  const ProductPlan pl = product_rows(S, P, product, rp);
+  int *col = S.take<int>((size_t)pl.nnz);
+  double *val = S.take<double>((size_t)pl.nnz);
+  amgk::product_fill(S.ctx->stream, P, product, pl.wide, rp, col, val, S.counters.p + 1);
+  return amgk::Mat{n, n_cols, rp, col, val};
+}
+
+void transpose(Scratch &S, const Csr &A, Csr &T) {
+  Ctx *ctx = S.ctx;
+  hipStream_t s = ctx->stream;
+  const int m = A.n_cols;
+  int *count = S.take<int>((size_t)m + 1);
+  NSK_HIP(hipMemsetAsync(count, 0, sizeof(int) * ((size_t)m + 1), s));
+  amgk::col_count(s, (long)A.nnz, A.col.p, count);
+  T.rowptr.alloc((size_t)m + 1);
+  const int64_t nnz = S.scan(m, count, T.rowptr.p);
+  int *cursor = S.take<int>((size_t)m + 1);
+  NSK_HIP(hipMemcpyAsync(cursor, T.rowptr.p, sizeof(int) * ((size_t)m + 1), hipMemcpyDeviceToDevice, s));
+  int *tcol = S.take<int>((size_t)nnz);
+  double *tval = S.take<double>((size_t)nnz);
+  T.col.alloc((size_t)std::max<int64_t>(nnz, 1));
+  T.val.alloc((size_t)std::max<int64_t>(nnz, 1));
+  amgk::transpose_scatter(s, mat(A), cursor, tcol, tval);
+  amgk::rows_sort(s, m, T.rowptr.p, tcol, tval, T.col.p, T.val.p);
+  finish_csr(ctx, T, m, A.n_rows, nnz);
+}
+
+// aggregates of the level: returns their number; agg and pw are level scratch
+int aggregate(Scratch &S, const Csr &A, const double *ad, int *&agg, double *&pw) {
+  Ctx *ctx = S.ctx;
+  hipStream_t s = ctx->stream;
+  const int n = A.n_rows;
+  const amgk::Mat M = mat(A);
+  uint16_t *flag = S.take<uint16_t>(amgk::flag_words((long)A.nnz, n));
+  int *need = S.take<int>((size_t)n), *other = S.take<int>((size_t)n);
+  uint64_t *key = S.take<uint64_t>((size_t)n), *k1 = S.take<uint64_t>((size_t)n), *k2 = S.take<uint64_t>((size_t)n);
+  agg = S.take<int>((size_t)n);
+  pw = nullptr;
+  S.zero_counter(0);
+  NSK_HIP(hipMemsetAsync(need, 0xff, sizeof(int) * (size_t)n, s));
+  amgk::strength(s, M, ad, kThreshold, flag, key, agg, S.counters.p);
+  int undecided = S.read_counter(0), stamp = -1;
+  // every round decides at least the undecided row with the largest key
+  for (int round = 0; undecided > 0; ++round) {
+    if (round > n) throw Error(-82, "AMG set-up: the independent-set rounds do not end");
+    amgk::mis_pull(s, M, flag, 1, key, need, stamp, key, k1);
+    amgk::mis_pull(s, M, flag, 2, key, need, stamp, k1, k2);
+    S.zero_counter(0);
+    amgk::mis_decide(s, n, key, k2, S.counters.p);
+    undecided = S.read_counter(0);
+    // while most rows are undecided pass 1 covers all rows; afterwards only what the undecided rows will read
+    stamp = -1;
+    if (undecided > 0 && undecided < n / 2) {
+      stamp = round + 1;
+      amgk::mis_mark(s, M, flag, key, stamp, need);
+    }
+    ++S.rounds;
+  }
+  int *is_root = S.take<int>((size_t)n), *scan = S.take<int>((size_t)n + 1);
+  amgk::root_flags(s, n, key, is_root);
+  const int nc = (int)S.scan(n, is_root, scan);
+  amgk::root_ids(s, n, key, scan, agg);
+  amgk::join(s, M, flag, key, 1, agg, other);   // pass A: rows next to a root
+  amgk::join(s, M, flag, key, 0, other, agg);   // pass B: the rest joins its strongest pass-A neighbour
+  if (nc > 0) {
+    int *count = S.take<int>((size_t)nc);
+    NSK_HIP(hipMemsetAsync(count, 0, sizeof(int) * (size_t)nc, s));
+    amgk::agg_sizes(s, n, agg, count);
+    pw = S.take<double>((size_t)nc);
+    amgk::agg_weights(s, nc, count, pw);
+  }
+  return nc;
 }
 
 }  // namespace
@@ -290,89 +236,90 @@ double now_ms() {
 double Amg::estimate_lambda_device(AmgLevel &L) {
   const int n = L.n;
   hipStream_t st = ctx->stream;
-  std::vector<double> x((size_t)n);
-  double nrm = 0.0;
-  for (int i = 0; i < n; ++i) { x[i] = start_entry(i); nrm += x[i] * x[i]; }
-  nrm = std::sqrt(nrm);
-  if (!(nrm > 0.0)) return 1.0 * kEigBoost;
-  for (int i = 0; i < n; ++i) x[i] /= nrm;
-  NSK_HIP(hipMemcpyAsync(L.r.p, x.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
   const int sl = ctx->alloc_slots(2);
+  amgk::start_vector(st, n, L.r.p);
+  vec_dot(st, ctx->ws, n, L.r.p, L.r.p, ctx->slot(sl), 1);
+  vec_scale(st, n, sref(1.0, nullptr, ctx->slot(sl + 1)), L.r.p);            // (n > 0: entry 0 of the start vector is -0.5)
   for (int it = 0; it < kEigIts; ++it) {
     mv(*L.A, L.r.p, L.w.p);
     vec_mul(st, n, L.dinv.p, L.w.p);                                         // y = D^-1 A x
     vec_dot(st, ctx->ws, n, L.w.p, L.w.p, ctx->slot(sl), 1);                  // rank-local: no all-reduce
     vec_equ(st, n, sref(1.0, nullptr, ctx->slot(sl + 1)), L.w.p, L.r.p);      // x = y / ||y||
   }
-  const double lam = ctx->read_slots(sl + 1, 1)[0];   // (also keeps the host staging vector alive until the copy is done)
+  const double lam = ctx->read_slots(sl + 1, 1)[0];
   ctx->slot_top = sl;
   return kEigBoost * lam;
 }
 
-void Amg::build(AmgHierarchy &H, const HostCsr &A0, Csr *alias) {
+// The hierarchy under one level-0 operator that is already on the device with its SpMV plan (the caller's block itself,
+// or the diagonal sub-block of a shard).
+void Amg::build(AmgHierarchy &H, Csr *A0, std::unique_ptr<Csr> own0) {
   hipStream_t s = ctx->stream;
-  HostCsr coarse;               // the current level's operator from level 1 on
-  const HostCsr *cur = &A0;     // level 0 stays with the caller (kept across set-ups: no 5 GB of page faults each time)
   const bool timing = std::getenv("NSK_AMG_TIMING") != nullptr;   // phase times of the set-up on stderr
   double tp = now_ms();
   auto lap = [&](int l, const char *what) {
     if (!timing) return;
+    ctx->sync();
     const double t = now_ms();
-    std::fprintf(stderr, "amg set-up: level %d %-22s %9.1f ms\n", l, what, t - tp);
+    std::fprintf(stderr, "amg set-up: level %d %-22s %9.2f ms\n", l, what, t - tp);
     tp = t;
   };
+  Scratch S(ctx, arena, arena_want);
+  std::unique_ptr<Csr> next = std::move(own0);   // the operator the next level owns
+  Csr *cur = A0;
   for (int l = 0;; ++l) {
     auto L = std::make_unique<AmgLevel>();
-    const HostCsr &A = *cur;
+    if (next) { L->own_A = std::move(*next); next.reset(); cur = &L->own_A; }
+    L->A = cur;
+    const Csr &A = *cur;
     const int n = A.n_rows;
     L->n = n;
-    std::vector<double> dinv((size_t)n, 1.0);
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < n; ++i) {
-      double d = 0.0;
-      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
-        if (A.col[k] == i) d = A.val[k];
-      dinv[i] = d != 0.0 ? 1.0 / d : 1.0;
-    }
-    lap(l, "diagonal");
-    if (l == 0 && alias) L->A = alias;
-    else { upload_csr(ctx, A, L->own_A); L->A = &L->own_A; }
-    L->dinv.upload(dinv, s);
+    double *ad = S.take<double>((size_t)n);
+    L->dinv.alloc((size_t)n);
+    amgk::diag(s, mat(A), ad, L->dinv.p);
     L->r.alloc((size_t)n);
     L->w.alloc((size_t)n);
-    lap(l, "upload");
-    // the ten power iterations run on the device copy of the level (same start vector and recurrence as the host
-    // routine, which stays as the fallback should the device value not be finite)
-    static const bool host_lambda = std::getenv("NSK_AMG_HOST_LAMBDA") != nullptr;   // A/B switch for measurements
-    L->lam = host_lambda ? -1.0 : estimate_lambda_device(*L);
-    if (!(L->lam > 0.0) || !std::isfinite(L->lam)) L->lam = estimate_lambda(A, dinv);
+    lap(l, "diagonal");
+    L->lam = estimate_lambda_device(*L);
+    if (!(L->lam > 0.0) || !std::isfinite(L->lam))
+      throw Error(-83, "AMG set-up: the power iteration on level " + std::to_string(l) + " did not give a finite eigenvalue estimate");
     lap(l, "lambda (power its)");
     if (l > 0) { L->x.alloc((size_t)n); L->b.alloc((size_t)n); }
     int nc = 0;
-    std::vector<int> agg;
-    if (n > kCoarseMax && l + 1 < kMaxLevels) nc = aggregate(A, agg);
+    int *agg = nullptr;
+    double *pw = nullptr;
+    if (n > kCoarseMax && l + 1 < kMaxLevels) nc = aggregate(S, A, ad, agg, pw);
     lap(l, "aggregation");
+    if (timing) std::fprintf(stderr, "amg set-up: level %d %d aggregates after %d independent-set rounds (all levels so far)\n", l, nc, S.rounds);
     if (nc <= 0 || nc >= n) {
-      if (n <= kDenseLimit) L->inv.upload(dense_inverse(A), s);
+      if (n <= kDenseLimit) {   // the coarsest operator goes to the host once, its inverse comes back
+        std::vector<int> rp((size_t)n + 1), col((size_t)A.nnz);
+        std::vector<double> val((size_t)A.nnz);
+        NSK_HIP(hipMemcpyAsync(rp.data(), A.rowptr.p, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, s));
+        NSK_HIP(hipMemcpyAsync(col.data(), A.col.p, sizeof(int) * (size_t)A.nnz, hipMemcpyDeviceToHost, s));
+        NSK_HIP(hipMemcpyAsync(val.data(), A.val.p, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToHost, s));
+        ctx->sync();
+        L->inv.upload(dense_inverse(n, rp, col, val), s);
+      }
       ctx->sync();
+      S.end_level();
       H.lev.push_back(std::move(L));
       break;
     }
-    HostCsr P = smoothed_prolongator(A, agg, nc, dinv, L->lam);
+    amgk::RowProduct pp{mat(A), amgk::Mat{}, agg, pw, L->dinv.p, kOmega / L->lam};
+    row_product(S, pp, 1, nc, L->P);
     lap(l, "smoothed prolongator");
-    HostCsr R = transpose(P);
+    transpose(S, L->P, L->R);
     lap(l, "transpose");
-    HostCsr AP = spgemm(A, P);
+    const amgk::Mat AP = row_product_scratch(S, amgk::RowProduct{mat(A), mat(L->P), nullptr, nullptr, nullptr, 0.0}, 0, nc);
     lap(l, "A P");
-    HostCsr Ac = spgemm(R, AP);
+    next = std::make_unique<Csr>();
+    row_product(S, amgk::RowProduct{mat(L->R), AP, nullptr, nullptr, nullptr, 0.0}, 0, nc, *next);
     lap(l, "R (A P)");
-    upload_csr(ctx, P, L->P);
-    upload_csr(ctx, R, L->R);
     L->has_coarse = true;
-    ctx->sync();  // host staging copies die below
+    ctx->sync();
+    S.end_level();
     H.lev.push_back(std::move(L));
-    coarse = std::move(Ac);
-    cur = &coarse;
   }
 }
 
@@ -385,62 +332,27 @@ void Amg::setup(Ctx *c, Csr &F, const std::vector<int> &shard_off) {
   if (off.size() < 2) off = {0, F.n_rows};
   const bool single_full = off.size() == 2 && F.n_cols == F.n_own_cols && F.n_cols == F.n_rows;
   shards.resize(off.size() - 1);
-  // The host copies of the shards' level-0 operators live across set-ups (the pattern of a block is fixed for the run,
-  // NSSolverStationary.cpp:304): only the values are fetched again, straight into their place.
-  const bool reuse = host0.size() == shards.size() && host0_key == &F && host0_nnz == F.nnz && host0_off == off;
-  if (!reuse) {
-    host0.clear();
-    host0.resize(shards.size());
-    host0_key = &F;
-    host0_nnz = F.nnz;
-    host0_off = off;
-  }
-  std::vector<double> val;   // staging for the general case only (ghost columns dropped / several shards)
-  if (single_full) {
-    HostCsr &B = host0[0];
-    if (!reuse) {
-      B.n_rows = B.n_cols = F.n_rows;
-      B.rp.assign(F.h_rowptr.begin(), F.h_rowptr.end());
-      B.col.resize((size_t)F.nnz);
-      B.val.resize((size_t)F.nnz);
-#pragma omp parallel for schedule(static)
-      for (int64_t k = 0; k < F.nnz; ++k) B.col[k] = F.h_col[k];
-    }
-    NSK_HIP(hipMemcpyAsync(B.val.data(), F.val.p, sizeof(double) * (size_t)F.nnz, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->sync();
-  } else {
-    // values live on the device (nsk_update_values): bring them back once for the host set-up
-    val.resize((size_t)F.nnz);
-    NSK_HIP(hipMemcpyAsync(val.data(), F.val.p, sizeof(double) * (size_t)F.nnz, hipMemcpyDeviceToHost, ctx->stream));
-    ctx->sync();
-  }
+  if (arena.n < arena_want) arena.alloc(arena_want + arena_want / 16);
   for (size_t sidx = 0; sidx + 1 < off.size(); ++sidx) {
     const int r0 = off[sidx], r1 = off[sidx + 1];
-    HostCsr &B = host0[sidx];
-    if (!single_full) {
-      if (!reuse) {
-        B.n_rows = B.n_cols = r1 - r0;
-        B.rp.assign((size_t)(r1 - r0) + 1, 0);
-#pragma omp parallel for schedule(static)
-        for (int i = r0; i < r1; ++i) {
-          int cnt = 0;
-          for (int k = F.h_rowptr[i]; k < F.h_rowptr[i + 1]; ++k) cnt += F.h_col[k] >= r0 && F.h_col[k] < r1;
-          B.rp[i - r0 + 1] = cnt;
-        }
-        for (int i = 0; i < r1 - r0; ++i) B.rp[i + 1] += B.rp[i];
-        B.col.resize((size_t)B.rp[r1 - r0]);
-        B.val.resize((size_t)B.rp[r1 - r0]);
-      }
-#pragma omp parallel for schedule(static)
-      for (int i = r0; i < r1; ++i) {
-        int w = B.rp[i - r0];
-        for (int k = F.h_rowptr[i]; k < F.h_rowptr[i + 1]; ++k)
-          if (F.h_col[k] >= r0 && F.h_col[k] < r1) { B.col[w] = F.h_col[k] - r0; B.val[w] = val[k]; ++w; }
-      }
-    }
     shards[sidx].offset = r0;
-    build(shards[sidx], B, single_full ? &F : nullptr);
+    if (single_full) { build(shards[sidx], &F, nullptr); continue; }
+    // the shard's diagonal block as a matrix of its own (ghost columns and other shards' columns dropped)
+    Scratch S(ctx, arena, arena_want);
+    auto B = std::make_unique<Csr>();
+    const amgk::Mat M{F.n_rows, F.n_cols, F.rowptr.p, F.col.p, F.val.p};
+    int *len = S.take<int>((size_t)(r1 - r0) + 1);
+    amgk::block_count(ctx->stream, M, r0, r1, len);
+    B->rowptr.alloc((size_t)(r1 - r0) + 1);
+    const int64_t nnz = S.scan(r1 - r0, len, B->rowptr.p);
+    B->col.alloc((size_t)std::max<int64_t>(nnz, 1));
+    B->val.alloc((size_t)std::max<int64_t>(nnz, 1));
+    amgk::block_fill(ctx->stream, M, r0, r1, B->rowptr.p, B->col.p, B->val.p);
+    finish_csr(ctx, *B, r1 - r0, r1 - r0, nnz);
+    S.end_level();
+    build(shards[sidx], nullptr, std::move(B));
   }
+  ctx->sync();
   setup_host_ms = now_ms() - t0;
   if (std::getenv("NSK_AMG_TIMING")) std::fprintf(stderr, "amg set-up: total %.1f ms\n", setup_host_ms);
 }

@@ -5,15 +5,17 @@
 // deal.II default AdditionalData (lab_new/src/NSSolverStationary.hpp:225,231).  ML's aggregates cannot be
 // reproduced bit for bit (its source is the only specification), so this is the same METHOD under the
 // same parameters — see DESIGN.md "AMG" for the deterministic details of this specification:
-//   uncoupled greedy aggregation (strength threshold 1e-4), one constant near-null-space vector,
+//   uncoupled root-and-neighbours aggregation (strength threshold 1e-4; the roots are a distance-2 maximal independent
+//   set found in synchronous rounds, so that it runs row-parallel), one constant near-null-space vector,
 //   prolongator smoothing (I - 4/3 / lambda D^-1 A), R = P^T, Galerkin R A P, <= 10 levels,
 //   coarsest level (<= 128 unknowns) solved directly, V(1,1) cycle with a degree-2 Chebyshev polynomial in
 //   D^-1 A (eigenvalue ratio 20), lambda = 1.1 x (10 power iterations).
 // Rank-local like every preconditioner of the reference's stack under additive Schwarz with overlap 0:
 // ghost columns are dropped (block Jacobi across ranks / sub-domains).
 //
-// Set-up runs on the host (OpenMP) from a copy of the block's values; the cycle runs on the device with
-// the library's CSR-stream SpMV kernels.
+// Set-up and cycle both run on the device: the set-up with the row-parallel kernels of nsk_amg_kernels.hip from the
+// block's device copy (only row pointers for the SpMV plans and the coarsest operator, for its dense inverse, visit
+// the host), the cycle with the library's CSR-stream SpMV kernels.
 #pragma once
 #include <memory>
 #include <vector>
@@ -21,12 +23,6 @@
 #include "nsk_core.hpp"
 
 namespace nsk {
-
-struct HostCsr {
-  int n_rows = 0, n_cols = 0;
-  std::vector<int> rp, col;
-  std::vector<double> val;
-};
 
 struct AmgLevel {
   int n = 0;
@@ -50,13 +46,10 @@ struct Amg {
   // F: device block with host pattern; shard_off: empty = one shard
   void setup(Ctx *ctx, Csr &F, const std::vector<int> &shard_off);
   void apply(const double *b, double *x);
-  void clear() { shards.clear(); }   // (the host copy of level 0 stays: see host0)
-  // a new PATTERN of the block (nsk_set_block_csr): the kept host copy of level 0 describes the old one
-  void drop_host_copy() {
-    std::vector<HostCsr>().swap(host0);
-    host0_key = nullptr;
-    host0_nnz = 0;
-    host0_off.clear();
+  void clear() { shards.clear(); }   // (the set-up's scratch arena stays for the next set-up)
+  void release() {                   // the preconditioner is no longer in use
+    shards.clear();
+    arena.release();
   }
   int n_levels(int shard = 0) const { return shards.empty() ? 0 : (int)shards[shard].lev.size(); }
   int level_rows(int shard, int l) const { return shards[shard].lev[l]->n; }
@@ -65,12 +58,9 @@ struct Amg {
   size_t apply_bytes() const;  // algorithmic bytes of one V-cycle (SURVEY 8d formulas)
 
  private:
-  void build(AmgHierarchy &H, const HostCsr &A0, Csr *alias);
-  // host copies of the shards' level-0 operators, kept across set-ups (pattern fixed, values refreshed)
-  std::vector<HostCsr> host0;
-  const void *host0_key = nullptr;
-  int64_t host0_nnz = 0;
-  std::vector<int> host0_off;
+  void build(AmgHierarchy &H, Csr *A0, std::unique_ptr<Csr> own0);
+  DBuf<char> arena;        // work arrays of the set-up, kept across set-ups (nsk_amg.cpp: Scratch)
+  size_t arena_want = 0;   // bytes the largest level took so far
   double estimate_lambda_device(AmgLevel &L);
   void cheby(AmgLevel &L, const double *b, double *x, bool zero_init);
   void vcycle(AmgHierarchy &H, int l, const double *b, double *x);

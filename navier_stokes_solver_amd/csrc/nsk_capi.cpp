@@ -422,7 +422,7 @@ void H::setup(int type, int variant_, double alpha_) {
     amgF.clear();
     amg_pending = true;
   } else {
-    amgF.clear();
+    amgF.release();
     if (!tF_ok || tF_key != key) {
       Phase ph("analyse F factor (host)");
       tF.analyze(&ctx, F, kindF, tri_ordering, sub_offsets(0), use_bsr && F.blk_ok && F.blk_R == 2 && F.blk_C == 2, xy(0),
@@ -825,7 +825,6 @@ int nsk_set_block_csr(nsk_handle h, int b, int n_rows, int n_cols, const int32_t
   if (b == NSK_BLK_F) {
     h->tF_ok = false;
     h->amgF.clear();
-    h->amgF.drop_host_copy();   // same address, same nnz, other pattern: the kept level-0 copy must not be reused
     if (h->amg_active) h->amg_pending = true;
   }
   if (b == NSK_BLK_MP) h->tMp_ok = false;

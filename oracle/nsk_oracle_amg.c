@@ -11,7 +11,7 @@
  * constant_modes = {} -> one constant near-null-space vector, smoother_sweeps = 2, smoother_overlap = 0,
  * smoother_type = "Chebyshev", coarse_type = "Amesos-KLU"), i.e. ML's "SA" parameter set:
  *
- *   smoothed aggregation, "Uncoupled" greedy aggregation (rank-local), damped-Jacobi prolongator
+ *   smoothed aggregation, "Uncoupled" (rank-local) root-and-neighbours aggregation, damped-Jacobi prolongator
  *   smoothing with omega = 4/3, Galerkin coarse operators R A P with R = P^T, at most 10 levels,
  *   coarsest level <= 128 unknowns solved directly, one V-cycle with a degree-2 Chebyshev polynomial in
  *   D^-1 A as pre- and post-smoother (eigenvalue ratio 20), lambda_max(D^-1 A) from 10 power iterations.
@@ -106,8 +106,22 @@ static double estimate_lambda(const hcsr *A, const double *dinv) {
   return AMG_EIG_BOOST * lam;
 }
 
-/* "Uncoupled" aggregation.  agg[i] >= 0: aggregate id; -2: row without strong connections (Dirichlet rows,
- * isolated unknowns): not aggregated, its prolongator row is empty.  Returns the number of aggregates. */
+/* Aggregation on the strength graph s(i -> j): a_ij^2 > threshold^2 |a_ii a_jj| (row i's entries only).
+ * agg[i] >= 0: aggregate id; -2: row without strong connections (Dirichlet rows, isolated unknowns): not aggregated,
+ * its prolongator row is empty.  Returns the number of aggregates.
+ *
+ * Roots are a distance-2 maximal independent set found in SYNCHRONOUS rounds (the parallel form of ML's
+ * root-and-neighbours rule; every round reads the previous round's state only, so any number of threads gives the
+ * same aggregates): key(i) = state << 62 | hash(i) << 31 | i with state 1 = undecided, 2 = root, key 0 = out; a round
+ * takes the maximum key over the strong neighbourhood twice; an undecided row that finds its own key becomes a root,
+ * one that finds a root's key is out.  Roots are numbered in row order.  Then (pass A) a row next to a root joins it
+ * and (pass B, on a snapshot) the others — every one of them has a pass-A neighbour, that is how it went out — join
+ * the aggregate of their strongest assigned neighbour; "strongest" compares |a_ij| rounded to float, first in the row
+ * wins ties (rounding noise of the coarse operators must not decide between mirror-image neighbours). */
+static uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
 static int aggregate(const hcsr *A, int *agg) {
   const int n = A->n_rows;
   double *ad = (double *)malloc(sizeof(double) * (size_t)n);
@@ -117,48 +131,53 @@ static int aggregate(const hcsr *A, int *agg) {
   }
   const double t2 = AMG_THRESHOLD * AMG_THRESHOLD;
 #define STRONG(i, k) (A->col[k] != (i) && A->val[k] * A->val[k] > t2 * ad[i] * ad[A->col[k]])
+  uint64_t *T = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n), *T1 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+  uint64_t *T2 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+  long undecided = 0;
   for (int i = 0; i < n; ++i) {
     int any = 0;
     for (int k = A->rp[i]; k < A->rp[i + 1] && !any; ++k) any = STRONG(i, k);
     agg[i] = any ? -1 : -2;
+    T[i] = any ? ((uint64_t)1 << 62) | ((uint64_t)(mix32((uint32_t)i) >> 2) << 31) | (uint64_t)i : 0;
+    undecided += any;
   }
-  int na = 0;
-  /* phase 1: a root whose strong neighbourhood is still untouched takes all of it */
-  for (int i = 0; i < n; ++i) {
-    if (agg[i] != -1) continue;
-    int free_nb = 1;
-    for (int k = A->rp[i]; k < A->rp[i + 1] && free_nb; ++k)
-      if (STRONG(i, k) && agg[A->col[k]] >= 0) free_nb = 0;
-    if (!free_nb) continue;
-    agg[i] = na;
-    for (int k = A->rp[i]; k < A->rp[i + 1]; ++k)
-      if (STRONG(i, k) && agg[A->col[k]] == -1) agg[A->col[k]] = na;
-    ++na;
-  }
-  /* phase 2: leftovers join the phase-1 aggregate of their strongest neighbour (decided on a snapshot) */
-  const int n1 = na;
-  int *join = (int *)malloc(sizeof(int) * (size_t)n);
-  for (int i = 0; i < n; ++i) {
-    join[i] = -1;
-    if (agg[i] != -1) continue;
-    double best = -1.0;
-    for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) {
-      const int j = A->col[k];
-      if (STRONG(i, k) && agg[j] >= 0 && agg[j] < n1 && fabs(A->val[k]) > best) { best = fabs(A->val[k]); join[i] = agg[j]; }
+  while (undecided > 0) {
+    for (int i = 0; i < n; ++i) {
+      uint64_t m = T[i];
+      for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) if (STRONG(i, k) && T[A->col[k]] > m) m = T[A->col[k]];
+      T1[i] = m;
+    }
+    for (int i = 0; i < n; ++i) {
+      uint64_t m = T1[i];
+      for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) if (STRONG(i, k) && T1[A->col[k]] > m) m = T1[A->col[k]];
+      T2[i] = m;
+    }
+    for (int i = 0; i < n; ++i) {
+      if ((T[i] >> 62) != 1) continue;
+      if (T2[i] == T[i]) { T[i] = (T[i] & ~((uint64_t)3 << 62)) | ((uint64_t)2 << 62); --undecided; }
+      else if ((T2[i] >> 62) == 2) { T[i] = 0; --undecided; }
     }
   }
-  for (int i = 0; i < n; ++i) if (join[i] >= 0) agg[i] = join[i];
-  free(join);
-  /* phase 3: what is left forms new aggregates with its still-free strong neighbours */
-  for (int i = 0; i < n; ++i) {
-    if (agg[i] != -1) continue;
-    agg[i] = na;
-    for (int k = A->rp[i]; k < A->rp[i + 1]; ++k)
-      if (STRONG(i, k) && agg[A->col[k]] == -1) agg[A->col[k]] = na;
-    ++na;
+  int na = 0;
+  for (int i = 0; i < n; ++i) if ((T[i] >> 62) == 2) agg[i] = na++;
+  int *join = (int *)malloc(sizeof(int) * (size_t)n);
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < n; ++i) {
+      join[i] = -1;
+      if (agg[i] != -1) continue;
+      float best = -1.0f;
+      for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) {
+        const int j = A->col[k];
+        if (!STRONG(i, k) || agg[j] < 0) continue;
+        if (pass == 0 && (T[j] >> 62) != 2) continue;
+        if ((float)fabs(A->val[k]) > best) { best = (float)fabs(A->val[k]); join[i] = agg[j]; }
+      }
+    }
+    for (int i = 0; i < n; ++i) if (join[i] >= 0) agg[i] = join[i];
   }
+  for (int i = 0; i < n; ++i) if (agg[i] == -1) agg[i] = -2;   /* (unreachable: see above) */
 #undef STRONG
-  free(ad);
+  free(join); free(T); free(T1); free(T2); free(ad);
   return na;
 }
 

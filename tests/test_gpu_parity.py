@@ -441,6 +441,31 @@ def test_amg_vcycle_matches_oracle(handles, name, subdomains):
     ls.set_option(S.OPT_VELOCITY_AMG, 1)
 
 
+def test_amg_device_setup_repeats_itself_and_the_wide_row_kernels_agree(monkeypatch):
+    """The hierarchy is built on the device (nsk_amg_kernels.hip): a second and third set-up on the same handle (scratch
+    arena reused) give the same bits as the first; the 64-lane row-product kernels (what a level with more than 128
+    distinct columns in a row falls to) give the 16-lane kernels' bits, hence the oracle's V-cycle too."""
+    S, O = _S(), _O()
+    pr = problem("ns60")
+    b = rng_vec(pr.n_u, 78)
+    ref = O.Amg(O.CsrHolder.from_block(pr.F))
+    out = []
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr)
+        for rep in range(4):
+            if rep == 3:
+                monkeypatch.setenv("NSK_AMG_WIDE_ROWS", "1")
+            ls.setup_preconditioner(S.BLOCK_TRIANGULAR, S.STATIONARY)
+            out.append((ls.amg_levels(), ls.tri_apply(S.TRI_VELOCITY, b)))
+    finally:
+        ls.close()
+    for lv, x in out[1:]:
+        assert lv == out[0][0] and np.array_equal(x, out[0][1])
+    assert [lv[:2] for lv in out[0][0]] == [lv[:2] for lv in ref.levels()]
+    assert rel_err(out[0][1], ref.apply(b)) <= 1e-11
+
+
 def test_amg_follows_a_second_hand_off_with_another_pattern():
     """A second nsk_set_block_csr(F) on the same handle with the same size and nnz but another PATTERN (a renumbered
     mesh): the AMG set-up must not reuse the level-0 host copy it kept from the first pattern."""
