@@ -194,32 +194,42 @@ int aggregate(Scratch &S, const Csr &A, const double *ad, int *&agg, double *&pw
   uint64_t *key = S.take<uint64_t>((size_t)n), *k1 = S.take<uint64_t>((size_t)n), *k2 = S.take<uint64_t>((size_t)n);
   agg = S.take<int>((size_t)n);
   pw = nullptr;
-  S.zero_counter(0);
-  NSK_HIP(hipMemsetAsync(need, 0xff, sizeof(int) * (size_t)n, s));
-  amgk::strength(s, M, ad, kThreshold, flag, key, agg, S.counters.p);
-  int undecided = S.read_counter(0), stamp = -1;
-  // every round decides at least the undecided row with the largest key
-  for (int round = 0; undecided > 0; ++round) {
-    if (round > n) throw Error(-82, "AMG set-up: the independent-set rounds do not end");
-    amgk::mis_pull(s, M, flag, 1, key, need, stamp, key, k1);
-    amgk::mis_pull(s, M, flag, 2, key, need, stamp, k1, k2);
-    S.zero_counter(0);
-    amgk::mis_decide(s, n, key, k2, S.counters.p);
-    undecided = S.read_counter(0);
-    // while most rows are undecided pass 1 covers all rows; afterwards only what the undecided rows will read
-    stamp = -1;
-    if (undecided > 0 && undecided < n / 2) {
-      stamp = round + 1;
-      amgk::mis_mark(s, M, flag, key, stamp, need);
-    }
-    ++S.rounds;
-  }
   int *is_root = S.take<int>((size_t)n), *scan = S.take<int>((size_t)n + 1);
-  amgk::root_flags(s, n, key, is_root);
-  const int nc = (int)S.scan(n, is_root, scan);
-  amgk::root_ids(s, n, key, scan, agg);
-  amgk::join(s, M, flag, key, 1, agg, other);   // pass A: rows next to a root
-  amgk::join(s, M, flag, key, 0, other, agg);   // pass B: the rest joins its strongest pass-A neighbour
+  NSK_HIP(hipMemsetAsync(need, 0xff, sizeof(int) * (size_t)n, s));
+  int stamp_base = 0;
+  // synchronous independent-set rounds over the connections in `bits`; every round decides at least the undecided row
+  // with the largest key.  Returns the number of roots found and gives them the aggregate ids first, first + 1, ...
+  auto roots = [&](const uint16_t *bits, int undecided, int first) {
+    int stamp = -1;
+    if (undecided > 0 && undecided < n / 2) {   // few candidates from the start
+      stamp = ++stamp_base;
+      amgk::mis_mark(s, M, bits, key, stamp, need);
+    }
+    for (int round = 0; undecided > 0; ++round) {
+      if (round > n) throw Error(-82, "AMG set-up: the independent-set rounds do not end");
+      amgk::mis_pull(s, M, bits, 1, key, need, stamp, key, k1);
+      amgk::mis_pull(s, M, bits, 2, key, need, stamp, k1, k2);
+      S.zero_counter(0);
+      amgk::mis_decide(s, n, key, k2, S.counters.p);
+      undecided = S.read_counter(0);
+      // while most rows are undecided pass 1 covers all rows; afterwards only what the undecided rows will read
+      stamp = -1;
+      if (undecided > 0 && undecided < n / 2) {
+        stamp = ++stamp_base;
+        amgk::mis_mark(s, M, bits, key, stamp, need);
+      }
+      ++S.rounds;
+    }
+    amgk::root_flags(s, n, key, is_root);
+    const int found = (int)S.scan(n, is_root, scan);
+    amgk::root_ids(s, n, key, scan, first, agg);
+    return found;
+  };
+  S.zero_counter(0);
+  amgk::strength(s, M, ad, kThreshold, flag, key, agg, S.counters.p);
+  const int nc = roots(flag, S.read_counter(0), 0);
+  amgk::join(s, M, flag, key, 1, agg, other);    // (A) rows next to a root
+  amgk::join(s, M, flag, key, 0, other, agg);    // (B) the rest joins its strongest pass-A neighbour
   if (nc > 0) {
     int *count = S.take<int>((size_t)nc);
     NSK_HIP(hipMemsetAsync(count, 0, sizeof(int) * (size_t)nc, s));

@@ -38,7 +38,7 @@ void mis_decide(hipStream_t s, int n, uint64_t *key, const uint64_t *key2, int *
 // need[j] = stamp for the undecided rows and their strong neighbours (what the next round's pass 2 reads)
 void mis_mark(hipStream_t s, const Mat &A, const uint16_t *flag, const uint64_t *key, int stamp, int *need);
 void root_flags(hipStream_t s, int n, const uint64_t *key, int *is_root);
-void root_ids(hipStream_t s, int n, const uint64_t *key, const int *scan, int *agg);
+void root_ids(hipStream_t s, int n, const uint64_t *key, const int *scan, int first, int *agg);   // agg[root] = first + scan[root]
 void join(hipStream_t s, const Mat &A, const uint16_t *flag, const uint64_t *key, int roots_only, const int *agg_in,
           int *agg_out);
 void agg_sizes(hipStream_t s, int n, const int *agg, int *count /* zeroed by the caller */);

@@ -305,9 +305,9 @@ __global__ __launch_bounds__(WG) void root_flags_kernel(int n, const uint64_t *_
 }
 
 __global__ __launch_bounds__(WG) void root_ids_kernel(int n, const uint64_t *__restrict__ key, const int *__restrict__ scan,
-                                                      int *__restrict__ agg) {
+                                                      int first, int *__restrict__ agg) {
   const int i = (int)(blockIdx.x * WG + threadIdx.x);
-  if (i < n && (key[i] >> 62) == 2) agg[i] = scan[i];
+  if (i < n && (key[i] >> 62) == 2) agg[i] = first + scan[i];
 }
 
 __global__ __launch_bounds__(WG) void join_kernel(Mat A, const uint16_t *__restrict__ fw, const uint64_t *__restrict__ key,
@@ -655,8 +655,8 @@ void mis_mark(hipStream_t s, const Mat &A, const uint16_t *flag, const uint64_t 
 void root_flags(hipStream_t s, int n, const uint64_t *key, int *is_root) {
   if (n > 0) hipLaunchKernelGGL(root_flags_kernel, dim3(ew_grid(n)), dim3(WG), 0, s, n, key, is_root);
 }
-void root_ids(hipStream_t s, int n, const uint64_t *key, const int *scan, int *agg) {
-  if (n > 0) hipLaunchKernelGGL(root_ids_kernel, dim3(ew_grid(n)), dim3(WG), 0, s, n, key, scan, agg);
+void root_ids(hipStream_t s, int n, const uint64_t *key, const int *scan, int first, int *agg) {
+  if (n > 0) hipLaunchKernelGGL(root_ids_kernel, dim3(ew_grid(n)), dim3(WG), 0, s, n, key, scan, first, agg);
 }
 void join(hipStream_t s, const Mat &A, const uint16_t *flag, const uint64_t *key, int roots_only, const int *agg_in,
           int *agg_out) {

@@ -122,34 +122,21 @@ static uint32_t mix32(uint32_t h) {
   h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
   return h;
 }
-static int aggregate(const hcsr *A, int *agg) {
+/* synchronous independent-set rounds over the edges with on[k] != 0; T holds the keys (1 << 62 | ... undecided, 0 out) */
+static void mis2_rounds(const hcsr *A, const unsigned char *on, uint64_t *T) {
   const int n = A->n_rows;
-  double *ad = (double *)malloc(sizeof(double) * (size_t)n);
-  for (int i = 0; i < n; ++i) {
-    ad[i] = 0.0;
-    for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) if (A->col[k] == i) ad[i] = fabs(A->val[k]);
-  }
-  const double t2 = AMG_THRESHOLD * AMG_THRESHOLD;
-#define STRONG(i, k) (A->col[k] != (i) && A->val[k] * A->val[k] > t2 * ad[i] * ad[A->col[k]])
-  uint64_t *T = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n), *T1 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
-  uint64_t *T2 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+  uint64_t *T1 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n), *T2 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
   long undecided = 0;
-  for (int i = 0; i < n; ++i) {
-    int any = 0;
-    for (int k = A->rp[i]; k < A->rp[i + 1] && !any; ++k) any = STRONG(i, k);
-    agg[i] = any ? -1 : -2;
-    T[i] = any ? ((uint64_t)1 << 62) | ((uint64_t)(mix32((uint32_t)i) >> 2) << 31) | (uint64_t)i : 0;
-    undecided += any;
-  }
+  for (int i = 0; i < n; ++i) undecided += (T[i] >> 62) == 1;
   while (undecided > 0) {
     for (int i = 0; i < n; ++i) {
       uint64_t m = T[i];
-      for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) if (STRONG(i, k) && T[A->col[k]] > m) m = T[A->col[k]];
+      for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) if (on[k] && T[A->col[k]] > m) m = T[A->col[k]];
       T1[i] = m;
     }
     for (int i = 0; i < n; ++i) {
       uint64_t m = T1[i];
-      for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) if (STRONG(i, k) && T1[A->col[k]] > m) m = T1[A->col[k]];
+      for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) if (on[k] && T1[A->col[k]] > m) m = T1[A->col[k]];
       T2[i] = m;
     }
     for (int i = 0; i < n; ++i) {
@@ -158,28 +145,58 @@ static int aggregate(const hcsr *A, int *agg) {
       else if ((T2[i] >> 62) == 2) { T[i] = 0; --undecided; }
     }
   }
+  free(T1); free(T2);
+}
+
+/* rows with agg == -1 join the aggregate of their strongest neighbour over the edges on[k] whose column is assigned
+ * (roots_only: and is a root of T); decided on a snapshot; |a_ij| compared as float, first in the row wins */
+static void join_pass(const hcsr *A, const unsigned char *on, const uint64_t *T, int roots_only, int *agg) {
+  const int n = A->n_rows;
+  int *join = (int *)malloc(sizeof(int) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    join[i] = -1;
+    if (agg[i] != -1) continue;
+    float best = -1.0f;
+    for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) {
+      const int j = A->col[k];
+      if (!on[k] || agg[j] < 0) continue;
+      if (roots_only && (T[j] >> 62) != 2) continue;
+      if ((float)fabs(A->val[k]) > best) { best = (float)fabs(A->val[k]); join[i] = agg[j]; }
+    }
+  }
+  for (int i = 0; i < n; ++i) if (join[i] >= 0) agg[i] = join[i];
+  free(join);
+}
+
+static int aggregate(const hcsr *A, int *agg) {
+  const int n = A->n_rows, nnz = A->rp[n];
+  double *ad = (double *)malloc(sizeof(double) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    ad[i] = 0.0;
+    for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) if (A->col[k] == i) ad[i] = fabs(A->val[k]);
+  }
+  const double t2 = AMG_THRESHOLD * AMG_THRESHOLD;
+  unsigned char *on = (unsigned char *)malloc((size_t)(nnz > 0 ? nnz : 1));
+  uint64_t *T = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    int any = 0;
+    for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) {
+      on[k] = A->col[k] != i && A->val[k] * A->val[k] > t2 * ad[i] * ad[A->col[k]];
+      any |= on[k];
+    }
+    agg[i] = any ? -1 : -2;
+    T[i] = any ? ((uint64_t)1 << 62) | ((uint64_t)(mix32((uint32_t)i) >> 2) << 31) | (uint64_t)i : 0;
+  }
+  mis2_rounds(A, on, T);
   int na = 0;
   for (int i = 0; i < n; ++i) if ((T[i] >> 62) == 2) agg[i] = na++;
-  int *join = (int *)malloc(sizeof(int) * (size_t)n);
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int i = 0; i < n; ++i) {
-      join[i] = -1;
-      if (agg[i] != -1) continue;
-      float best = -1.0f;
-      for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) {
-        const int j = A->col[k];
-        if (!STRONG(i, k) || agg[j] < 0) continue;
-        if (pass == 0 && (T[j] >> 62) != 2) continue;
-        if ((float)fabs(A->val[k]) > best) { best = (float)fabs(A->val[k]); join[i] = agg[j]; }
-      }
-    }
-    for (int i = 0; i < n; ++i) if (join[i] >= 0) agg[i] = join[i];
-  }
+  join_pass(A, on, T, 1, agg);                       /* (A) rows next to a root */
+  join_pass(A, on, T, 0, agg);                       /* (B) the rest joins its strongest assigned neighbour */
   for (int i = 0; i < n; ++i) if (agg[i] == -1) agg[i] = -2;   /* (unreachable: see above) */
-#undef STRONG
-  free(join); free(T); free(T1); free(T2); free(ad);
+  free(on); free(T); free(ad);
   return na;
 }
+
 
 /* P = (I - omega/lam D^-1 A) Phat, Phat(i, agg(i)) = 1/sqrt(|agg|); columns sorted */
 static void smoothed_prolongator(const hcsr *A, const int *agg, int nc, const double *dinv, double lam, hcsr *P) {

@@ -441,6 +441,28 @@ def test_amg_vcycle_matches_oracle(handles, name, subdomains):
     ls.set_option(S.OPT_VELOCITY_AMG, 1)
 
 
+def test_amg_device_setup_matches_the_oracle_at_600x200():
+    """The device-built hierarchy at a BASELINE-sized block (2.1 M rows, 107 M non-zeros, five levels; the oracle's
+    set-up takes a few seconds): same level sizes, non-zeros and lambda, one V-cycle to rounding.  (1200x400:
+    tests/studies/amg_parity_full_size.py, profiles/r03_amg_device_vs_cpu_restatement_1200x400.log.)"""
+    S, O = _S(), _O()
+    from navier_stokes_solver_amd import problem as P
+    pr = P.generate(600, 200, nu=1.0 / 90.0, mode=1, state=1)
+    b = rng_vec(pr.n_u, 5)
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr)
+        ls.setup_preconditioner(S.BLOCK_TRIANGULAR, S.STATIONARY)
+        lv, x = ls.amg_levels(), ls.tri_apply(S.TRI_VELOCITY, b)
+    finally:
+        ls.close()
+    M = O.Amg(O.CsrHolder.from_block(pr.F))
+    ov = M.levels()
+    assert len(lv) == len(ov) == 5 and [a[:2] for a in lv] == [a[:2] for a in ov]
+    assert all(abs(a[2] - o[2]) <= 1e-12 * o[2] for a, o in zip(lv, ov))
+    assert rel_err(x, M.apply(b)) <= 1e-11
+
+
 def test_amg_device_setup_repeats_itself_and_the_wide_row_kernels_agree(monkeypatch):
     """The hierarchy is built on the device (nsk_amg_kernels.hip): a second and third set-up on the same handle (scratch
     arena reused) give the same bits as the first; the 64-lane row-product kernels (what a level with more than 128
