@@ -442,7 +442,7 @@ def test_amg_vcycle_matches_oracle(handles, name, subdomains):
 
 
 def test_amg_device_setup_matches_the_oracle_at_600x200():
-    """The device-built hierarchy at a BASELINE-sized block (2.1 M rows, 107 M non-zeros, five levels; the oracle's
+    """The device-built hierarchy at a BASELINE-sized block (2.1 M rows, 107 M non-zeros; the oracle's
     set-up takes a few seconds): same level sizes, non-zeros and lambda, one V-cycle to rounding.  (1200x400:
     tests/studies/amg_parity_full_size.py, profiles/r03_amg_device_vs_cpu_restatement_1200x400.log.)"""
     S, O = _S(), _O()
@@ -458,7 +458,7 @@ def test_amg_device_setup_matches_the_oracle_at_600x200():
         ls.close()
     M = O.Amg(O.CsrHolder.from_block(pr.F))
     ov = M.levels()
-    assert len(lv) == len(ov) == 5 and [a[:2] for a in lv] == [a[:2] for a in ov]
+    assert len(lv) == len(ov) >= 4 and [a[:2] for a in lv] == [a[:2] for a in ov]
     assert all(abs(a[2] - o[2]) <= 1e-12 * o[2] for a, o in zip(lv, ov))
     assert rel_err(x, M.apply(b)) <= 1e-11
 
