@@ -192,6 +192,7 @@ int aggregate(Scratch &S, const Csr &A, const double *ad, int *&agg, double *&pw
   uint16_t *flag = S.take<uint16_t>(amgk::flag_words((long)A.nnz, n));
   int *need = S.take<int>((size_t)n), *other = S.take<int>((size_t)n);
   uint64_t *key = S.take<uint64_t>((size_t)n), *k1 = S.take<uint64_t>((size_t)n), *k2 = S.take<uint64_t>((size_t)n);
+  uint64_t *key_next = S.take<uint64_t>((size_t)n);
   agg = S.take<int>((size_t)n);
   pw = nullptr;
   int *is_root = S.take<int>((size_t)n), *scan = S.take<int>((size_t)n + 1);
@@ -210,7 +211,8 @@ int aggregate(Scratch &S, const Csr &A, const double *ad, int *&agg, double *&pw
       amgk::mis_pull(s, M, bits, 1, key, need, stamp, key, k1);
       amgk::mis_pull(s, M, bits, 2, key, need, stamp, k1, k2);
       S.zero_counter(0);
-      amgk::mis_decide(s, n, key, k2, S.counters.p);
+      amgk::mis_decide(s, n, key, k2, key_next, S.counters.p);
+      std::swap(key, key_next);
       undecided = S.read_counter(0);
       // while most rows are undecided pass 1 covers all rows; afterwards only what the undecided rows will read
       stamp = -1;

@@ -34,7 +34,8 @@ void strength(hipStream_t s, const Mat &A, const double *ad, double threshold, u
 // stamp < 0); pass 2: the same over pass 1's result, undecided rows only
 void mis_pull(hipStream_t s, const Mat &A, const uint16_t *flag, int pass, const uint64_t *key, const int *need, int stamp,
               const uint64_t *in, uint64_t *out);
-void mis_decide(hipStream_t s, int n, uint64_t *key, const uint64_t *key2, int *undecided /* zeroed by the caller */);
+// the round's decisions from the snapshot (key, key2) into key_out; *undecided (zeroed by the caller) += rows still open
+void mis_decide(hipStream_t s, int n, const uint64_t *key, const uint64_t *key2, uint64_t *key_out, int *undecided);
 // need[j] = stamp for the undecided rows and their strong neighbours (what the next round's pass 2 reads)
 void mis_mark(hipStream_t s, const Mat &A, const uint16_t *flag, const uint64_t *key, int stamp, int *need);
 void root_flags(hipStream_t s, int n, const uint64_t *key, int *is_root);

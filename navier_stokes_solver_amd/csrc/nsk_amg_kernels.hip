@@ -258,20 +258,28 @@ __global__ __launch_bounds__(WG) void mis_pull_kernel(Mat A, const uint16_t *__r
   }
 }
 
-__global__ __launch_bounds__(WG) void mis_decide_kernel(int n, uint64_t *__restrict__ key, const uint64_t *__restrict__ key2,
-                                                        int *__restrict__ undecided) {
+// Decided on the round's snapshot (key, key2), written to key_out: a row is a root when it found its own key, out when
+// it found a root's key — or the key of a row that becomes a root in this very round (that row found its own key).
+__global__ __launch_bounds__(WG) void mis_decide_kernel(int n, const uint64_t *__restrict__ key, const uint64_t *__restrict__ key2,
+                                                        uint64_t *__restrict__ key_out, int *__restrict__ undecided) {
   __shared__ int wg_count;
   if (threadIdx.x == 0) wg_count = 0;
   __syncthreads();
   const int i = (int)(blockIdx.x * WG + threadIdx.x);
   if (i < n) {
     const uint64_t k = key[i];
+    uint64_t out = k;
     if ((k >> 62) == 1) {
       const uint64_t k2 = key2[i];
-      if (k2 == k) key[i] = (k & ~((uint64_t)3 << 62)) | ((uint64_t)2 << 62);
-      else if ((k2 >> 62) == 2) key[i] = 0;
-      else atomicAdd(&wg_count, 1);
+      if (k2 == k) out = (k & ~((uint64_t)3 << 62)) | ((uint64_t)2 << 62);
+      else if ((k2 >> 62) == 2) out = 0;
+      else {
+        const int m = (int)(k2 & 0x7fffffffu);
+        if (key2[m] == key[m]) out = 0;
+        else atomicAdd(&wg_count, 1);
+      }
     }
+    key_out[i] = out;
   }
   __syncthreads();
   if (threadIdx.x == 0 && wg_count) atomicAdd(undecided, wg_count);
@@ -646,8 +654,8 @@ void mis_pull(hipStream_t s, const Mat &A, const uint16_t *flag, int pass, const
   if (pass == 1) hipLaunchKernelGGL(mis_pull_kernel<1>, grid, dim3(WG), 0, s, A, flag, key, need, stamp, in, out);
   else hipLaunchKernelGGL(mis_pull_kernel<2>, grid, dim3(WG), 0, s, A, flag, key, need, stamp, in, out);
 }
-void mis_decide(hipStream_t s, int n, uint64_t *key, const uint64_t *key2, int *undecided) {
-  if (n > 0) hipLaunchKernelGGL(mis_decide_kernel, dim3(ew_grid(n)), dim3(WG), 0, s, n, key, key2, undecided);
+void mis_decide(hipStream_t s, int n, const uint64_t *key, const uint64_t *key2, uint64_t *key_out, int *undecided) {
+  if (n > 0) hipLaunchKernelGGL(mis_decide_kernel, dim3(ew_grid(n)), dim3(WG), 0, s, n, key, key2, key_out, undecided);
 }
 void mis_mark(hipStream_t s, const Mat &A, const uint16_t *flag, const uint64_t *key, int stamp, int *need) {
   if (A.n_rows > 0) hipLaunchKernelGGL(mis_mark_kernel, dim3(row_grid(A.n_rows, SLAB)), dim3(WG), 0, s, A, flag, key, stamp, need);

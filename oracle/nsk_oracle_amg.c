@@ -114,7 +114,7 @@ static double estimate_lambda(const hcsr *A, const double *dinv) {
  * root-and-neighbours rule; every round reads the previous round's state only, so any number of threads gives the
  * same aggregates): key(i) = state << 62 | hash(i) << 31 | i with state 1 = undecided, 2 = root, key 0 = out; a round
  * takes the maximum key over the strong neighbourhood twice; an undecided row that finds its own key becomes a root,
- * one that finds a root's key is out.  Roots are numbered in row order.  Then (pass A) a row next to a root joins it
+ * one that finds a root's key — or the key of a row that becomes a root in the same round — is out.  Roots are numbered in row order.  Then (pass A) a row next to a root joins it
  * and (pass B, on a snapshot) the others — every one of them has a pass-A neighbour, that is how it went out — join
  * the aggregate of their strongest assigned neighbour; "strongest" compares |a_ij| rounded to float, first in the row
  * wins ties (rounding noise of the coarse operators must not decide between mirror-image neighbours). */
@@ -139,11 +139,21 @@ static void mis2_rounds(const hcsr *A, const unsigned char *on, uint64_t *T) {
       for (int k = A->rp[i]; k < A->rp[i + 1]; ++k) if (on[k] && T1[A->col[k]] > m) m = T1[A->col[k]];
       T2[i] = m;
     }
+    /* decided on the round's snapshot (T, T2), written to T1 (no longer needed) and copied back: a row is a root when
+     * it finds its own key, out when it finds a root's key — or the key of a row that becomes a root in this very
+     * round (that row found its own key) */
     for (int i = 0; i < n; ++i) {
+      T1[i] = T[i];
       if ((T[i] >> 62) != 1) continue;
-      if (T2[i] == T[i]) { T[i] = (T[i] & ~((uint64_t)3 << 62)) | ((uint64_t)2 << 62); --undecided; }
-      else if ((T2[i] >> 62) == 2) { T[i] = 0; --undecided; }
+      const uint64_t t2 = T2[i];
+      if (t2 == T[i]) { T1[i] = (T[i] & ~((uint64_t)3 << 62)) | ((uint64_t)2 << 62); --undecided; }
+      else if ((t2 >> 62) == 2) { T1[i] = 0; --undecided; }
+      else {
+        const int m = (int)(t2 & 0x7fffffffu);
+        if (T2[m] == T[m]) { T1[i] = 0; --undecided; }
+      }
     }
+    memcpy(T, T1, sizeof(uint64_t) * (size_t)n);
   }
   free(T1); free(T2);
 }
