@@ -158,8 +158,9 @@ int nsk_set_option(nsk_handle h, int opt, double value);
 /* Preconditioner::initialize(...)  (NSSolverStationary.hpp:120,176,242; NSSolver.hpp:143,198,263).
  * Symbolic analysis is cached per pattern; numeric work (diag, SpGEMM, ILU) runs on the GPU.
  * The AMG hierarchy of the stationary block-triangular type is built when the preconditioner is first applied (a
- * solve that stops at step 0 never pays for it), from the values block (0,0) holds at that moment;
- * nsk_update_values / nsk_scale_values on block (0,0) build a pending hierarchy first, nsk_assemble does not. */
+ * solve that stops at step 0 never pays for it), from the values block (0,0) holds at that moment: change the block
+ * (nsk_update_values, nsk_scale_values, nsk_assemble) and call nsk_setup_preconditioner again before the next solve,
+ * as solve_system() does (NSSolverStationary.cpp:621-626). */
 int nsk_setup_preconditioner(nsk_handle h, int type, int variant, double alpha);
 
 /* solver.solve(jacobian_matrix, delta_owned, residual_vector, preconditioner):

@@ -138,7 +138,13 @@ struct nsk_handle_s {
     if (!amg_pending) return;
     amg_pending = false;
     const double t0 = wall_ms();
-    amgF.setup(&ctx, blk[NSK_BLK_F], sub_offsets(0));
+    try {
+      amgF.setup(&ctx, blk[NSK_BLK_F], sub_offsets(0));
+    } catch (...) {   // no half-built hierarchy: the next application tries (and reports) again
+      amgF.clear();
+      amg_pending = true;
+      throw;
+    }
     setup_ms += wall_ms() - t0;
     lazy_setup_ms += wall_ms() - t0;   // set-up work that ran inside a solve: counted as set-up, not as solve time
   }
@@ -837,7 +843,6 @@ int nsk_update_values(nsk_handle h, int b, const double *val) {
   NSK_TRY(h)
   if (b < 0 || b > NSK_BLK_BT_GHOST || !h->blk[b].present) throw Error(-60, "nsk_update_values: block not set");
   (void)hipSetDevice(h->ctx.device);
-  if (b == NSK_BLK_F) h->amg_ready();   // a pending hierarchy belongs to the values it was requested for
   Csr &A = h->blk[b];
   NSK_HIP(hipMemcpyAsync(A.val.p, val, sizeof(double) * (size_t)A.nnz, hipMemcpyHostToDevice, h->s()));
   A.refresh_blocked(h->s());
@@ -1291,8 +1296,8 @@ int nsk_assemble(nsk_handle h, int stokes, double nu, double inv_dt, double p_ou
   auto &A = h->asmd;
   if (!A.ready || !A.dirichlet_set || !A.state_set) throw Error(-66, "nsk_assemble needs cells, Dirichlet flags and a state");
   if (!(nu > 0.0)) throw Error(-60, "nsk_assemble: nu must be positive");
-  // (a hierarchy still pending here was requested for a solve that never applied it: it is NOT built from the old
-  //  values now; should a solve follow without a new nsk_setup_preconditioner, it is built from the new ones)
+  // (a hierarchy still pending here was requested for a solve that never applied it: it is built from the values the
+  //  block holds when it is first applied — nsk.h, nsk_setup_preconditioner — here as after nsk_update_values)
   if (inhomogeneous_bc && !A.have_bc) throw Error(-60, "nsk_assemble: no boundary values were given");
   Csr &F = h->blk[NSK_BLK_F];
   hipStream_t s = h->s();
@@ -1336,7 +1341,6 @@ int nsk_scale_values(nsk_handle h, int blk, double factor) {
   NSK_TRY(h)
   (void)hipSetDevice(h->ctx.device);
   if (blk < 0 || blk > NSK_BLK_S || !h->blk[blk].present) throw Error(-52, "nsk_scale_values: no such block");
-  if (blk == NSK_BLK_F) h->amg_ready();
   Csr &A = h->blk[blk];
   vec_scale(h->s(), (int)A.nnz, sref(factor), A.val.p);
   A.refresh_blocked(h->s());

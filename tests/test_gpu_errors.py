@@ -94,3 +94,29 @@ def test_update_values_refreshes_the_preconditioner():
         assert abs(its - info["iters"]) <= max(3, 0.2 * info["iters"])
     finally:
         ls.close()
+
+
+def test_a_failed_amg_setup_is_reported_and_does_not_stick():
+    """The velocity AMG is built when first applied.  Values it cannot be built from (a NaN: no finite eigenvalue
+    estimate) are reported at that application, no half-built hierarchy stays behind, and new values are accepted —
+    the hierarchy is then built from them."""
+    from navier_stokes_solver_amd import solver as S
+    from tests.util import rng_vec
+    pr = problem("ns16")
+    b = rng_vec(pr.n_u, 9)
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr)
+        ls.setup_preconditioner(S.BLOCK_TRIANGULAR, S.STATIONARY)
+        good = ls.tri_apply(S.TRI_VELOCITY, b)
+        bad = pr.F.val.copy()
+        bad[pr.F.rowptr[7]] = np.nan
+        ls.update_values(S.BLK_F, bad)
+        ls.setup_preconditioner(S.BLOCK_TRIANGULAR, S.STATIONARY)
+        for _ in range(2):
+            with pytest.raises(RuntimeError, match="AMG set-up"):
+                ls.tri_apply(S.TRI_VELOCITY, b)
+        ls.update_values(S.BLK_F, pr.F.val)          # the request is still pending: built from these values
+        assert np.array_equal(ls.tri_apply(S.TRI_VELOCITY, b), good)
+    finally:
+        ls.close()
