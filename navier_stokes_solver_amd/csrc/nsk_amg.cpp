@@ -125,41 +125,43 @@ void finish_csr(Ctx *ctx, Csr &D, int n_rows, int n_cols, int64_t nnz) {
 }
 
 // C = A B (product 0) or C = (I - c D^-1 A) Phat (product 1): count and prefix sum (row pointers into rp, n + 1 ints),
-// then fill; 16 lanes per row first, 64 when a row holds more distinct columns than the narrow hash set takes
+// then fill; the narrowest tier first (8 lanes per row; first_tier = 1 where rows are known to hold more than 64
+// distinct columns), the next one when a row holds more distinct columns than the tier's hash set takes
 struct ProductPlan {
-  int wide;
+  int tier;
   int64_t nnz;
 };
-ProductPlan product_rows(Scratch &S, const amgk::RowProduct &P, int product, int *rp) {
+ProductPlan product_rows(Scratch &S, const amgk::RowProduct &P, int product, int first_tier, int *rp) {
   hipStream_t s = S.ctx->stream;
   const int n = P.A.n_rows;
   int *len = S.take<int>((size_t)n + 1);
-  int wide = std::getenv("NSK_AMG_WIDE_ROWS") ? 1 : 0;   // test hook: start with the 64-lane kernels
-  for (;; ++wide) {
+  const char *hook = std::getenv("NSK_AMG_ROW_TIER");   // test hook: start with the 16- or 64-lane kernels
+  int tier = hook ? std::max(first_tier, std::min(2, std::atoi(hook))) : first_tier;
+  for (;; ++tier) {
     S.zero_counter(1);
-    amgk::product_count(s, P, product, wide, len, S.counters.p + 1);
+    amgk::product_count(s, P, product, tier, len, S.counters.p + 1);
     if (S.read_counter(1) == 0) break;
-    if (wide) throw Error(-81, "AMG set-up: a row of a level operator has more than 512 distinct columns");
+    if (tier == 2) throw Error(-81, "AMG set-up: a row of a level operator has more than 512 distinct columns");
   }
-  return ProductPlan{wide, S.scan(n, len, rp)};
+  return ProductPlan{tier, S.scan(n, len, rp)};
 }
-void row_product(Scratch &S, const amgk::RowProduct &P, int product, int n_cols, Csr &C) {
+void row_product(Scratch &S, const amgk::RowProduct &P, int product, int n_cols, int first_tier, Csr &C) {
   const int n = P.A.n_rows;
   C.rowptr.alloc((size_t)n + 1);
-  const ProductPlan pl = product_rows(S, P, product, C.rowptr.p);
+  const ProductPlan pl = product_rows(S, P, product, first_tier, C.rowptr.p);
   C.col.alloc((size_t)std::max<int64_t>(pl.nnz, 1));
   C.val.alloc((size_t)std::max<int64_t>(pl.nnz, 1));
-  amgk::product_fill(S.ctx->stream, P, product, pl.wide, C.rowptr.p, C.col.p, C.val.p, S.counters.p + 1);
+  amgk::product_fill(S.ctx->stream, P, product, pl.tier, C.rowptr.p, C.col.p, C.val.p, S.counters.p + 1);
   finish_csr(S.ctx, C, n, n_cols, pl.nnz);
 }
 // the same into scratch: an intermediate product that is never multiplied with a vector
-amgk::Mat row_product_scratch(Scratch &S, const amgk::RowProduct &P, int product, int n_cols) {
+amgk::Mat row_product_scratch(Scratch &S, const amgk::RowProduct &P, int product, int n_cols, int first_tier) {
   const int n = P.A.n_rows;
   int *rp = S.take<int>((size_t)n + 1);
-  const ProductPlan pl = product_rows(S, P, product, rp);
+  const ProductPlan pl = product_rows(S, P, product, first_tier, rp);
   int *col = S.take<int>((size_t)pl.nnz);
   double *val = S.take<double>((size_t)pl.nnz);
-  amgk::product_fill(S.ctx->stream, P, product, pl.wide, rp, col, val, S.counters.p + 1);
+  amgk::product_fill(S.ctx->stream, P, product, pl.tier, rp, col, val, S.counters.p + 1);
   return amgk::Mat{n, n_cols, rp, col, val};
 }
 
@@ -319,14 +321,14 @@ void Amg::build(AmgHierarchy &H, Csr *A0, std::unique_ptr<Csr> own0) {
       break;
     }
     amgk::RowProduct pp{mat(A), amgk::Mat{}, agg, pw, L->dinv.p, kOmega / L->lam};
-    row_product(S, pp, 1, nc, L->P);
+    row_product(S, pp, 1, nc, 1, L->P);   // (16 lanes: the row's terms, up to 98 on the Q3 block, are staged in LDS)
     lap(l, "smoothed prolongator");
     transpose(S, L->P, L->R);
     lap(l, "transpose");
-    const amgk::Mat AP = row_product_scratch(S, amgk::RowProduct{mat(A), mat(L->P), nullptr, nullptr, nullptr, 0.0}, 0, nc);
+    const amgk::Mat AP = row_product_scratch(S, amgk::RowProduct{mat(A), mat(L->P), nullptr, nullptr, nullptr, 0.0}, 0, nc, 0);
     lap(l, "A P");
     next = std::make_unique<Csr>();
-    row_product(S, amgk::RowProduct{mat(L->R), AP, nullptr, nullptr, nullptr, 0.0}, 0, nc, *next);
+    row_product(S, amgk::RowProduct{mat(L->R), AP, nullptr, nullptr, nullptr, 0.0}, 0, nc, 1, *next);   // (a coarse row: some 40 columns and more)
     lap(l, "R (A P)");
     L->has_coarse = true;
     ctx->sync();

@@ -47,16 +47,16 @@ void agg_weights(hipStream_t s, int nc, const int *count, double *pw /* 1 / sqrt
 
 // ---- row products with a hash set per row in LDS ----
 // product = 0: C = A B ; product = 1: C = (I - c D^-1 A) Phat with Phat(i, agg[i]) = pw[agg[i]] (B unused).
-// wide = 0: 16 lanes per row, at most 128 distinct columns per row; wide = 1: 64 lanes, at most 512.  *err |= 1 when a
-// row has more (the caller retries wide, then gives up loudly).
+// tier 0: 8 lanes per row, at most 64 distinct columns per row; 1: 16 lanes, 128; 2: 64 lanes, 512.  *err |= 1 when a row
+// has more (the caller retries with the next tier, then gives up loudly).
 struct RowProduct {
   Mat A, B;
   const int *agg;
   const double *pw, *dinv;
   double c;
 };
-void product_count(hipStream_t s, const RowProduct &P, int product, int wide, int *len, int *err);
-void product_fill(hipStream_t s, const RowProduct &P, int product, int wide, const int *c_rp, int *c_col, double *c_val,
+void product_count(hipStream_t s, const RowProduct &P, int product, int tier, int *len, int *err);
+void product_fill(hipStream_t s, const RowProduct &P, int product, int tier, const int *c_rp, int *c_col, double *c_val,
                   int *err);
 
 void start_vector(hipStream_t s, int n, double *x);   // start vector of the power iteration (hash of the row index)

@@ -678,23 +678,30 @@ void agg_weights(hipStream_t s, int nc, const int *count, double *pw) {
   if (nc > 0) hipLaunchKernelGGL(agg_weights_kernel, dim3(ew_grid(nc)), dim3(WG), 0, s, nc, count, pw);
 }
 
+// tier 0: 8 lanes per row, 64 distinct columns; 1: 16 lanes, 128; 2: 64 lanes, 512
 template <bool FILL>
-static void product_launch(hipStream_t s, const RowProduct &P, int product, int wide, const int *c_rp, int *out, double *c_val,
+static void product_launch(hipStream_t s, const RowProduct &P, int product, int tier, const int *c_rp, int *out, double *c_val,
                            int *err) {
   const int n = P.A.n_rows;
   if (n <= 0) return;
-  const dim3 grid(row_grid(n, wide ? WG / 64 : WG / 16)), block(WG);
-  if (product && wide) hipLaunchKernelGGL((prolong_kernel<64, 512, FILL>), grid, block, 0, s, P, c_rp, out, c_val, err);
-  else if (product) hipLaunchKernelGGL((prolong_kernel<16, 128, FILL>), grid, block, 0, s, P, c_rp, out, c_val, err);
-  else if (wide) hipLaunchKernelGGL((product_ab_kernel<64, 512, FILL>), grid, block, 0, s, P.A, P.B, c_rp, out, c_val, err);
-  else hipLaunchKernelGGL((product_ab_kernel<16, 128, FILL>), grid, block, 0, s, P.A, P.B, c_rp, out, c_val, err);
+  const int lanes = tier == 0 ? 8 : tier == 1 ? 16 : 64;
+  const dim3 grid(row_grid(n, WG / lanes)), block(WG);
+  if (product) {
+    if (tier == 0) hipLaunchKernelGGL((prolong_kernel<8, 64, FILL>), grid, block, 0, s, P, c_rp, out, c_val, err);
+    else if (tier == 1) hipLaunchKernelGGL((prolong_kernel<16, 128, FILL>), grid, block, 0, s, P, c_rp, out, c_val, err);
+    else hipLaunchKernelGGL((prolong_kernel<64, 512, FILL>), grid, block, 0, s, P, c_rp, out, c_val, err);
+  } else {
+    if (tier == 0) hipLaunchKernelGGL((product_ab_kernel<8, 64, FILL>), grid, block, 0, s, P.A, P.B, c_rp, out, c_val, err);
+    else if (tier == 1) hipLaunchKernelGGL((product_ab_kernel<16, 128, FILL>), grid, block, 0, s, P.A, P.B, c_rp, out, c_val, err);
+    else hipLaunchKernelGGL((product_ab_kernel<64, 512, FILL>), grid, block, 0, s, P.A, P.B, c_rp, out, c_val, err);
+  }
 }
-void product_count(hipStream_t s, const RowProduct &P, int product, int wide, int *len, int *err) {
-  product_launch<false>(s, P, product, wide, nullptr, len, nullptr, err);
+void product_count(hipStream_t s, const RowProduct &P, int product, int tier, int *len, int *err) {
+  product_launch<false>(s, P, product, tier, nullptr, len, nullptr, err);
 }
-void product_fill(hipStream_t s, const RowProduct &P, int product, int wide, const int *c_rp, int *c_col, double *c_val,
+void product_fill(hipStream_t s, const RowProduct &P, int product, int tier, const int *c_rp, int *c_col, double *c_val,
                   int *err) {
-  product_launch<true>(s, P, product, wide, c_rp, c_col, c_val, err);
+  product_launch<true>(s, P, product, tier, c_rp, c_col, c_val, err);
 }
 
 // x[i] = the start vector of the power iteration (an integer hash of the row index, in [-0.5, 0.5))

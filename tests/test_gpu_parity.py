@@ -465,8 +465,8 @@ def test_amg_device_setup_matches_the_oracle_at_600x200():
 
 def test_amg_device_setup_repeats_itself_and_the_wide_row_kernels_agree(monkeypatch):
     """The hierarchy is built on the device (nsk_amg_kernels.hip): a second and third set-up on the same handle (scratch
-    arena reused) give the same bits as the first; the 64-lane row-product kernels (what a level with more than 128
-    distinct columns in a row falls to) give the 16-lane kernels' bits, hence the oracle's V-cycle too."""
+    arena reused) give the same bits as the first; the 16- and 64-lane row-product kernels (what a level with more than
+    64 / 128 distinct columns in a row falls to) give the 8-lane kernels' bits, hence the oracle's V-cycle too."""
     S, O = _S(), _O()
     pr = problem("ns60")
     b = rng_vec(pr.n_u, 78)
@@ -475,9 +475,9 @@ def test_amg_device_setup_repeats_itself_and_the_wide_row_kernels_agree(monkeypa
     ls = S.LinearSolver()
     try:
         ls.set_problem(pr)
-        for rep in range(4):
-            if rep == 3:
-                monkeypatch.setenv("NSK_AMG_WIDE_ROWS", "1")
+        for rep in range(5):
+            if rep >= 3:
+                monkeypatch.setenv("NSK_AMG_ROW_TIER", str(rep - 2))
             ls.setup_preconditioner(S.BLOCK_TRIANGULAR, S.STATIONARY)
             out.append((ls.amg_levels(), ls.tri_apply(S.TRI_VELOCITY, b)))
     finally:
