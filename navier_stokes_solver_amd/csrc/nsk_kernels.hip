@@ -957,7 +957,7 @@ __device__ __forceinline__ void ilu0_row(int i, int lane, double *w, const int *
       const int j = col[m];
       int lo = k + 1, hi = re;
       while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
+        const int mid = lo + ((hi - lo) >> 1);   // (positions pass 2^30 at a rank's share of 4800x1600 on four GPUs)
         if (col[mid] < j) lo = mid + 1; else hi = mid;
       }
       if (lo < re && col[lo] == j) w[lo - rs] -= l * val[m];
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(BLK) void spgemm_kernel(CsrView B, const double *__
       const int j = R.col[q];
       int lo = ss, hi = se;
       while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
+        const int mid = lo + ((hi - lo) >> 1);   // (positions pass 2^30 at a rank's share of 4800x1600 on four GPUs)
         if (scol[mid] < j) lo = mid + 1; else hi = mid;
       }
       acc[lo - ss] += a * R.val[q];  // the pattern is the structural product, so j is always present
