@@ -284,7 +284,10 @@ def test_solve_matches_oracle_and_direct(handles, name, solver, prec, variant, t
     x = np.concatenate([xu, xp])
     true_res = np.linalg.norm(b - J @ x)
     if solver == 0:
-        assert true_res <= 1e3 * tol  # left-preconditioned GMRES controls the preconditioned residual
+        # left-preconditioned GMRES controls the PRECONDITIONED residual: the true one is whatever the oracle's is
+        true_res_o = np.linalg.norm(b - J @ xo)
+        print(f"GMRES true residual {true_res:.3e}, oracle {true_res_o:.3e}, tol {tol:.1e}")
+        assert true_res <= 3.0 * max(true_res_o, tol), (true_res, true_res_o)
     else:
         assert true_res <= 1.05 * tol
     if solver == 2:
