@@ -2,8 +2,8 @@
 //
 // The method is the one DESIGN.md 5a specifies for TrilinosWrappers::PreconditionAMG
 // (lab_new/src/NSSolverStationary.hpp:225,231); here every step is a row-parallel kernel:
-//   * rows are handled by groups of 16 (or 64) lanes of a wavefront: a row of the Q3 velocity block holds 32-98
-//     entries, which a group reads coalesced; group results come from shuffles;
+//   * rows are handled by groups of 16 lanes of a wavefront (8 or 64 in the row products, by the row lengths): a row of
+//     the Q3 velocity block holds 32-98 entries, which a group reads coalesced; group results come from shuffles;
 //   * products of sparse rows (the smoothed prolongator, A P, R (A P)) find the distinct columns of a row with a hash
 //     SET in LDS (insertion order does not matter); the sums are then formed term by term in the order the serial
 //     restatement forms them — no atomics on values, no fused multiply-adds — so that a run reproduces itself and the
