@@ -493,7 +493,7 @@ def test_amg_device_setup_repeats_itself_and_the_wide_row_kernels_agree(monkeypa
 
 def test_amg_follows_a_second_hand_off_with_another_pattern():
     """A second nsk_set_block_csr(F) on the same handle with the same size and nnz but another PATTERN (a renumbered
-    mesh): the AMG set-up must not reuse the level-0 host copy it kept from the first pattern."""
+    mesh): the hierarchy follows the new pattern (rounds 1-2 kept a host copy of level 0 that had to be dropped)."""
     S = _S()
     import scipy.sparse as sp
     from types import SimpleNamespace
@@ -524,6 +524,49 @@ def test_amg_follows_a_second_hand_off_with_another_pattern():
             ls.close()
     assert out[0][0] == out[1][0] and len(out[0][0]) >= 2
     assert np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("seed,mean_row", [(11, 12), (12, 60), (13, 150)])
+def test_amg_device_setup_on_an_irregular_nonsymmetric_block(seed, mean_row):
+    """The set-up kernels away from the lattice they were tuned on: a random nonsymmetric pattern with rows of a few to a
+    few hundred entries (longer than the 128-entry staging area of the prolongator kernel, more distinct columns than the
+    narrow hash sets take, strength that holds in one direction only), weak entries and rows without strong connections
+    mixed in.  Hierarchy sizes and one V-cycle against the oracle."""
+    S, O = _S(), _O()
+    import scipy.sparse as sp
+    from types import SimpleNamespace
+    pr = problem("ns16")
+    n = pr.n_u
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        k = int(np.clip(rng.geometric(1.0 / mean_row), 1, n // 4))
+        c = np.unique(np.concatenate([rng.integers(0, n, k), np.clip(i + rng.integers(-30, 31, 8), 0, n - 1)]))
+        c = c[c != i]
+        v = -rng.uniform(0.0, 1.0, len(c)) * 10.0 ** rng.integers(-7, 1, len(c))    # weak and strong entries
+        if i % 97 == 0:
+            v *= 1e-9                                                                 # a row without strong connections
+        rows += [i] * (len(c) + 1)
+        cols += list(c) + [i]
+        vals += list(v) + [np.abs(v).sum() + 1.0]
+    F2 = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    F2.sort_indices()
+    assert np.diff(F2.indptr).max() > 128
+    blk2 = SimpleNamespace(rowptr=F2.indptr.astype(np.int32), col=F2.indices.astype(np.int32), val=F2.data, rows=n, cols=n)
+    b = rng_vec(n, 6)
+    ls = S.LinearSolver()
+    try:
+        ls.set_problem(pr)
+        ls.set_block(S.BLK_F, blk2)
+        ls.setup_preconditioner(S.BLOCK_TRIANGULAR, S.STATIONARY)
+        lv, x = ls.amg_levels(), ls.tri_apply(S.TRI_VELOCITY, b)
+    finally:
+        ls.close()
+    M = O.Amg(O.CsrHolder.from_scipy(F2))
+    ov = M.levels()
+    assert [a[:2] for a in lv] == [a[:2] for a in ov], (lv, ov)
+    assert all(abs(a[2] - o[2]) <= 1e-10 * o[2] for a, o in zip(lv, ov))
+    assert rel_err(x, M.apply(b)) <= 1e-10
 
 
 def test_solve_system_raises_like_reference(handles):
