@@ -68,6 +68,7 @@ void orc_amg_free(orc_amg *M);
 int orc_amg_levels(const orc_amg *M, int shard);
 int orc_amg_level_rows(const orc_amg *M, int shard, int level);
 long orc_amg_level_nnz(const orc_amg *M, int shard, int level);
+int orc_amg_level_aggregates(const orc_amg *M, int shard, int level, int *out);
 double orc_amg_level_lambda(const orc_amg *M, int shard, int level);
 
 typedef struct {

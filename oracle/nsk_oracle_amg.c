@@ -50,6 +50,7 @@ typedef struct {
   double *dinv;
   double lam;   /* boosted estimate of lambda_max(D^-1 A) */
   double *inv;  /* coarsest level: dense inverse (row-major) or NULL */
+  int *agg;     /* aggregate of every row (-2: not aggregated), levels with a coarser one */
   double *x, *b, *r, *w;
 } amg_level;
 
@@ -383,7 +384,7 @@ static void hier_build(amg_hier *H, hcsr A0 /* ownership taken */) {
       break;
     }
     smoothed_prolongator(&L->A, agg, nc, L->dinv, L->lam, &L->P);
-    free(agg);
+    L->agg = agg;
     transpose(&L->P, &L->R);
     hcsr AP;
     spgemm(&L->A, &L->P, &AP);
@@ -444,7 +445,7 @@ static void hier_free(amg_hier *H) {
   for (int l = 0; l < H->n_levels; ++l) {
     amg_level *L = &H->lev[l];
     hcsr_free(&L->A); hcsr_free(&L->P); hcsr_free(&L->R);
-    free(L->dinv); free(L->inv); free(L->x); free(L->b); free(L->r); free(L->w);
+    free(L->dinv); free(L->inv); free(L->x); free(L->b); free(L->r); free(L->w); free(L->agg);
   }
 }
 
@@ -497,3 +498,10 @@ long orc_amg_level_nnz(const orc_amg *M, int shard, int level) {
   return A->rp[A->n_rows];
 }
 double orc_amg_level_lambda(const orc_amg *M, int shard, int level) { return M->h[shard].lev[level].lam; }
+/* aggregate ids of the level's rows into out[rows]; returns 0 when the level has no coarser one */
+int orc_amg_level_aggregates(const orc_amg *M, int shard, int level, int *out) {
+  const amg_level *L = &M->h[shard].lev[level];
+  if (!L->agg) return 0;
+  memcpy(out, L->agg, sizeof(int) * (size_t)L->A.n_rows);
+  return 1;
+}

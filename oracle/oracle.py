@@ -71,6 +71,7 @@ def lib() -> C.CDLL:
         L.orc_amg_level_nnz.restype = C.c_long
         L.orc_amg_level_lambda.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_amg_level_lambda.restype = C.c_double
+        L.orc_amg_level_aggregates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_solve.argtypes = [C.POINTER(Problem), C.POINTER(Opts), C.c_void_p, C.c_void_p, C.POINTER(Result)]
         L.orc_set_history.argtypes = [C.c_void_p, C.c_int]
         L.orc_prec_apply.argtypes = [C.POINTER(Problem), C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_int]
@@ -170,6 +171,12 @@ class Amg:
         L = lib()
         return [(L.orc_amg_level_rows(self.h, shard, l), L.orc_amg_level_nnz(self.h, shard, l),
                  L.orc_amg_level_lambda(self.h, shard, l)) for l in range(L.orc_amg_levels(self.h, shard))]
+
+    def aggregates(self, level, shard=0):
+        """Aggregate id of every row of a level (-2: not aggregated), or None on the coarsest level."""
+        L = lib()
+        out = np.empty(L.orc_amg_level_rows(self.h, shard, level), np.int32)
+        return out if L.orc_amg_level_aggregates(self.h, shard, level, out.ctypes.data) else None
 
     def __del__(self):
         if getattr(self, "h", None):

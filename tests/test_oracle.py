@@ -122,6 +122,89 @@ def test_amg_vcycle_properties():
     assert (~free).sum() > 0
 
 
+def _aggregate_numpy(A):
+    """DESIGN.md 5a restated with numpy (whole-array rounds, no row order anywhere): the second, independent statement of
+    the aggregation rule that oracle/nsk_oracle_amg.c and the device kernels follow."""
+    A = A.tocsr()
+    A.sort_indices()
+    n = A.shape[0]
+    rp, col, val = A.indptr, A.indices, A.data
+    row = np.repeat(np.arange(n), np.diff(rp))
+    d = np.zeros(n)
+    d[row[col == row]] = np.abs(val[col == row])
+    strong = (col != row) & (val * val > (1e-4 * 1e-4) * d[row] * d[col])
+    has = np.zeros(n, bool)
+    has[row[strong]] = True
+    u = np.uint64
+
+    def mix32(h):
+        h = h.astype(u)
+        h ^= h >> u(16); h = (h * u(0x7feb352d)) & u(0xffffffff)
+        h ^= h >> u(15); h = (h * u(0x846ca68b)) & u(0xffffffff)
+        h ^= h >> u(16)
+        return h
+    idx = np.arange(n, dtype=u)
+    key = np.where(has, (u(1) << u(62)) | ((mix32(idx) >> u(2)) << u(31)) | idx, u(0)).astype(u)
+    srow, scol = row[strong], col[strong]
+
+    def pull(v):                                        # max over the row itself and its strong (directed) neighbours
+        out = v.copy()
+        np.maximum.at(out, srow, v[scol])
+        return out
+    while np.any((key >> u(62)) == 1):
+        k2 = pull(pull(key))
+        und = (key >> u(62)) == 1
+        becomes_root = und & (k2 == key)
+        sees_root = und & ((k2 >> u(62)) == 2)
+        m = (k2 & u(0x7fffffff)).astype(np.int64)      # the row whose key was found
+        sees_root_to_be = und & ~becomes_root & ~sees_root & ((k2 >> u(62)) == 1) & becomes_root[m]
+        key = np.where(becomes_root, (key & ~(u(3) << u(62))) | (u(2) << u(62)), key)
+        key = np.where(sees_root | sees_root_to_be, u(0), key)
+    is_root = (key >> u(62)) == 2
+    agg = np.where(has, -1, -2).astype(np.int64)
+    agg[is_root] = np.arange(is_root.sum())
+    for roots_only in (True, False):
+        snap = agg.copy()
+        for i in np.flatnonzero(snap == -1):
+            ks = np.arange(rp[i], rp[i + 1])
+            ks = ks[strong[ks] & (snap[col[ks]] >= 0)]
+            if roots_only:
+                ks = ks[is_root[col[ks]]]
+            if len(ks):
+                w = np.abs(val[ks]).astype(np.float32)
+                agg[i] = snap[col[ks[np.argmax(w)]]]    # (argmax: the first of equal weights)
+    return agg
+
+
+def test_amg_aggregates_follow_the_specification():
+    """The aggregates of the C restatement against the numpy statement of DESIGN.md 5a, on level 0 of the 60x20 velocity
+    block (a DIRECTED strength graph: 13 % of its connections hold in one direction only) and on a symmetric Laplacian;
+    independence of the number of threads."""
+    import scipy.sparse as sp
+    pr = problem("ns60")
+    A = pr.F.to_scipy().tocsr()
+    M = O.Amg(O.CsrHolder.from_block(pr.F))
+    agg = M.aggregates(0)
+    assert agg is not None and M.aggregates(len(M.levels()) - 1) is None
+    ref = _aggregate_numpy(A)
+    assert np.array_equal(agg, ref)
+    assert agg.max() + 1 == M.levels()[1][0] and (agg == -2).sum() > 0          # Dirichlet rows stay out
+    # a 5-point Laplacian (symmetric strength)
+    k = 40
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(k, k))
+    L = (sp.kron(sp.identity(k), T) + sp.kron(T, sp.identity(k))).tocsr()
+    ML = O.Amg(O.CsrHolder.from_scipy(L))
+    aggL = ML.aggregates(0)
+    assert np.array_equal(aggL, _aggregate_numpy(L))
+    sizes = np.bincount(aggL)
+    assert sizes.min() >= 2 and sizes.max() <= 13                                # a root, its 4 neighbours, part of the ring
+    O.lib().orc_set_threads(3)
+    try:
+        assert np.array_equal(O.Amg(O.CsrHolder.from_block(pr.F)).aggregates(0), agg)
+    finally:
+        O.lib().orc_set_threads(1)
+
+
 def test_block_triangular_with_amg_reaches_the_direct_solution():
     pr, J, b, x0 = _sys("ns16")
     xs = spl.splu(J).solve(b)
