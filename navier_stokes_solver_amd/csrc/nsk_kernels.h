@@ -211,31 +211,41 @@ void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, 
 
 // ---- natural-order ("caller's order") triangular solve through an LDS ring ----
 // A factor in the caller's order has O(nx + ny) dependent levels of a few hundred rows: nothing to spread over a GPU,
-// and one workgroup walking the levels pays a trip to memory per level.  Here ONE 1024-thread workgroup walks PASSES
-// (at most kRingRows independent rows each, 8 lanes per row) whose data sits in padded per-pass records (one coalesced
-// load per thread, issued kRingDepth passes ahead), and the results the following passes need live in an LDS ring
-// indexed by the row's position in the pass order: the critical path of a pass is LDS + one barrier, not a trip to HBM.
-// Requirements (checked by the analysis): at most 8 * kRingE entries per row and half, and every dependency at most
-// kRingSlots - 2 * kRingRows positions back.
-// Shape: 8 lanes per row, 2 entries per lane (rows of <= 16 entries per half), 128 rows per pass, 8 passes ahead — the
-// lane decomposition, the order of the row sums and the DIVISION by the diagonal of the level walker (tri_row<8>), so
-// that both give the same bits.  (4 lanes x 3 entries, 256 rows per pass = one pass per level on the reference's
-// lattices, measured 9.5 against 10.9 ms per application at 600x200; its other summation order tipped the third Newton
-// system of config 5 from 1 363 iterations into a stall — DESIGN.md 5d.1 — and it was not kept.)
-constexpr int kRingThreads = 1024, kRingSlots = 8192;   // (the ring: 64 KB of LDS)
+// and one workgroup walking the levels pays a trip to memory per level.  Here ONE workgroup of kRingWaves wavefronts
+// walks PASSES (at most kRingRows independent rows each); the results the following passes need live in an LDS ring
+// indexed by the row's position in the pass order, and the hand-off between wavefronts is point-to-point: a ring slot
+// holds a NaN until its row is done, a consumer whose row sum comes out NaN reads its operands again.  There is no
+// barrier per pass — only one every `epoch` passes, behind which the slots of the epoch after the next are set back to
+// NaN (so no wavefront is ever more than two epochs from another, and a slot is never re-used while it can be read).
+// Shape: 2 lanes per row, 8 entries per lane (rows of <= 16 entries per half), 32 rows per wavefront.  A lane sums its
+// entries the way lanes l, l+2, l+4, l+6 of the level walker's 8-lane group do (tri_row<8>) and the partial sums are
+// added in the order of its shuffle tree, the diagonal is DIVIDED by: the walker's bits (config 5 sits
+// on an edge that rounding decides).
+// Data: everything a wavefront needs for a pass is contiguous and holds no padding — rows of a pass are sorted by
+// length, so the lanes that own an entry in register r are a prefix of the wavefront and a buffer load whose
+// descriptor ends after n_r records returns {0.0, slot 0} to the others (slot 0 of the LDS image holds 0.0): the
+// addresses are scalar arithmetic on a 16-byte header per (pass, wavefront), no lane computes one.  One CU streams the
+// whole factor, so bytes count: 12 per entry, 24 per row.
+constexpr int kRingWaves = 8, kRingThreads = 64 * kRingWaves, kRingLpr = 2, kRingRegs = 8;
+constexpr int kRingRowsPerWave = 64 / kRingLpr, kRingRows = kRingWaves * kRingRowsPerWave;
+constexpr int kRingSlots = 8192;      // the ring: 64 KB of LDS (+ 8 bytes: the zero that padding reads)
+constexpr int kRingDepth = 4;         // passes whose records are in flight (registers)
+constexpr int kRingMaxEpoch = 48;     // passes between two workgroup barriers, at most (a multiple of kRingDepth)
+constexpr int kRingMaxRows = 1 << 26; // (the header keeps a position in 26 bits)
 struct RingHalf {
-  int n_pass;             // a multiple of the shape's look-ahead depth; the records hold `depth` empty passes more
-  int lpr;                // lanes per row: 8 (E = 2, depth 8)
-  const int *pass_base;   // [passes] position (in pass order) of the pass's first row
-  const int *rowid;       // [passes * rows_per_pass] row of (pass, slot) or -1
-  const double *rdiag;    // [passes * rows_per_pass] diagonal of that row
-  const int *epos;        // [passes * kRingThreads * E] position of the entry's column row (0 for padding)
-  const double *eval;     // [passes * kRingThreads * E] value (0 for padding)
+  int n_pass;                 // a multiple of kRingDepth; the records hold 2 * kRingDepth empty passes more
+  int epoch;                  // passes between two workgroup barriers (a multiple of kRingDepth)
+  const uint4 *hdr;           // [passes * kRingWaves] {first entry, first position | rows << 26, lanes holding register 0..3 (a byte each), 4..7}
+  const char *ent;            // 12-byte entries {double value; u32 LDS byte offset of the column's slot}
+  const double *rdiag;        // [positions] diagonal of the row at that position
+  const uint2 *meta;          // [positions] {byte offset of the row's result in dst, LDS byte offset of its slot}
+  const int2 *rearm;          // [n_pass / epoch + 1] positions {first, count} set back to NaN behind barrier k
 };
-constexpr int ring_entries(int lpr) { return lpr == 8 ? 2 : 3; }
-constexpr int ring_depth(int lpr) { return lpr == 8 ? 8 : 6; }
-// lower: y[i] = kind ? (rhs[i] - s) * dinv : rhs[i] - s ; upper: out[i] = kind ? y[i] - s * dinv : (y[i] - s) * dinv
+// own: the row's own value (right-hand side / lower half's result) in POSITION order; dst: see RingHalf::meta
+// lower: dst = kind ? (own - s) / d : own - s ; upper: dst = kind ? own - s / d : (own - s) / d
 void tri_ring(hipStream_t s, const RingHalf &R, int lower, int kind, const double *own, double *dst);
+// ent[12 i] = idx[i] >= 0 ? x[idx[i]] : 0 (the value part of the 12-byte entries)
+void ring_fill_values(hipStream_t s, long n, const int *idx, const double *x, char *ent);
 
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,

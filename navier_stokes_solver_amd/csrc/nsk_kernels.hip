@@ -887,54 +887,143 @@ __global__ __launch_bounds__(SERIAL_BLK) void tri_serial_kernel(TriView T, const
 }
 
 // ------------------------------------------------------------------ natural-order solve through an LDS ring
-template <int KIND, bool LOWER, int LPR>
-__global__ __launch_bounds__(kRingThreads) void tri_ring_kernel(RingHalf R, const double *__restrict__ own_src,
-                                                                double *__restrict__ dst) {
-  __shared__ double ring[kRingSlots];
-  constexpr int D = ring_depth(LPR), E = ring_entries(LPR), MASK = kRingSlots - 1, kRingRows = kRingThreads / LPR;
-  const int t = threadIdx.x, sub = t / LPR, lane = t % LPR;
-  for (int k = t; k < kRingSlots; k += kRingThreads) ring[k] = 0.0;
-  int rid[D], bs[D], ps[D][E];
-  double dv[D], vl[D][E], ow[D];
-  // (the records are padded to a multiple of kRingDepth passes plus kRingDepth empty ones, so that every load below is
-  //  unconditional: with branches around them the compiler waits for ALL outstanding loads at every join, i.e. pays the
-  //  trip to memory in every pass — measured: 3 us per pass instead of 0.4)
-  auto load_a = [&](int slot, int q) {   // the pass's padded record: no load depends on another
-    rid[slot] = R.rowid[(size_t)q * kRingRows + sub];
-    bs[slot] = R.pass_base[q];
-    dv[slot] = R.rdiag[(size_t)q * kRingRows + sub];
+// (nsk_kernels.h has the design.)  LDS image: [0] = 0.0, read by padding entries; [1, kRingSlots] the ring;
+// [kRingSlots + 1] a word that tells every wavefront to stop waiting (a NaN that is DATA would otherwise be waited for
+// at every row it reaches).
+constexpr int kRingSpinLimit = 1 << 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ring_rsrc(const void *base, unsigned bytes) {
+  // raw buffer (stride 0): a lane whose offset is >= `bytes` gets zeros back — the lanes behind a record's last entry
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double ring_pair_partner(double v) {   // lane 2k receives lane 2k + 1's value (DPP, no LDS trip)
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0xF5 /* quad_perm:[1,1,3,3] */, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0xF5, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int KIND, bool LOWER>
+__global__ __launch_bounds__(kRingThreads) void tri_ring_kernel(RingHalf R, const int2 *__restrict__ rearm /* = R.rearm: a scalar load */,
+                                                                const double *__restrict__ own_src, double *__restrict__ dst) {
+  __shared__ double ring_lds[kRingSlots + 2];
+  constexpr int D = kRingDepth, E = kRingRegs;
+  constexpr bool DIAG = !(KIND == 0 && LOWER);   // (the unit lower factor of ILU(0) has no diagonal to divide by)
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const double nan_v = __longlong_as_double((long long)kSentinel);
+  // (LDS pointers keep their address space: through a generic pointer every access would be a FLAT instruction that
+  //  waits for all vector-memory traffic — the records in flight)
+  using lds_char = __attribute__((address_space(3))) char;
+  using lds_double = __attribute__((address_space(3))) double;
+  using lds_int = __attribute__((address_space(3))) int;
+  lds_char *const lds = (lds_char *)ring_lds;
+  for (int k = t; k < kRingSlots; k += kRingThreads) ring_lds[1 + k] = nan_v;
+  if (t == 0) { ring_lds[0] = 0.0; ring_lds[kRingSlots + 1] = 0.0; }
+  volatile lds_int *const give_up = (volatile lds_int *)(lds + 8 * (kRingSlots + 1));
+
+  // per stage: the records of one pass (registers); per stage one header in flight for the pass kRingDepth later
+  unsigned e_lo[D][E], e_hi[D][E], e_off[D][E], m_dst[D], m_slot[D], n_lanes[D];
+  double own[D], dg[D];
+  unsigned hx[D], hy[D], hz[D], hw[D];
+  const unsigned vo12 = (unsigned)lane * 12u, vo8 = (unsigned)(lane >> 1) * 8u;
+  const __amdgpu_buffer_rsrc_t hdr_rs = ring_rsrc(R.hdr, 0x7FFFFFF0u);
+  auto load_hdr = [&](int slot, int q) {   // (a VECTOR load of a uniform address: scalar loads share lgkmcnt with the LDS traffic)
+    const auto h = __builtin_amdgcn_raw_buffer_load_b128(hdr_rs, 0, (q * kRingWaves + wave) * 16, 0);
+    hx[slot] = h[0]; hy[slot] = h[1]; hz[slot] = h[2]; hw[slot] = h[3];
+  };
+  auto issue = [&](int slot) {   // every load of the pass whose header sits in this stage: 8 entry registers + the rows' own data
+    const unsigned h0 = __builtin_amdgcn_readfirstlane(hx[slot]), h1 = __builtin_amdgcn_readfirstlane(hy[slot]);
+    const unsigned h2 = __builtin_amdgcn_readfirstlane(hz[slot]), h3 = __builtin_amdgcn_readfirstlane(hw[slot]);
+    const unsigned pos0 = h1 & 0x3FFFFFFu, rows = h1 >> 26;
+    const char *ep = R.ent + (size_t)h0 * 12u;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const size_t idx = ((size_t)q * kRingThreads + t) * E + e;
-      ps[slot][e] = R.epos[idx];
-      vl[slot][e] = R.eval[idx];
+    for (int r = 0; r < E; ++r) {
+      const unsigned n = ((r < 4 ? h2 : h3) >> (8 * (r & 3))) & 0xFFu;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b96(ring_rsrc(ep, n * 12u), vo12, 0, 0);
+      e_lo[slot][r] = v[0]; e_hi[slot][r] = v[1]; e_off[slot][r] = v[2];
+      ep += n * 12u;
+    }
+    const auto o = __builtin_amdgcn_raw_buffer_load_b64(ring_rsrc(own_src + pos0, rows * 8u), vo8, 0, 0);
+    own[slot] = __hiloint2double((int)o[1], (int)o[0]);
+    if (DIAG) {
+      const auto g = __builtin_amdgcn_raw_buffer_load_b64(ring_rsrc(R.rdiag + pos0, rows * 8u), vo8, 0, 0);
+      dg[slot] = __hiloint2double((int)g[1], (int)g[0]);
+    }
+    const auto m = __builtin_amdgcn_raw_buffer_load_b64(ring_rsrc(R.meta + pos0, rows * 8u), vo8, 0, 0);
+    m_dst[slot] = m[0]; m_slot[slot] = m[1];
+    n_lanes[slot] = rows * kRingLpr;
+  };
+  auto compute = [&](int slot) {
+    const unsigned nl = n_lanes[slot];
+    const bool rowlane = (lane & 1) == 0 && (unsigned)lane < nl;
+    double res = 0.0;
+    if (nl != 0) {   // (wavefront-uniform; no vector-memory instruction inside: the counts the waits rely on stay static)
+      for (int tries = 0;;) {
+        double x[E], s[4];
+#pragma unroll
+        for (int r = 0; r < E; ++r) x[r] = *(volatile lds_double *)(lds + e_off[slot][r]);
+        // lane l of a pair holds the walker's lanes l, l + 2, l + 4, l + 6: entry w sits in walker lane w % 8, the
+        // walker adds entry w + 8 onto entry w, then lanes (l, l + 4), then (l, l + 2), then (0, 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          s[j] = __builtin_fma(__hiloint2double((int)e_hi[slot][4 + j], (int)e_lo[slot][4 + j]), x[4 + j],
+                               __builtin_fma(__hiloint2double((int)e_hi[slot][j], (int)e_lo[slot][j]), x[j], 0.0));
+        const double t0 = s[0] + s[2], t1 = s[1] + s[3];
+        double u = t0 + t1;
+        u = u + ring_pair_partner(u);
+        if (LOWER) res = KIND == 0 ? (own[slot] - u) : (own[slot] - u) / dg[slot];      // (divisions, as tri_row: same bits)
+        else res = KIND == 0 ? (own[slot] - u) / dg[slot] : own[slot] - u / dg[slot];
+        if (!__any(rowlane && res != res)) break;        // every operand had arrived
+        if ((++tries & 63) == 0 && (*give_up != 0 || tries >= kRingSpinLimit)) { *give_up = 1; break; }
+      }
+    }
+    if (rowlane) {
+      *(lds_double *)(lds + m_slot[slot]) = res;
+      *reinterpret_cast<double *>(reinterpret_cast<char *>(dst) + m_dst[slot]) = res;
     }
   };
-  auto load_b = [&](int slot) { ow[slot] = own_src[rid[slot] > 0 ? rid[slot] : 0]; };   // the row's own value
 #pragma unroll
-  for (int d = 0; d < D; ++d) load_a(d, d);
+  for (int d = 0; d < D; ++d) load_hdr(d, d);
+  // (scheduling barriers: the loop's waits count the loads issued since a stage's records — the prologue has to issue
+  //  them in the loop's order, or the merged count at the loop head is the prologue's and every pass over-waits)
 #pragma unroll
-  for (int d = 0; d < D / 2; ++d) load_b(d);
+  for (int d = 0; d < D; ++d) {
+    __builtin_amdgcn_sched_barrier(0);
+    issue(d);
+    load_hdr(d, D + d);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   __syncthreads();
-  for (int q0 = 0; q0 < R.n_pass; q0 += D) {   // n_pass is a multiple of D
+  int next_barrier = R.epoch, epoch_id = 1;
+  for (int q0 = 0; q0 < R.n_pass; q0 += D) {   // n_pass and epoch are multiples of D
+    if (q0 == next_barrier) {
+      // everything before pass q0 is done by everybody: the slots of the epoch AFTER this one can be set back to NaN
+      // (their old occupants were last read before this barrier — the analysis checked it), and nobody looks at them
+      // before the next barrier
+      __syncthreads();
+      const int2 ra = rearm[epoch_id];
+      for (int k = t; k < ra.y; k += kRingThreads) ring_lds[1 + ((ra.x + k) & (kRingSlots - 1))] = nan_v;
+      next_barrier += R.epoch;
+      ++epoch_id;
+    }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const int q = q0 + d;
-      load_b((d + D / 2) % D);    // the own value of pass q + D / 2, whose record arrived D / 2 passes ago
-      double s = 0.0;
-#pragma unroll
-      for (int e = 0; e < E; ++e) s += vl[d][e] * ring[ps[d][e] & MASK];
-      s = subwave_sum<LPR>(s);
-      if (lane == 0 && rid[d] >= 0) {
-        double x;
-        if (LOWER) x = KIND == 0 ? (ow[d] - s) : (ow[d] - s) / dv[d];      // (divisions, as tri_row: same bits)
-        else x = KIND == 0 ? (ow[d] - s) / dv[d] : ow[d] - s / dv[d];
-        ring[(bs[d] + sub) & MASK] = x;
-        dst[rid[d]] = x;
-      }
-      __syncthreads();
-      load_a(d, q + D);
+      compute(d);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(d);                        // pass q0 + d + D
+      load_hdr(d, q0 + d + 2 * D);
+      __builtin_amdgcn_sched_barrier(0);
     }
+  }
+}
+
+__global__ __launch_bounds__(BLK) void ring_fill_values_kernel(long n, const int *__restrict__ idx, const double *__restrict__ x,
+                                                               char *__restrict__ ent) {
+  for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
+    const double v = idx[i] >= 0 ? x[idx[i]] : 0.0;
+    unsigned *p = reinterpret_cast<unsigned *>(ent + 12 * i);   // (12-byte records: two dword stores)
+    p[0] = (unsigned)__double2loint(v);
+    p[1] = (unsigned)__double2hiint(v);
   }
 }
 
@@ -1510,10 +1599,16 @@ void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const V
 
 void tri_ring(hipStream_t s, const RingHalf &R, int lower, int kind, const double *own, double *dst) {
   if (R.n_pass <= 0) return;
-#define NSK_RING(K, L, W) hipLaunchKernelGGL((tri_ring_kernel<K, L, W>), dim3(1), dim3(kRingThreads), 0, s, R, own, dst)
-  if (lower) { if (kind == 0) NSK_RING(0, true, 8); else NSK_RING(1, true, 8); }
-  else { if (kind == 0) NSK_RING(0, false, 8); else NSK_RING(1, false, 8); }
+#define NSK_RING(K, L) hipLaunchKernelGGL((tri_ring_kernel<K, L>), dim3(1), dim3(kRingThreads), 0, s, R, R.rearm, own, dst)
+  if (lower) { if (kind == 0) NSK_RING(0, true); else NSK_RING(1, true); }
+  else { if (kind == 0) NSK_RING(0, false); else NSK_RING(1, false); }
 #undef NSK_RING
+}
+void ring_fill_values(hipStream_t s, long n, const int *idx, const double *x, char *ent) {
+  if (n <= 0) return;
+  long b = (n + BLK - 1) / BLK;
+  if (b > 4096) b = 4096;
+  hipLaunchKernelGGL(ring_fill_values_kernel, dim3((unsigned)b), dim3(BLK), 0, s, n, idx, x, ent);
 }
 
 void tri_lower_level(hipStream_t s, const TriView &T, int kind, int lpr, const int *rows, int nrows, const double *rhs,

@@ -645,12 +645,15 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       stream_ready = true;
     }
   }
-  // Natural ordering: padded per-pass records for the LDS-ring solve.  A pass = at most kRingRows rows of one level
-  // (independent), positions = the order the passes walk the rows in; an entry names the POSITION of its column's row.
+  // Natural ordering: per-(pass, wavefront) records for the LDS-ring solve (nsk_kernels.h).  A pass = at most kRingRows
+  // rows of one level (independent), sorted by length; positions = the order the passes walk the rows in; an entry names
+  // the ring slot of its column's POSITION.
   ring_ready = false;
-  if (perm.empty() && n >= 4096) {
-    auto build_ring = [&](const std::vector<int> &asap, bool lower, int lpr, Ring &Rg) -> bool {
-      const int kRingRows = kRingThreads / lpr, kRingE = ring_entries(lpr), kRingDepth = ring_depth(lpr);
+  if (perm.empty() && n >= 4096 && n < kRingMaxRows) {
+    struct RingPlan {
+      std::vector<int> pos, order, pass_first;   // position of a row; row at a position; first position of a pass (+ end)
+    };
+    auto plan_ring = [&](const std::vector<int> &asap, bool lower, RingPlan &P) -> bool {
       // Pass order.  The earliest level of a row (asap) can lie far before its consumers' — rows behind the obstacle
       // are ready at once and needed hundreds of levels later — and a value must not wait that long in the ring.  So
       // every row starts as LATE as its consumers allow: t(row) = min over its consumers of t(consumer) - 1, rows
@@ -662,62 +665,118 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
         const int i = lower ? n - 1 - q : q;
         tt[i] = tmin[i] == INT32_MAX ? asap[i] : tmin[i];
         const int kb = lower ? prp[i] : pdiag[i] + 1, ke = lower ? pdiag[i] : prp[i + 1];
+        if (ke - kb > kRingLpr * kRingRegs) return false;
         for (int e = kb; e < ke; ++e) tmin[pcol[e]] = std::min(tmin[pcol[e]], tt[i] - 1);
       }
       int nl = 0;
       for (int i = 0; i < n; ++i) nl = std::max(nl, tt[i] + 1);
       std::vector<int> lp, lr;
       level_lists(tt, nl, lp, lr);
-      std::vector<int> pos((size_t)n), base, rid;
-      int p = 0;
+      auto len = [&](int i) { return lower ? pdiag[i] - prp[i] : prp[i + 1] - pdiag[i] - 1; };
+      P.pos.assign((size_t)n, 0);
+      P.order.clear();
+      P.order.reserve((size_t)n);
+      P.pass_first.clear();
       for (int l = 0; l < nl; ++l)
         for (int b = lp[l]; b < lp[l + 1]; b += kRingRows) {
           const int cnt = std::min(kRingRows, lp[l + 1] - b);
-          base.push_back(p);
-          for (int k = 0; k < kRingRows; ++k) rid.push_back(k < cnt ? lr[b + k] : -1);
-          for (int k = 0; k < cnt; ++k) pos[lr[b + k]] = p + k;
-          p += cnt;
+          P.pass_first.push_back((int)P.order.size());
+          const size_t o = P.order.size();
+          P.order.insert(P.order.end(), lr.begin() + b, lr.begin() + b + cnt);
+          // longest rows first (ties: row order): the lanes that own an entry in register r are then a prefix of a wavefront
+          std::stable_sort(P.order.begin() + o, P.order.end(), [&](int x, int y) { return (len(x) + 1) / 2 > (len(y) + 1) / 2; });
         }
-      // padded to a multiple of kRingDepth passes + kRingDepth empty ones (the kernel loads ahead without branches)
-      const int np_real = (int)base.size();
-      const int np = (np_real + kRingDepth - 1) / kRingDepth * kRingDepth, np_alloc = np + kRingDepth;
-      base.resize((size_t)np_alloc, p);
-      rid.resize((size_t)np_alloc * kRingRows, -1);
-      std::vector<int> ep((size_t)np_alloc * kRingThreads * kRingE, 0), es((size_t)np_alloc * kRingThreads * kRingE, -1),
-          ds((size_t)np_alloc * kRingRows, -1);
+      P.pass_first.push_back((int)P.order.size());
+      for (int p = 0; p < n; ++p) P.pos[P.order[p]] = p;
+      return true;
+    };
+    auto build_ring = [&](const RingPlan &P, const RingPlan &other, bool lower, Ring &Rg) -> bool {
+      const int np_real = (int)P.pass_first.size() - 1;
+      const int np = (np_real + kRingDepth - 1) / kRingDepth * kRingDepth, np_alloc = np + 2 * kRingDepth;
+      auto first_pos = [&](int q) { return P.pass_first[std::min(q, np_real)]; };
+      // longest dependency (in positions), then the epoch: behind the barrier in front of epoch k the slots of epoch
+      // k + 1 are set back to NaN — their old occupants (kRingSlots positions earlier) must have been read for the last
+      // time before epoch k: two epochs + the longest dependency fit the ring
+      int maxback = 0;
       bool ok = true;
-#pragma omp parallel for schedule(static) reduction(&& : ok)
-      for (int q = 0; q < np_real; ++q)
-        for (int k = 0; k < kRingRows; ++k) {
-          const int i = rid[(size_t)q * kRingRows + k];
-          if (i < 0) continue;
-          ds[(size_t)q * kRingRows + k] = pdiag[i];
-          const int kb = lower ? prp[i] : pdiag[i] + 1, ke = lower ? pdiag[i] : prp[i + 1];
-          if (ke - kb > lpr * kRingE) { ok = false; continue; }
-          for (int e = kb; e < ke; ++e) {
-            const int w = e - kb;   // entry w of the row: lane w % lpr, register w / lpr
-            const size_t idx = ((size_t)q * kRingThreads + (size_t)k * lpr + (w % lpr)) * kRingE + (w / lpr);
-            const int back = pos[i] - pos[pcol[e]];
-            if (back <= 0 || back > kRingSlots - 2 * kRingRows) ok = false;
-            ep[idx] = pos[pcol[e]];
-            es[idx] = e;
-          }
+#pragma omp parallel for schedule(static) reduction(max : maxback) reduction(&& : ok)
+      for (int i = 0; i < n; ++i) {
+        const int kb = lower ? prp[i] : pdiag[i] + 1, ke = lower ? pdiag[i] : prp[i + 1];
+        for (int e = kb; e < ke; ++e) {
+          const int back = P.pos[i] - P.pos[pcol[e]];
+          if (back <= 0) ok = false;
+          maxback = std::max(maxback, back);
         }
+      }
       if (!ok) return false;
+      int epoch = 0;
+      for (int B = kRingMaxEpoch; B >= kRingDepth && !epoch; B -= kRingDepth) {
+        bool fits = true;
+        for (int q = 0; q < np && fits; q += B) fits = first_pos(q + 2 * B) - first_pos(q) + maxback <= kRingSlots;
+        if (fits) epoch = B;
+      }
+      if (!epoch) return false;
+      std::vector<int2> rearm((size_t)np / epoch + 2, make_int2(0, 0));
+      for (int k = 1; k * epoch < np; ++k) rearm[k] = make_int2(first_pos((k + 1) * epoch), first_pos((k + 2) * epoch) - first_pos((k + 1) * epoch));
+      auto slot_off = [](int p) { return (unsigned)(8 + 8 * (p & (kRingSlots - 1))); };
+      // headers and entries
+      std::vector<uint4> hdr((size_t)np_alloc * kRingWaves, make_uint4(0, 0, 0, 0));
+      std::vector<int> es;
+      std::vector<unsigned> eo;
+      es.reserve((size_t)(lower ? nnz / 2 : nnz / 2) + (size_t)n);
+      eo.reserve(es.capacity());
+      for (int q = 0; q < np_real; ++q) {
+        const int p0 = P.pass_first[q], p1 = P.pass_first[q + 1];
+        for (int w = 0; w < kRingWaves; ++w) {
+          const int r0 = std::min(p1, p0 + w * kRingRowsPerWave), r1 = std::min(p1, r0 + kRingRowsPerWave);
+          unsigned nl[kRingRegs] = {0, 0, 0, 0, 0, 0, 0, 0};
+          const unsigned ebase = (unsigned)es.size();
+          for (int r = 0; r < kRingRegs; ++r)
+            for (int p = r0; p < r1; ++p) {
+              const int i = P.order[p];
+              const int kb = lower ? prp[i] : pdiag[i] + 1, ke = lower ? pdiag[i] : prp[i + 1];
+              if (ke - kb <= kRingLpr * r) break;   // (sorted: the rows behind are no longer)
+              nl[r] += kRingLpr;
+              for (int l = 0; l < kRingLpr; ++l) {
+                const int e = kb + kRingLpr * r + l;   // entry 2 r + l of the row: walker lane (2 r + l) % 8
+                if (e < ke) { es.push_back(e); eo.push_back(slot_off(P.pos[pcol[e]])); }
+                else { es.push_back(-1); eo.push_back(0u); }   // (an odd row's last lane: 0.0 times LDS word 0 = 0.0)
+              }
+            }
+          hdr[(size_t)q * kRingWaves + w] =
+              make_uint4(ebase, (unsigned)r0 | (unsigned)(r1 - r0) << 26, nl[0] | nl[1] << 8 | nl[2] << 16 | nl[3] << 24,
+                         nl[4] | nl[5] << 8 | nl[6] << 16 | nl[7] << 24);
+        }
+      }
+      if (es.size() >= (size_t)UINT32_MAX) return false;
+      std::vector<char> ent(es.size() * 12 + 16, 0);
+      for (size_t k = 0; k < es.size(); ++k) memcpy(&ent[k * 12 + 8], &eo[k], 4);
+      std::vector<int> ds((size_t)n);
+      std::vector<uint2> meta((size_t)n);
+      for (int p = 0; p < n; ++p) {
+        const int i = P.order[p];
+        ds[p] = pdiag[i];
+        // the lower half hands its result to the upper half in THAT half's position order, the upper half writes the caller's
+        meta[p] = make_uint2(8u * (unsigned)(lower ? other.pos[i] : i), slot_off(p));
+      }
       Rg.n_pass = np;
-      Rg.lpr = lpr;
-      Rg.pass_base.upload(base, s);
-      Rg.rowid.upload(rid, s);
-      Rg.dsrc.upload(ds, s);
-      Rg.epos.upload(ep, s);
+      Rg.epoch = epoch;
+      Rg.n_ent = (long)es.size();
+      Rg.hdr.upload(hdr, s);
+      Rg.ent.upload(ent, s);
       Rg.esrc.upload(es, s);
-      Rg.rdiag.alloc(ds.size());
-      Rg.eval.alloc(es.size());
+      Rg.dsrc.upload(ds, s);
+      Rg.rowid.upload(P.order, s);
+      Rg.meta.upload(meta, s);
+      Rg.rearm.upload(rearm, s);
+      Rg.rdiag.alloc((size_t)n);
+      Rg.own.alloc((size_t)n);
       ctx->sync();
       return true;
     };
-    const int lpr_ring = 8;
-    ring_ready = build_ring(levL, true, lpr_ring, ringL) && build_ring(levU, false, lpr_ring, ringU);
+    RingPlan PL, PU;
+    ring_ready = plan_ring(levL, true, PL) && plan_ring(levU, false, PU) && build_ring(PL, PU, true, ringL) &&
+                 build_ring(PU, PL, false, ringU);
   }
   rowptr.upload(prp, s);
   col.upload(pcol, s);
@@ -769,8 +828,8 @@ void TriSolve::numeric(const double *a_val_dev) {
   }
   if (ring_ready)
     for (Ring *Rg : {&ringL, &ringU}) {
-      vec_gather_or_zero(s, (long)Rg->eval.n, Rg->esrc.p, val.p, Rg->eval.p);
-      vec_gather_or_zero(s, (long)Rg->rdiag.n, Rg->dsrc.p, val.p, Rg->rdiag.p);   // (padding slots: 0, never used)
+      ring_fill_values(s, Rg->n_ent, Rg->esrc.p, val.p, Rg->ent.p);
+      vec_gather(s, n, Rg->dsrc.p, val.p, Rg->rdiag.p);
     }
 }
 
@@ -840,8 +899,9 @@ void TriSolve::apply(const double *b, double *x) {
     return;
   }
   if (ring_ready && use_stream && !tiny) {   // the caller's order: one workgroup, passes through an LDS ring
-    tri_ring(s, ringL.view(), 1, kind, b, y.p);
-    tri_ring(s, ringU.view(), 0, kind, y.p, x);
+    vec_gather(s, n, ringL.rowid.p, b, ringL.own.p);              // the right-hand side in the lower half's position order
+    tri_ring(s, ringL.view(), 1, kind, ringL.own.p, ringU.own.p);   // (its result lands in the upper half's order)
+    tri_ring(s, ringU.view(), 0, kind, ringU.own.p, x);
     ++ctx->st.ring_applies;
     ++ctx->st.tri_applies;
     ctx->st.tri_bytes += (double)apply_bytes();

@@ -88,10 +88,16 @@ struct TriSolve {
 
   // natural ordering: the LDS-ring solve (nsk_kernels.h: tri_ring) when the factor qualifies
   struct Ring {
-    int n_pass = 0, lpr = 8;
-    DBuf<int> pass_base, rowid, dsrc, epos, esrc;
-    DBuf<double> rdiag, eval;
-    RingHalf view() const { return RingHalf{n_pass, lpr, pass_base.p, rowid.p, rdiag.p, epos.p, eval.p}; }
+    int n_pass = 0, epoch = 0;
+    long n_ent = 0;
+    DBuf<uint4> hdr;
+    DBuf<char> ent;            // 12-byte entries
+    DBuf<int> esrc, dsrc;      // where an entry's value / a position's diagonal sits in the factor (-1: padding)
+    DBuf<int> rowid;           // [positions] the row at that position (gathers the right-hand side into position order)
+    DBuf<double> rdiag, own;   // [positions]
+    DBuf<uint2> meta;
+    DBuf<int2> rearm;
+    RingHalf view() const { return RingHalf{n_pass, epoch, hdr.p, ent.p, rdiag.p, meta.p, rearm.p}; }
   } ringL, ringU;
   bool ring_ready = false;
 

@@ -159,7 +159,8 @@ def test_line_group_sizes_in_the_single_launch_solves(group_u, group_p, subdomai
         ls.close()
 
 
-@pytest.mark.parametrize("mesh,subdomains", [((60, 20), 1), ((60, 20), 3), ((100, 70), 1)])
+# (24 x 400: levels of 267 rows, more than one pass holds — and 49 k rows, six times round the ring)
+@pytest.mark.parametrize("mesh,subdomains", [((60, 20), 1), ((60, 20), 3), ((100, 70), 1), ((24, 400), 1)])
 def test_natural_order_pressure_solves_through_the_lds_ring(mesh, subdomains):
     """The caller's order in the pressure-mass factor (default of the unsteady block-diagonal preconditioner; any factor
     under NSK_OPT_TRI_ORDERING = 0 with at most 16 entries per row and half): one workgroup walks passes of independent
