@@ -98,13 +98,21 @@ enum {
                                  17 instead of 29-31 for the Schur complement on the reference's lattices) at the same or
                                  lower inner iteration counts; still ILU(0)/SGS of a symmetrically permuted matrix
                                  (nsk_tri_get_perm).  0: colour the DoFs one by one */
-  NSK_OPT_MASS_ORDERING = 13   /* ordering of the pressure-mass factor alone: 0 the caller's order, 1 multicolour, -1 (default)
+  NSK_OPT_MASS_ORDERING = 13,  /* ordering of the pressure-mass factor alone: 0 the caller's order, 1 multicolour, -1 (default)
                                  the caller's order in the UNSTEADY block-diagonal preconditioner and NSK_OPT_TRI_ORDERING
                                  everywhere else.  There the pressure block is about ONE ILU(M_p)-preconditioned CG step
                                  (absolute tolerance 1e-1, NSSolver.hpp:155-176) and whether restarted FGMRES converges hangs
                                  on the quality of that one application: the caller's order reproduces
                                  the factor one MPI rank of the reference builds (same iteration counts as the CPU
                                  restatement: 241 / 403 at 100x70), at O(nx + ny) dependent levels per application */
+  NSK_OPT_SCHUR_SIGN = 14      /* +1 (default): aSIMPLE's S = B~ D^-1 B~^T exactly as the reference forms it
+                                 (NSSolverStationary.hpp:275, NSSolver.hpp:288).  -1: S = -B~ D^-1 B~^T, the Schur-complement
+                                 approximation SIMPLE is derived with for J = [[F, B~^T], [B~, 0]] — a LABELLED DEVIATION from
+                                 the reference, off by default: with the reference's sign the pressure correction comes out
+                                 negated, the preconditioned operator has eigenvalues near +1 (velocity) and near -alpha
+                                 (pressure), and restarted FGMRES(30) crawls on the indefinite spectrum (3 062
+                                 against 580 outer iterations to 1e-10 at 60x20 in the CPU restatement).  Every parity test,
+                                 the drivers and the bench headline keep +1 */
 };
 
 typedef struct {

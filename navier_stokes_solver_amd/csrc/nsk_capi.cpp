@@ -129,6 +129,7 @@ struct nsk_handle_s {
   TriSolve tF, tMp, tS;
   Amg amgF;                 // velocity AMG of the stationary block-triangular preconditioner
   int velocity_amg = 1;     // NSK_OPT_VELOCITY_AMG
+  int schur_sign = 1;       // NSK_OPT_SCHUR_SIGN: +1 the reference's S = B D^-1 Bt, -1 the negated (SIMPLE's) one
   bool amg_active = false;  // the current setup preconditions F with amgF instead of tF
   // The hierarchy is built on first use: PreconditionAMG::initialize is called before every solve (NSSolverStationary.hpp:231),
   // also before the many solves of a Newton run that stop at step 0 without ever applying the preconditioner; building it
@@ -458,6 +459,7 @@ void H::setup(int type, int variant_, double alpha_) {
     Csr &S = blk[NSK_BLK_S], &B = blk[NSK_BLK_B], &Bt = blk[NSK_BLK_BT], &Btg = blk[NSK_BLK_BT_GHOST];
     spgemm_bdbt_numeric(s(), B.view(), Dinv, Dinv + n_u(), Bt.view(), Btg.present ? Btg.view() : Bt.view(), S.rowptr.p,
                         S.col.p, S.val.p, S.n_rows, std::max(1, s_max_row));
+    if (schur_sign < 0) vec_scale(s(), (int)S.nnz, sref(-1.0), S.val.p);   // opt-in deviation (nsk.h: NSK_OPT_SCHUR_SIGN)
     if (!tS_ok || tS_key != key) {
       Phase ph("analyse S factor (host)");
       tS.analyze(&ctx, S, 0, tri_ordering, sub_offsets(1), false, xy(1), group_p);
@@ -703,6 +705,86 @@ int nsk_debug_tri_ordering(int n, const int32_t *rowptr, const int32_t *col, int
   }
 }
 
+// Test hooks of nsk_internal.h: set-up kernels on positions shifted by `base`
+extern "C++" {
+namespace {
+std::vector<int> shifted(const int32_t *p, size_t n, int64_t base) {
+  std::vector<int> v(n);
+  for (size_t i = 0; i < n; ++i) {
+    const int64_t q = (int64_t)p[i] + base;
+    if (q < 0 || q > INT32_MAX) throw Error(-62, "position beyond int32");
+    v[i] = (int)q;
+  }
+  return v;
+}
+DBuf<int> on_device(const int *h, size_t n) {
+  DBuf<int> d;
+  d.upload(h, n, nullptr);
+  return d;
+}
+DBuf<double> on_device(const double *h, size_t n) {
+  DBuf<double> d;
+  d.upload(h, n, nullptr);
+  return d;
+}
+}  // namespace
+}  // extern "C++"
+
+int nsk_debug_ilu0_at_offset(int what, int n, const int32_t *rowptr, const int32_t *col, double *val_inout, int64_t base) {
+  try {
+    const int nnz = rowptr[n];
+    std::vector<int> diag((size_t)n, -1), rows((size_t)n), lvl((size_t)n + 1);
+    int max_row = 1;
+    for (int i = 0; i < n; ++i) {
+      rows[i] = i;
+      lvl[i] = i;
+      max_row = std::max(max_row, rowptr[i + 1] - rowptr[i]);
+      for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) if (col[k] == i) diag[i] = k;
+      if (diag[i] < 0) throw Error(-62, "row without a diagonal");
+    }
+    lvl[n] = n;
+    const std::vector<int> rp = shifted(rowptr, (size_t)n + 1, base), dg = shifted(diag.data(), (size_t)n, base);
+    DBuf<int> d_rp = on_device(rp.data(), rp.size()), d_dg = on_device(dg.data(), dg.size()), d_col = on_device(col, (size_t)nnz),
+              d_rows = on_device(rows.data(), rows.size()), d_lvl = on_device(lvl.data(), lvl.size());
+    DBuf<double> d_val = on_device(val_inout, (size_t)nnz);
+    NSK_HIP(hipDeviceSynchronize());
+    const int *colb = d_col.p - base;   // entry `base + k` of these is entry k of the arrays that exist
+    double *valb = d_val.p - base;
+    if (what == 0)
+      for (int i = 0; i < n; ++i) ilu0_factor_level(nullptr, 1, d_rows.p + i, d_rp.p, d_dg.p, colb, valb, max_row);
+    else
+      ilu0_factor_serial(nullptr, d_lvl.p, d_rows.p, 0, n, d_rp.p, d_dg.p, colb, valb, max_row);
+    NSK_HIP(hipMemcpy(val_inout, d_val.p, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost));
+    return 0;
+  } catch (const std::exception &) {
+    return -1;
+  }
+}
+
+int nsk_debug_schur_at_offset(int n_p, int n_u, const int32_t *b_rp, const int32_t *b_col, const double *b_val,
+                              const double *dinv, const int32_t *bt_rp, const int32_t *bt_col, const double *bt_val,
+                              const int32_t *s_rp, const int32_t *s_col, double *s_val_out, int64_t base) {
+  try {
+    const int nb = b_rp[n_p], nbt = bt_rp[n_u], ns = s_rp[n_p];
+    int max_row = 1;
+    for (int i = 0; i < n_p; ++i) max_row = std::max(max_row, s_rp[i + 1] - s_rp[i]);
+    const std::vector<int> brp = shifted(b_rp, (size_t)n_p + 1, base), btrp = shifted(bt_rp, (size_t)n_u + 1, base),
+                           srp = shifted(s_rp, (size_t)n_p + 1, base);
+    DBuf<int> d_brp = on_device(brp.data(), brp.size()), d_btrp = on_device(btrp.data(), btrp.size()),
+              d_srp = on_device(srp.data(), srp.size()), d_bcol = on_device(b_col, (size_t)nb),
+              d_btcol = on_device(bt_col, (size_t)nbt), d_scol = on_device(s_col, (size_t)ns);
+    DBuf<double> d_bval = on_device(b_val, (size_t)nb), d_btval = on_device(bt_val, (size_t)nbt), d_dinv = on_device(dinv, (size_t)n_u), d_sval;
+    d_sval.alloc((size_t)ns);
+    NSK_HIP(hipDeviceSynchronize());
+    const CsrView B{n_p, n_u, d_brp.p, d_bcol.p - base, d_bval.p - base}, Bt{n_u, n_p, d_btrp.p, d_btcol.p - base, d_btval.p - base};
+    spgemm_bdbt_numeric(nullptr, B, d_dinv.p, nullptr, Bt, Bt, d_srp.p, d_scol.p - base, d_sval.p - base, n_p, max_row);
+    NSK_HIP(hipMemcpy(s_val_out, d_sval.p, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost));
+    return 0;
+  } catch (const std::exception &) {
+    return -1;
+  }
+}
+
 int nsk_local_group_id_mode(int nranks, int on_stream, void *out128) {   // nsk_internal.h
   if (nranks < 1 || !out128) return -1;
   make_local_group(nranks, out128, on_stream);
@@ -888,6 +970,10 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
     case NSK_IOPT_TINY_BYTES: h->tF.tiny_bytes = h->tMp.tiny_bytes = h->tS.tiny_bytes = v; break;
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
     case NSK_OPT_VELOCITY_AMG: h->velocity_amg = v != 0.0; break;
+    case NSK_OPT_SCHUR_SIGN:
+      if (v != 1.0 && v != -1.0) throw Error(-61, "NSK_OPT_SCHUR_SIGN: +1 or -1");
+      h->schur_sign = (int)v;
+      break;
     case NSK_IOPT_TRI_X_LAYOUT:
       h->x_layout_mode = v == 0.0 ? 0 : 2;
       h->tF_ok = false;

@@ -42,6 +42,17 @@ int nsk_local_group_id_mode(int nranks, int on_stream, void *out128);
 int nsk_debug_tri_ordering(int n, const int32_t *rowptr, const int32_t *col, int n_sub, const int32_t *sub_off,
                            int want_block2, const double *xy, int group, int32_t *perm_out, int32_t *info4,
                            uint8_t *chain_out);
+/* Test hooks for the 32-bit POSITION arithmetic of the set-up kernels (a rank's share of 4800x1600 on four GPUs holds
+ * 1.67 G non-zeros in F: positions pass 2^30, where `(lo + hi) >> 1` overflowed in round 3).  The kernels run on a small
+ * matrix whose positions — row pointers, diagonal positions — are shifted by `base`, through array base pointers moved
+ * back by `base` entries: the index arithmetic of a factor with > 2^30 non-zeros without the 13 GB.  Device 0, stream 0.
+ * what = 0: ilu0_factor_level, one launch per row; 1: ilu0_factor_serial (one workgroup walks the rows).  val_inout: the
+ * matrix values in, the ILU(0) factor out (rows are factorised in index order). */
+int nsk_debug_ilu0_at_offset(int what, int n, const int32_t *rowptr, const int32_t *col, double *val_inout, int64_t base);
+/* S = B diag(dinv) Bt on the given structural pattern (spgemm_bdbt_numeric), all three matrices' positions shifted. */
+int nsk_debug_schur_at_offset(int n_p, int n_u, const int32_t *b_rp, const int32_t *b_col, const double *b_val,
+                              const double *dinv, const int32_t *bt_rp, const int32_t *bt_col, const double *bt_val,
+                              const int32_t *s_rp, const int32_t *s_col, double *s_val_out, int64_t base);
 #ifdef __cplusplus
 }
 #endif

@@ -656,6 +656,7 @@ static void prec_setup(prec_t *pc, const orc_problem *P, const orc_opts *o, orc_
     pc->s_col = (int *)malloc(sizeof(int) * (size_t)nnz);
     pc->s_val = (double *)malloc(sizeof(double) * (size_t)nnz);
     orc_spgemm_adb(&P->B, pc->Dinv, &P->Bt, pc->s_rowptr, pc->s_col, pc->s_val);
+    if (o->schur_sign < 0) for (int k = 0; k < nnz; ++k) pc->s_val[k] = -pc->s_val[k]; /* study only: see nsk_oracle.h */
     pc->S.n_rows = np; pc->S.n_cols = np; pc->S.rowptr = pc->s_rowptr; pc->S.col = pc->s_col; pc->S.val = pc->s_val;
     pc->tF = orc_tri_setup(&P->F, 0, P->n_shards, P->u_shard_off, P->perm_F);
     pc->tP = orc_tri_setup(&pc->S, 0, P->n_shards, P->p_shard_off, P->perm_S);

@@ -91,6 +91,8 @@ typedef struct {
   double alpha;   /* aSIMPLE damping, 0.5 */
   int velocity_amg; /* stationary blockTriangular: 1 = AMG V-cycle for F (what the reference configures),
                        0 = ILU(0) (what the unsteady variant uses) */
+  int schur_sign;   /* 0 / +1: aSIMPLE's S = B D^-1 Bt as the reference forms it (NSSolverStationary.hpp:275); -1: STUDY ONLY,
+                       S negated = the Schur approximation SIMPLE is derived with (tests/studies/oracle_study_asimple_sign.py) */
 } orc_opts;
 
 typedef struct {

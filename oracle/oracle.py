@@ -28,7 +28,7 @@ class Problem(C.Structure):
 
 class Opts(C.Structure):
     _fields_ = [("solver", C.c_int), ("prec", C.c_int), ("variant", C.c_int), ("max_iter", C.c_int),
-                ("tol", C.c_double), ("alpha", C.c_double), ("velocity_amg", C.c_int)]
+                ("tol", C.c_double), ("alpha", C.c_double), ("velocity_amg", C.c_int), ("schur_sign", C.c_int)]
 
 
 class Result(C.Structure):
@@ -213,10 +213,11 @@ class OracleProblem:
         return cls(CsrHolder.from_block(pr.F), CsrHolder.from_block(pr.Bt), CsrHolder.from_block(pr.B),
                    CsrHolder.from_block(pr.Mp), **kw)
 
-    def solve(self, rhs, x0, solver=1, prec=0, variant=0, tol=1e-6, max_iter=None, alpha=0.5, velocity_amg=0, history=0):
+    def solve(self, rhs, x0, solver=1, prec=0, variant=0, tol=1e-6, max_iter=None, alpha=0.5, velocity_amg=0, history=0,
+              schur_sign=1):
         if max_iter is None:
             max_iter = 20000 if variant == 0 else 100000  # NSSolverStationary.cpp:580 / NSSolver.cpp:604
-        o = Opts(solver, prec, variant, max_iter, tol, alpha, velocity_amg)
+        o = Opts(solver, prec, variant, max_iter, tol, alpha, velocity_amg, schur_sign)
         r = Result()
         x = _f64(x0).copy()
         rhs = _f64(rhs)
@@ -233,8 +234,8 @@ class OracleProblem:
                 lib().orc_set_history(None, 0)
         return x, info
 
-    def prec_apply(self, src, dst0=None, prec=2, variant=0, alpha=0.5, calls=1, velocity_amg=0):
-        o = Opts(1, prec, variant, 0, 0.0, alpha, velocity_amg)
+    def prec_apply(self, src, dst0=None, prec=2, variant=0, alpha=0.5, calls=1, velocity_amg=0, schur_sign=1):
+        o = Opts(1, prec, variant, 0, 0.0, alpha, velocity_amg, schur_sign)
         src = _f64(src)
         dst = np.zeros(self.n_u + self.n_p) if dst0 is None else _f64(dst0).copy()
         rc = lib().orc_prec_apply(C.byref(self.c), C.byref(o), src.ctypes.data, dst.ctypes.data, calls)

@@ -393,6 +393,40 @@ def test_first_restart_cycle_matches_oracle(handles, prec, solver):
     assert np.abs(hg[:n] - ho[:n]).max() <= 1e-8 * np.abs(ho[:n]).max(), np.abs(hg[:n] / ho[:n] - 1).max()
 
 
+@pytest.mark.parametrize("prec", [0, 1, 2])
+@pytest.mark.parametrize("solver", [0, 1, 2])
+def test_first_cycle_of_all_nine_stationary_pairs_matches_oracle(handles, prec, solver):
+    """solve_system() of the stationary driver dispatches 3 solvers x 3 preconditioners (NSSolverStationary.cpp:588-638);
+    the converged-solve cases above only run FGMRES with them.  Here every pair does its first restart cycle (GMRES: 28
+    steps, FGMRES: 29, BiCGStab: 6 steps = 12 residuals) on the Newton system ns16 and the residuals SolverControl sees
+    are compared with the oracle's.  The stationary preconditioners run inner Krylov solves to a RELATIVE 1e-1 / 1e-2
+    (NSSolverStationary.hpp:132-153,189-218,285-298) and keep state between applications (aSIMPLE's stale delta_p,
+    FGMRES's z_j): GMRES and BiCGStab call them as if they were fixed linear operators, exactly as the reference does."""
+    S, O = _S(), _O()
+    pr = problem("ns16")
+    ls = handles("ns16", 1)
+    ls.setup_preconditioner(prec, S.STATIONARY, 0.5)
+    op = O.OracleProblem.from_local(pr, perm_F=ls.tri_perm(S.TRI_VELOCITY),
+                                    **{"perm_S" if prec == 2 else "perm_Mp": ls.tri_perm(S.TRI_PRESSURE)})
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    steps = {0: 28, 1: 29, 2: 6}[solver]
+    ls.setup_preconditioner(prec, S.STATIONARY, 0.5)
+    xu, xp, its, res, rc = ls.solve(solver, 0.0, steps, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+    hg = ls.history()
+    xo, info = op.solve(b, np.concatenate([pr.x0_u, pr.x0_p]), solver=solver, prec=prec, variant=0, tol=0.0, max_iter=steps,
+                        history=64, velocity_amg=int(prec == 1))
+    ho = info["history"]
+    n = min(len(hg), len(ho))
+    dev = np.abs(hg[:n] - ho[:n]).max() / np.abs(ho[:n]).max()
+    print(f"solver {solver} prec {prec}: {len(hg)} / {len(ho)} residuals, largest deviation {dev:.2e}, "
+          f"x: {rel_err(np.concatenate([xu, xp]), xo):.2e}, iterations {its} / {info['iters']}")
+    assert its == info["iters"] == steps and len(hg) == len(ho) and n >= steps
+    # the inner solves stop at the same step on both sides (relative tolerances, far from rounding), so the histories
+    # agree to what the inner recurrences amplify: 1e-8 for the Arnoldi solvers, 1e-6 for BiCGStab's 12 values
+    assert dev <= (1e-6 if solver == 2 else 1e-8), dev
+    assert rel_err(np.concatenate([xu, xp]), xo) <= (1e-5 if solver == 2 else 1e-7)
+
+
 def test_vector_ops_directly(handles):
     """a4: the BLAS-1 family of TrilinosWrappers::MPI::Vector as the library runs it (sadd, scale, add, equ, *=,
     add_and_dot ...), element-wise against NumPy (one multiply-add per entry: 1e-15), through nsk_vec_op."""
