@@ -87,8 +87,11 @@ def parse():
                     help="NSK_OPT_TRI_LINE_GROUPS: 1 colour pairs of velocity nodes / triples of pressure DoFs along the lattice "
                          "lines in the triangular factors' orderings (fewer colours), 0 colour single DoFs, 2 (default) by size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-mesh", type=str, default="300,100")
-    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-mesh", type=str, default="",
+                    help="mesh of the CPU baseline's first sample; default: the bench mesh itself (1200,400 at N = 1)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="outer iterations of the CPU baseline's first sample")
+    ap.add_argument("--cpu-mesh2", type=str, default="300,100", help="second, smaller CPU sample ('' = none)")
+    ap.add_argument("--cpu-steps2", type=int, default=12)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--converge", type=float, default=0.0, help="if > 0: also one full solve to this tolerance (see --converge-*)")
     ap.add_argument("--converge-mesh", type=str, default="300,100")
@@ -165,7 +168,7 @@ def timed_steps(ls, pr, solver, prec, variant, steps, warmup, barrier, sync):
     return its, res, rc, time.perf_counter() - t0
 
 
-def cpu_baseline(args, nu):
+def cpu_baseline(args, nu, mesh, steps):
     """Oracle (CPU restatement of the reference path, kind 'port') on a bounded sample of the same workload: same
     solver / preconditioner / Reynolds number on a smaller mesh, a few outer iterations, run the way the reference runs
     on a node: one emulated MPI rank per host core (x-strip shards, block-Jacobi ILU(0) = Ifpack overlap 0), OpenMP
@@ -173,7 +176,8 @@ def cpu_baseline(args, nu):
     import numpy as np
     from navier_stokes_solver_amd import problem as P
     from oracle import oracle as O
-    nx, ny = (int(v) for v in args.cpu_mesh.split(","))
+    nx, ny = (int(v) for v in mesh.split(","))
+    say(f"CPU baseline: oracle on {nx}x{ny}, {steps} outer iterations")
     from navier_stokes_solver_amd._threads import cpu_budget
     cores = max(1, min(args.cpu_threads or min(cpu_budget(), 16), nx // 4))   # a one-GPU box's CPU share is 16 cores
     pr = P.generate(nx, ny, nu=nu, mode=1, state=1)
@@ -186,7 +190,7 @@ def cpu_baseline(args, nu):
         x0 = np.concatenate([pr.x0_u, pr.x0_p])
         t0 = time.time()
         _, info = op.solve(b, x0, solver=args.solver, prec=args.preconditioner, variant=args.variant, tol=0.0,
-                           max_iter=args.cpu_steps)
+                           max_iter=steps)
         wall = time.time() - t0
     finally:
         O.set_threads(1)
@@ -340,24 +344,39 @@ def main():
     dev_bytes = int(total_b - free_b)
     assert its == args.steps, (its, args.steps)
     n_u_local, n_p_local, nnz_F_local = pr.n_u, pr.n_p, pr.F.nnz
+
+    # ---- like-for-like pairs of the CPU baseline: the same K iterations on the CPU samples' meshes, on the GPU
+    def gpu_pair(lsx, prx, nx_, ny_, K):
+        i2, r2, _, dt2 = timed_steps(lsx, prx, args.solver, args.preconditioner, args.variant, K, 2, lambda: None, sync)
+        st2 = lsx.stats()
+        return {"value": prx.n * i2 / dt2, "unit": "DoF*iters/s", "mesh": f"{nx_}x{ny_}", "K": i2,
+                "ms_per_step": 1e3 * dt2 / max(1, i2),
+                "inner_F_its_per_step": st2["inner_u_its"] / max(1, st2["prec_applies"]),
+                "inner_S_its_per_step": st2["inner_p_its"] / max(1, st2["prec_applies"]),
+                "dof_inner_iters_per_s": (prx.n_u * st2["inner_u_its"] + prx.n_p * st2["inner_p_its"]) / dt2,
+                "ordering": ["natural", "multicolour"][args.ordering], "shards": args.subdomains}
+
+    cpu_samples = []     # (mesh string, K, GPU pair)
+    if world == 1 and not args.no_cpu_baseline:
+        m1 = args.cpu_mesh or f"{nx},{ny}"
+        for mesh_s, K in ((m1, args.cpu_steps), (args.cpu_mesh2, args.cpu_steps2)):
+            if not mesh_s or K <= 0 or any(mesh_s == c[0] for c in cpu_samples):
+                continue
+            cx, cy = (int(v) for v in mesh_s.split(","))
+            if (cx, cy) == (nx, ny) and args.lx == 2.2:
+                say(f"GPU pair of the CPU sample on the bench mesh: the first {K} outer iterations")
+                cpu_samples.append((mesh_s, K, gpu_pair(ls, pr, cx, cy, K)))
     ls.close()
     del pr
-
-    # ---- like-for-like pair of the CPU baseline: the same K iterations on the CPU baseline's mesh, on the GPU
-    gpu_same = None
     if world == 1 and not args.no_cpu_baseline:
-        cx, cy = (int(v) for v in args.cpu_mesh.split(","))
-        ls2, pr2, n2, _, _ = make_solver(S, PT, P, dist, args, cx, cy, nu, inv_dt, 1, 0, local_rank)
-        i2, r2, _, dt2 = timed_steps(ls2, pr2, args.solver, args.preconditioner, args.variant, args.cpu_steps, 2,
-                                     lambda: None, sync)
-        st2 = ls2.stats()
-        gpu_same = {"value": n2 * i2 / dt2, "unit": "DoF*iters/s", "mesh": f"{cx}x{cy}", "K": i2,
-                    "ms_per_step": 1e3 * dt2 / max(1, i2),
-                    "inner_F_its_per_step": st2["inner_u_its"] / max(1, st2["prec_applies"]),
-                    "inner_S_its_per_step": st2["inner_p_its"] / max(1, st2["prec_applies"]),
-                    "dof_inner_iters_per_s": (pr2.n_u * st2["inner_u_its"] + pr2.n_p * st2["inner_p_its"]) / dt2,
-                    "ordering": ["natural", "multicolour"][args.ordering], "shards": args.subdomains}
-        ls2.close()
+        for mesh_s, K in ((m1, args.cpu_steps), (args.cpu_mesh2, args.cpu_steps2)):
+            if not mesh_s or K <= 0 or any(mesh_s == c[0] for c in cpu_samples):
+                continue
+            cx, cy = (int(v) for v in mesh_s.split(","))
+            ls2, pr2, n2, _, _ = make_solver(S, PT, P, dist, args, cx, cy, nu, inv_dt, 1, 0, local_rank)
+            cpu_samples.append((mesh_s, K, gpu_pair(ls2, pr2, cx, cy, K)))
+            ls2.close()
+            del pr2
 
     conv = None
     if args.converge > 0:
@@ -455,12 +474,19 @@ def main():
         if conv:
             out["converged_solve"] = conv
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args, nu)
-            cb["gpu_same_mesh"] = gpu_same    # the like-for-like pair: same mesh, same K, same inner work per iteration
-            if gpu_same:
-                cb["gpu_over_cpu_same_mesh"] = gpu_same["value"] / cb["value"]
-                cb["gpu_over_cpu_inner_work"] = gpu_same["dof_inner_iters_per_s"] / cb["dof_inner_iters_per_s"]
-            out["cpu_baseline"] = cb
+            # first sample: the bench mesh itself (a few outer iterations: the oracle needs tens of seconds for one at
+            # 1200x400); second sample: a mesh the oracle does a dozen iterations on
+            cbs = []
+            for mesh_s, K, pair in cpu_samples:
+                cb = cpu_baseline(args, nu, mesh_s, K)
+                cb["gpu_same_mesh"] = pair    # the like-for-like pair: same mesh, same K
+                cb["gpu_over_cpu_same_mesh"] = pair["value"] / cb["value"]
+                cb["gpu_over_cpu_inner_work"] = pair["dof_inner_iters_per_s"] / cb["dof_inner_iters_per_s"]
+                cbs.append(cb)
+            if cbs:
+                out["cpu_baseline"] = cbs[0]
+                if len(cbs) > 1:
+                    out["cpu_baseline"]["second_sample"] = cbs[1]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -25,7 +25,7 @@
  * the reference would throw SolverControl::NoConvergence); 2 BiCGStab breakdown
  * restarts exhausted; 3 an inner (preconditioner) solver did not converge;
  * < 0 usage / HIP / RCCL error, text via nsk_last_error():
- *   -10..-11 HIP runtime / out of device scalar slots      -20..-24 RCCL / in-process group transport
+ *   -10..-11 HIP runtime / out of device scalar slots      -20..-25 RCCL / in-process group transport (-25: a peer of the in-process group failed or left)
  *   -30..-32 triangular-solve analysis (missing diagonal, row too long)
  *   -40..-47 missing blocks, bad preconditioner / solver type, call order
  *   -50..-59 bad arguments of the hand-off calls           -60..-66 device assembly / Newton state
@@ -276,6 +276,12 @@ int nsk_get_history(nsk_handle h, double *out, int cap);
 /* End the outer solve running on this handle at its next SolverControl check (status 1, iters/final_res valid).
  * The only entry point that may be called from another thread while a solve is in progress. */
 int nsk_cancel(nsk_handle h);
+/* In-process test transport (nsk_local_group_id) only: take this handle's group down.  Every rank blocked in a
+ * collective of the group, and every later collective, returns -25.  The library does this by itself when a rank fails
+ * inside nsk_setup_preconditioner / nsk_solve / nsk_solve_resident / nsk_assemble / nsk_precond_vmult or is destroyed;
+ * the caller does it when a rank fails on ITS side between two calls (so that the peers' threads can be joined).  No-op
+ * on RCCL handles.  Callable from any thread. */
+int nsk_abort_group(nsk_handle h);
 int nsk_reset_stats(nsk_handle h);
 
 /* Device-side timing of one operation repeated `reps` times between HIP events on the

@@ -295,18 +295,27 @@ def run_ranks(cfg, unsteady: bool, nranks: int) -> int:
                 f"{'the time loop' if unsteady else 'solve_newton'} -> {(n_u + n_p) * its / max(dt, 1e-12):.4g} DoF*iters/s")
         except Exception as e:  # noqa: BLE001
             errs.append((r, repr(e)))
+            # a rank that fails on its own must not leave the others waiting: the Python rendezvous AND the library's
+            # collectives (the peers may be inside nsk_solve's all-reduce) are taken down; the peers get error -25
             meet.abort()
+            S.abort_local_group(uid)
         finally:
             if ls is not None:
                 ls.close()
 
     print(f"  Number of ranks            = {nranks} (cell columns per rank: "
           f"{' '.join(str(b - a) for a, b in zip(PP.cell_columns(nx, nranks)[:-1], PP.cell_columns(nx, nranks)[1:]))})")
-    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(nranks)]
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
     [t.start() for t in th]
-    [t.join() for t in th]
+    while any(t.is_alive() for t in th) and not errs:
+        [t.join(0.2) for t in th]
     if errs:
-        raise RuntimeError(f"rank failures: {errs}")
+        # the aborts above end every wait of the peers; should one still be stuck (in a HIP call, say) it is left behind as
+        # a daemon thread after a deadline rather than hanging the process
+        deadline = time.time() + float(os.environ.get("NSK_RANK_JOIN_TIMEOUT", "60"))
+        [t.join(max(0.0, deadline - time.time())) for t in th]
+        stuck = [r for r, t in enumerate(th) if t.is_alive()]
+        raise RuntimeError(f"rank failures: {sorted(errs)}" + (f"; ranks still blocked after the deadline: {stuck}" if stuck else ""))
     return 0
 
 

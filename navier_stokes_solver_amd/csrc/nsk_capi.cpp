@@ -668,6 +668,21 @@ int H::solve_resident(int solver, double tol, int max_iter, int *iters, double *
     return -1;                                        \
   }
 
+// entries that run collectives: a rank that fails inside one takes the in-process group down with it, so that the
+// peers blocked in the collective get Error -25 instead of waiting for ever (RCCL has its own abort path)
+#define NSK_CATCH_ABORT(h)                            \
+  }                                                   \
+  catch (const Error &e) {                            \
+    (h)->err = e.what();                              \
+    if (e.code != -25) (h)->ctx.comm.abort_group();   \
+    return e.code;                                    \
+  }                                                   \
+  catch (const std::exception &e) {                   \
+    (h)->err = e.what();                              \
+    (h)->ctx.comm.abort_group();                      \
+    return -1;                                        \
+  }
+
 extern "C" {
 
 int nsk_get_unique_id(void *out128) {
@@ -784,6 +799,8 @@ int nsk_debug_schur_at_offset(int n_p, int n_u, const int32_t *b_rp, const int32
     return -1;
   }
 }
+
+int nsk_abort_local_group(const void *uid128) { return abort_local_group(uid128); }   // nsk_internal.h
 
 int nsk_local_group_id_mode(int nranks, int on_stream, void *out128) {   // nsk_internal.h
   if (nranks < 1 || !out128) return -1;
@@ -995,7 +1012,7 @@ int nsk_setup_preconditioner(nsk_handle h, int type, int variant, double alpha) 
   (void)hipSetDevice(h->ctx.device);
   h->setup(type, variant, alpha);
   return 0;
-  NSK_CATCH(h)
+  NSK_CATCH_ABORT(h)
 }
 
 int nsk_upload_system(nsk_handle h, const double *ru, const double *rp, const double *xu, const double *xp) {
@@ -1016,7 +1033,7 @@ int nsk_solve_resident(nsk_handle h, int solver, double tol, int max_iter, int *
   NSK_TRY(h)
   (void)hipSetDevice(h->ctx.device);
   return h->solve_resident(solver, tol, max_iter, iters, final_res);
-  NSK_CATCH(h)
+  NSK_CATCH_ABORT(h)
 }
 
 int nsk_download_solution(nsk_handle h, double *xu, double *xp) {
@@ -1420,7 +1437,7 @@ int nsk_assemble(nsk_handle h, int stokes, double nu, double inv_dt, double p_ou
   if (residual_norm) *residual_norm = nrm;
   A.assemble_ms = wall_ms() - t0;
   return 0;
-  NSK_CATCH(h)
+  NSK_CATCH_ABORT(h)
 }
 
 int nsk_scale_values(nsk_handle h, int blk, double factor) {
@@ -1580,7 +1597,7 @@ int nsk_precond_vmult(nsk_handle h, const double *su, const double *sp_, double 
   h->pool_b.put(db);
   h->check_sync_free();
   return rc;
-  NSK_CATCH(h)
+  NSK_CATCH_ABORT(h)
 }
 
 int64_t nsk_block_nnz(nsk_handle h, int b) {
@@ -1629,6 +1646,12 @@ int nsk_get_stats(nsk_handle h, nsk_stats *o) {
   o->ring_applies = h->ctx.st.ring_applies;
   return 0;
   NSK_CATCH(h)
+}
+
+int nsk_abort_group(nsk_handle h) {   // callable from any thread
+  if (!h) return -1;
+  h->ctx.comm.abort_group();
+  return 0;
 }
 
 int nsk_cancel(nsk_handle h) {   // callable from another thread while a solve runs on this handle

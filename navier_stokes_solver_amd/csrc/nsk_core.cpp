@@ -29,16 +29,24 @@ struct LocalGroup {
   std::vector<double> scratch;  // n * kCap
   static constexpr int kCap = 64;
   bool on_stream = false;
+  bool aborted = false;   // a member failed or left: every rendezvous — pending or later — ends with Error -25 (under m)
   void barrier() {
     std::unique_lock<std::mutex> lk(m);
+    if (aborted) throw Error(-25, "a rank of the local group failed or left: collective aborted");
     const long gen = generation;
     if (++waiting == n) {
       waiting = 0;
       ++generation;
       cv.notify_all();
     } else {
-      cv.wait(lk, [&] { return generation != gen; });
+      cv.wait(lk, [&] { return generation != gen || aborted; });
+      if (generation == gen) throw Error(-25, "a rank of the local group failed or left: collective aborted");
     }
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lk(m);
+    aborted = true;
+    cv.notify_all();
   }
 };
 namespace {
@@ -62,6 +70,21 @@ int make_local_group(int nranks, void *out128, int on_stream) {
   std::memcpy((char *)out128 + 8, &id, sizeof(int));
   std::memcpy((char *)out128 + 12, &nranks, sizeof(int));
   return id;
+}
+
+int abort_local_group(const void *unique_id) {
+  if (!unique_id || std::memcmp(unique_id, kLocalMagic, 8) != 0) return -1;
+  int id = 0;
+  std::memcpy(&id, (const char *)unique_id + 8, sizeof(int));
+  std::shared_ptr<LocalGroup> g;
+  {
+    std::lock_guard<std::mutex> lk(g_groups_mutex);
+    auto it = g_groups.find(id);
+    if (it == g_groups.end()) return -1;
+    g = it->second;
+  }
+  g->abort();
+  return 0;
 }
 
 void Comm::init(int rank_, int nranks_, const void *unique_id, int device_id) {
@@ -110,7 +133,13 @@ void Comm::init(int rank_, int nranks_, const void *unique_id, int device_id) {
   comm = c;
 }
 
+void Comm::abort_group() {
+  if (local) local->abort();
+}
+
 void Comm::destroy() {
+  // a member that leaves takes the group down with it: a peer still (or later) waiting for it would wait for ever
+  if (local) local->abort();
   if (comm) ncclCommDestroy((ncclComm_t)comm);
   comm = nullptr;
   for (int k = 0; k < 2; ++k) {

@@ -188,6 +188,7 @@ struct Comm {
   bool active() const { return nranks > 1 || comm != nullptr; }
   void init(int rank, int nranks, const void *unique_id, int device_id = 0);
   void destroy();
+  void abort_group();   // local group only: every rendezvous of the group, pending or later, ends with Error -25
   void allreduce_sum(double *d, int count, hipStream_t s);
   void halo_exchange(Space &sp, const DVec &x, hipStream_t s);
   void halo_exchange2(Space &sa, const DVec &xa, Space &sb, const DVec &xb, hipStream_t s);   // both in one RCCL group
@@ -198,6 +199,8 @@ struct Comm {
 // on_stream = 1: device-to-device copies and a summing kernel ordered by events across the ranks' streams, host threads
 // only rendezvous — the stream ordering RCCL would see (second-stream overlap, grouped exchange) races for real.
 int make_local_group(int nranks, void *out128, int on_stream = 0);
+// every rendezvous of that group, pending or later (also of members that have not joined yet), ends with Error -25
+int abort_local_group(const void *unique_id);
 
 struct Stats {
   double setup_ms = 0, solve_ms = 0;

@@ -36,6 +36,10 @@ int nsk_debug_tri_trace(struct nsk_handle_s *h, int which, int64_t *out16, int m
  * threads only rendezvous), so the second-stream overlap of the SpMVs and the grouped exchange race as they would under
  * RCCL; on_stream = 0 is nsk_local_group_id (streams synchronised with the host around every collective). */
 int nsk_local_group_id_mode(int nranks, int on_stream, void *out128);
+/* Take an in-process group down by its id: every rendezvous of the group, pending or later — also of members that are
+ * still inside nsk_create — ends with error -25.  For the thread that drives the ranks when one of them failed before
+ * it had a handle (nsk_abort_group needs one).  Callable from any thread. */
+int nsk_abort_local_group(const void *uid128);
 /* Host-only (no handle, no GPU): the multicolour ordering the triangular-solve analysis chooses for a local pattern —
  * perm_out[new] = old; info4 = {colours, largest line group, node structure found, items}; chain_out (may be null): per
  * permuted item position | length << 4 in its line group.  xy: 2 doubles per row or null; group: members per group. */

@@ -211,41 +211,46 @@ void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, 
 
 // ---- natural-order ("caller's order") triangular solve through an LDS ring ----
 // A factor in the caller's order has O(nx + ny) dependent levels of a few hundred rows: nothing to spread over a GPU,
-// and one workgroup walking the levels pays a trip to memory per level.  Here ONE workgroup of kRingWaves wavefronts
-// walks PASSES (at most kRingRows independent rows each); the results the following passes need live in an LDS ring
-// indexed by the row's position in the pass order, and the hand-off between wavefronts is point-to-point: a ring slot
-// holds a NaN until its row is done, a consumer whose row sum comes out NaN reads its operands again.  There is no
-// barrier per pass — only one every `epoch` passes, behind which the slots of the epoch after the next are set back to
-// NaN (so no wavefront is ever more than two epochs from another, and a slot is never re-used while it can be read).
-// Shape: 2 lanes per row, 8 entries per lane (rows of <= 16 entries per half), 32 rows per wavefront.  A lane sums its
-// entries the way lanes l, l+2, l+4, l+6 of the level walker's 8-lane group do (tri_row<8>) and the partial sums are
-// added in the order of its shuffle tree, the diagonal is DIVIDED by: the walker's bits (config 5 sits
-// on an edge that rounding decides).
-// Data: everything a wavefront needs for a pass is contiguous and holds no padding — rows of a pass are sorted by
-// length, so the lanes that own an entry in register r are a prefix of the wavefront and a buffer load whose
-// descriptor ends after n_r records returns {0.0, slot 0} to the others (slot 0 of the LDS image holds 0.0): the
-// addresses are scalar arithmetic on a 16-byte header per (pass, wavefront), no lane computes one.  One CU streams the
-// whole factor, so bytes count: 12 per entry, 24 per row.
-constexpr int kRingWaves = 8, kRingThreads = 64 * kRingWaves, kRingLpr = 2, kRingRegs = 8;
+// and one workgroup walking the levels pays a trip to memory per level.  Here ONE workgroup walks PASSES (at most
+// kRingRows independent rows each); the results the following passes need live in an LDS ring indexed by the row's
+// position in the pass order, and the hand-off between wavefronts is point-to-point: a ring slot holds a NaN until its
+// row is done, a consumer whose row sum comes out NaN reads its operands again.  There is no barrier per pass — only
+// one every `epoch` passes, behind which the slots of the epoch after the next are set back to NaN (so no wavefront is
+// ever more than two epochs from another, and a slot is never re-used while it can be read).
+// A wavefront issues one instruction every four cycles at best, whatever the instruction: what a pass costs is the
+// length of ONE wavefront's instruction stream.  So the wavefronts form two groups that take the passes in turn: while
+// one group sums and hands over, the other fetches the records of its next pass — the chain from level to level then
+// holds the row sums only.
+// Shape: 2 lanes per row, 8 entries per lane (rows of <= 16 entries per half), 32 rows per wavefront, 8 wavefronts per
+// group.  A lane sums its entries the way lanes l, l+2, l+4, l+6 of the level walker's 8-lane group do (tri_row<8>) and
+// the partial sums are added in the order of its shuffle tree, the diagonal is DIVIDED by: the walker's bits (DESIGN.md
+// 5d.1: config 5 sits on an edge that rounding decides).
+// Data: what a wavefront needs for a pass is one contiguous chunk — `regs` registers x (2 x rows) lanes of 12-byte
+// entries, register-major — read with buffer loads whose descriptor ends with the chunk: the registers a wavefront's
+// rows do not reach and the lanes beyond its rows get {0.0, slot 0} back (slot 0 of the LDS image holds 0.0).  Rows of a
+// pass are dealt to wavefronts by length, so a chunk holds next to no padding: one CU streams the whole factor, bytes
+// count (12 per entry, 24 per row).
+constexpr int kRingGroups = 2, kRingWaves = 8, kRingThreads = 64 * kRingWaves * kRingGroups, kRingLpr = 2, kRingRegs = 8;
 constexpr int kRingRowsPerWave = 64 / kRingLpr, kRingRows = kRingWaves * kRingRowsPerWave;
-constexpr int kRingSlots = 8192;      // the ring: 64 KB of LDS (+ 8 bytes: the zero that padding reads)
-constexpr int kRingDepth = 4;         // passes whose records are in flight (registers)
-constexpr int kRingMaxEpoch = 48;     // passes between two workgroup barriers, at most (a multiple of kRingDepth)
+constexpr int kRingSlots = 8192;      // the ring: 64 KB of LDS (+ 16 bytes: the zero that padding reads, the give-up word)
+constexpr int kRingDepth = 2;         // passes OF A GROUP whose records are in flight (registers)
+constexpr int kRingStep = 24;         // n_pass and epoch are multiples of this (any groups x depth the kernel is built for divides it)
+constexpr int kRingMaxEpoch = 48;     // passes between two workgroup barriers, at most (a multiple of kRingStep)
 constexpr int kRingMaxRows = 1 << 26; // (the header keeps a position in 26 bits)
 struct RingHalf {
-  int n_pass;                 // a multiple of kRingDepth; the records hold 2 * kRingDepth empty passes more
-  int epoch;                  // passes between two workgroup barriers (a multiple of kRingDepth)
-  const uint4 *hdr;           // [passes * kRingWaves] {first entry, first position | rows << 26, lanes holding register 0..3 (a byte each), 4..7}
+  int n_pass;                 // a multiple of kRingStep; the records hold kRingStep + 8 empty passes more
+  int epoch;                  // passes between two workgroup barriers (a multiple of kRingStep)
+  const uint4 *hdr;           // [passes * kRingWaves] {first entry, first position | rows << 26, registers, 0}
   const char *ent;            // 12-byte entries {double value; u32 LDS byte offset of the column's slot}
-  const double *rdiag;        // [positions] diagonal of the row at that position
-  const uint2 *meta;          // [positions] {byte offset of the row's result in dst, LDS byte offset of its slot}
+  const char *rowrec;         // [positions] 16 bytes {double diagonal; u32 byte offset of the result in dst; u32 LDS byte offset of the row's slot}
   const int2 *rearm;          // [n_pass / epoch + 1] positions {first, count} set back to NaN behind barrier k
+  unsigned long long *trace;  // diagnostics (NSK_RING_TRACE): 8 counters per wavefront, or null
 };
-// own: the row's own value (right-hand side / lower half's result) in POSITION order; dst: see RingHalf::meta
+// own: the row's own value (right-hand side / lower half's result) in POSITION order; dst: see RingHalf::rowrec
 // lower: dst = kind ? (own - s) / d : own - s ; upper: dst = kind ? own - s / d : (own - s) / d
 void tri_ring(hipStream_t s, const RingHalf &R, int lower, int kind, const double *own, double *dst);
-// ent[12 i] = idx[i] >= 0 ? x[idx[i]] : 0 (the value part of the 12-byte entries)
-void ring_fill_values(hipStream_t s, long n, const int *idx, const double *x, char *ent);
+// the double at dst + stride i = idx[i] >= 0 ? x[idx[i]] : 0 (the value part of 12- / 16-byte records)
+void ring_fill_values(hipStream_t s, long n, const int *idx, const double *x, char *dst, int stride);
 
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,

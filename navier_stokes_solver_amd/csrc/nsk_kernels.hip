@@ -804,6 +804,78 @@ __global__ __launch_bounds__(RBLK) void reduce1_kernel(int n, F f, ReduceWs ws, 
   reduce_finish<1>(v, ws, out, want_sqrt);
 }
 
+// Pairs of entries through 16-byte loads (the vectors come from hipMalloc: 16-byte aligned; the launchers check and fall
+// back to the scalar kernels otherwise): the 8-byte-per-lane forms above stream at 4.0-5.4 TB/s where the 24-byte-per-
+// entry axpy reaches 6.5-6.9.  F2(j) handles entries 2 j and 2 j + 1; an odd last entry goes through F1.
+template <class F2, class F1>
+__global__ __launch_bounds__(RBLK) void reduce2_kernel(int n, F2 f2, F1 f1, ReduceWs ws, double *out, int want_sqrt) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  const long stride = (long)gridDim.x * RBLK, np = n >> 1;
+  long i = (long)blockIdx.x * RBLK + threadIdx.x;
+  for (; i + 3 * stride < np; i += 4 * stride) {
+    a0 += f2((int)i);
+    a1 += f2((int)(i + stride));
+    a2 += f2((int)(i + 2 * stride));
+    a3 += f2((int)(i + 3 * stride));
+  }
+  for (; i < np; i += stride) a0 += f2((int)i);
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) a1 += f1(n - 1);
+  double v[1] = {(a0 + a1) + (a2 + a3)};
+  reduce_finish<1>(v, ws, out, want_sqrt);
+}
+
+template <int M>
+__global__ __launch_bounds__(RBLK) void multi_dot2_kernel(int n, const double *__restrict__ w, VecPack P, ReduceWs ws,
+                                                         double *out) {
+  double acc[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) acc[k] = 0.0;
+  const long np = n >> 1;
+  for (long i = (long)blockIdx.x * RBLK + threadIdx.x; i < np; i += (long)gridDim.x * RBLK) {
+    const double2 wi = reinterpret_cast<const double2 *>(w)[i];
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      const double2 vk = reinterpret_cast<const double2 *>(P.v[k])[i];
+      acc[k] += wi.x * vk.x;
+      acc[k] += wi.y * vk.y;
+    }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < M; ++k) acc[k] += w[n - 1] * P.v[k][n - 1];
+  }
+  reduce_finish<M>(acc, ws, out, 0);
+}
+
+template <int M, bool NORM>
+__global__ __launch_bounds__(RBLK) void multi_axpy2_kernel(int n, double *__restrict__ w, VecPack P,
+                                                          const double *__restrict__ h, ReduceWs ws, double *out) {
+  double hk[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) hk[k] = h[k];
+  double acc[1] = {0.0};
+  const long np = n >> 1;
+  for (long i = (long)blockIdx.x * RBLK + threadIdx.x; i < np; i += (long)gridDim.x * RBLK) {
+    double2 wi = reinterpret_cast<double2 *>(w)[i];
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      const double2 vk = reinterpret_cast<const double2 *>(P.v[k])[i];
+      wi.x -= hk[k] * vk.x;
+      wi.y -= hk[k] * vk.y;
+    }
+    reinterpret_cast<double2 *>(w)[i] = wi;
+    if (NORM) { acc[0] += wi.x * wi.x; acc[0] += wi.y * wi.y; }
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double wi = w[n - 1];
+#pragma unroll
+    for (int k = 0; k < M; ++k) wi -= hk[k] * P.v[k][n - 1];
+    w[n - 1] = wi;
+    if (NORM) acc[0] += wi * wi;
+  }
+  if (NORM) reduce_finish<1>(acc, ws, out, 1);
+}
+
 template <int M>
 __global__ __launch_bounds__(RBLK) void multi_dot_kernel(int n, const double *__restrict__ w, VecPack P, ReduceWs ws,
                                                         double *out) {
@@ -902,14 +974,19 @@ __device__ __forceinline__ double ring_pair_partner(double v) {   // lane 2k rec
   return __hiloint2double(hi, lo);
 }
 
-template <int KIND, bool LOWER>
-__global__ __launch_bounds__(kRingThreads) void tri_ring_kernel(RingHalf R, const int2 *__restrict__ rearm /* = R.rearm: a scalar load */,
-                                                                const double *__restrict__ own_src, double *__restrict__ dst) {
+template <int KIND, bool LOWER, int G, int D, bool TRACE>
+__global__ __launch_bounds__(64 * kRingWaves * G) void tri_ring_kernel(RingHalf R, const int2 *__restrict__ rearm, const uint4 *__restrict__ hdr,
+                                                                      const char *__restrict__ ent, const char *__restrict__ rowrec,
+                                                                      const double *__restrict__ own_src, double *__restrict__ dst) {
+  // (rearm, hdr, ent, rowrec = R's pointers once more, as restrict parameters: read-only and uniform => scalar loads)
   __shared__ double ring_lds[kRingSlots + 2];
-  constexpr int D = kRingDepth, E = kRingRegs;
+  constexpr int E = kRingRegs, kThreads = 64 * kRingWaves * G;
+  unsigned long long tr_wait = 0, tr_tries = 0, tr_comp = 0, tr_issue = 0, tr_rows = 0, tr_t0 = 0;
+  if (TRACE) tr_t0 = __builtin_amdgcn_s_memtime();
   constexpr bool DIAG = !(KIND == 0 && LOWER);   // (the unit lower factor of ILU(0) has no diagonal to divide by)
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int group = wave / kRingWaves, wslot = wave % kRingWaves;   // this wavefront takes the passes q = group (mod G)
   const double nan_v = __longlong_as_double((long long)kSentinel);
   // (LDS pointers keep their address space: through a generic pointer every access would be a FLAT instruction that
   //  waits for all vector-memory traffic — the records in flight)
@@ -917,48 +994,65 @@ __global__ __launch_bounds__(kRingThreads) void tri_ring_kernel(RingHalf R, cons
   using lds_double = __attribute__((address_space(3))) double;
   using lds_int = __attribute__((address_space(3))) int;
   lds_char *const lds = (lds_char *)ring_lds;
-  for (int k = t; k < kRingSlots; k += kRingThreads) ring_lds[1 + k] = nan_v;
+  for (int k = t; k < kRingSlots; k += kThreads) ring_lds[1 + k] = nan_v;
   if (t == 0) { ring_lds[0] = 0.0; ring_lds[kRingSlots + 1] = 0.0; }
   volatile lds_int *const give_up = (volatile lds_int *)(lds + 8 * (kRingSlots + 1));
 
-  // per stage: the records of one pass (registers); per stage one header in flight for the pass kRingDepth later
+  // per stage: the records of one pass (registers); per stage one header in flight for the pass D of this group's later
   unsigned e_lo[D][E], e_hi[D][E], e_off[D][E], m_dst[D], m_slot[D], n_lanes[D];
   double own[D], dg[D];
-  unsigned hx[D], hy[D], hz[D], hw[D];
-  const unsigned vo12 = (unsigned)lane * 12u, vo8 = (unsigned)(lane >> 1) * 8u;
-  const __amdgpu_buffer_rsrc_t hdr_rs = ring_rsrc(R.hdr, 0x7FFFFFF0u);
-  auto load_hdr = [&](int slot, int q) {   // (a VECTOR load of a uniform address: scalar loads share lgkmcnt with the LDS traffic)
-    const auto h = __builtin_amdgcn_raw_buffer_load_b128(hdr_rs, 0, (q * kRingWaves + wave) * 16, 0);
-    hx[slot] = h[0]; hy[slot] = h[1]; hz[slot] = h[2]; hw[slot] = h[3];
+  unsigned hx[D], hy[D], hz[D];
+  const unsigned vo12 = (unsigned)lane * 12u, vo8 = (unsigned)(lane >> 1) * 8u, vo16 = (unsigned)(lane >> 1) * 16u;
+  auto load_hdr = [&](int slot, int q) {   // (uniform address, read-only, restrict: a scalar load)
+    const uint4 h = hdr[q * kRingWaves + wslot];
+    hx[slot] = h.x; hy[slot] = h.y; hz[slot] = h.z;
   };
-  auto issue = [&](int slot) {   // every load of the pass whose header sits in this stage: 8 entry registers + the rows' own data
-    const unsigned h0 = __builtin_amdgcn_readfirstlane(hx[slot]), h1 = __builtin_amdgcn_readfirstlane(hy[slot]);
-    const unsigned h2 = __builtin_amdgcn_readfirstlane(hz[slot]), h3 = __builtin_amdgcn_readfirstlane(hw[slot]);
-    const unsigned pos0 = h1 & 0x3FFFFFFu, rows = h1 >> 26;
-    const char *ep = R.ent + (size_t)h0 * 12u;
+  // The CU's address unit takes about 16 cycles per vector-memory instruction of a wavefront, whatever its width and
+  // however many lanes fall behind the descriptor's end (measured: 104 such instructions per level cost the 1 600 cycles
+  // a level took, in three differently organised kernels) — so a wavefront issues the loads it NEEDS, nothing else:
+  // none for a pass it has no rows in, none for registers its rows do not reach.  The branches are wavefront-uniform;
+  // they cost the exact wait counts (the compiler waits for everything outstanding before a stage is used), which the
+  // alternation of the groups pays for: a stage's loads are issued a whole pass of the other group before their use.
+  auto issue = [&](int slot) {
+    const unsigned h0 = hx[slot], h1 = hy[slot], regs = hz[slot];
+    const unsigned pos0 = h1 & 0x3FFFFFFu, rows = h1 >> 26, nl = rows * kRingLpr, stride = nl * 12u;
+    n_lanes[slot] = nl;
+    if (rows == 0) return;
+    // register r of lane l sits at (r * lanes + l) * 12 of the chunk; lanes without a row fall behind the descriptor's
+    // end and read zeros
+    const __amdgpu_buffer_rsrc_t ers = ring_rsrc(ent + (size_t)h0 * 12u, regs * stride);
+    unsigned vo = (unsigned)lane < nl ? vo12 : 0x7FFF0000u;
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-      const unsigned n = ((r < 4 ? h2 : h3) >> (8 * (r & 3))) & 0xFFu;
-      const auto v = __builtin_amdgcn_raw_buffer_load_b96(ring_rsrc(ep, n * 12u), vo12, 0, 0);
-      e_lo[slot][r] = v[0]; e_hi[slot][r] = v[1]; e_off[slot][r] = v[2];
-      ep += n * 12u;
+      if ((unsigned)r < regs) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b96(ers, vo, 0, 0);
+        e_lo[slot][r] = v[0]; e_hi[slot][r] = v[1]; e_off[slot][r] = v[2];
+        vo += stride;
+      } else {
+        e_lo[slot][r] = 0u; e_hi[slot][r] = 0u; e_off[slot][r] = 0u;
+      }
     }
     const auto o = __builtin_amdgcn_raw_buffer_load_b64(ring_rsrc(own_src + pos0, rows * 8u), vo8, 0, 0);
     own[slot] = __hiloint2double((int)o[1], (int)o[0]);
+    const __amdgpu_buffer_rsrc_t rrs = ring_rsrc(rowrec + (size_t)pos0 * 16u, rows * 16u);
     if (DIAG) {
-      const auto g = __builtin_amdgcn_raw_buffer_load_b64(ring_rsrc(R.rdiag + pos0, rows * 8u), vo8, 0, 0);
+      const auto g = __builtin_amdgcn_raw_buffer_load_b128(rrs, vo16, 0, 0);
       dg[slot] = __hiloint2double((int)g[1], (int)g[0]);
+      m_dst[slot] = g[2]; m_slot[slot] = g[3];
+    } else {
+      const auto g = __builtin_amdgcn_raw_buffer_load_b64(rrs, vo16 + 8u, 0, 0);
+      m_dst[slot] = g[0]; m_slot[slot] = g[1];
     }
-    const auto m = __builtin_amdgcn_raw_buffer_load_b64(ring_rsrc(R.meta + pos0, rows * 8u), vo8, 0, 0);
-    m_dst[slot] = m[0]; m_slot[slot] = m[1];
-    n_lanes[slot] = rows * kRingLpr;
   };
   auto compute = [&](int slot) {
     const unsigned nl = n_lanes[slot];
     const bool rowlane = (lane & 1) == 0 && (unsigned)lane < nl;
-    double res = 0.0;
+    double u = 0.0;
+    unsigned long long tw0 = 0;
+    if (TRACE) { tw0 = __builtin_amdgcn_s_memtime(); tr_rows += nl != 0; }
     if (nl != 0) {   // (wavefront-uniform; no vector-memory instruction inside: the counts the waits rely on stay static)
       for (int tries = 0;;) {
+        if (TRACE) ++tr_tries;
         double x[E], s[4];
 #pragma unroll
         for (int r = 0; r < E; ++r) x[r] = *(volatile lds_double *)(lds + e_off[slot][r]);
@@ -969,59 +1063,70 @@ __global__ __launch_bounds__(kRingThreads) void tri_ring_kernel(RingHalf R, cons
           s[j] = __builtin_fma(__hiloint2double((int)e_hi[slot][4 + j], (int)e_lo[slot][4 + j]), x[4 + j],
                                __builtin_fma(__hiloint2double((int)e_hi[slot][j], (int)e_lo[slot][j]), x[j], 0.0));
         const double t0 = s[0] + s[2], t1 = s[1] + s[3];
-        double u = t0 + t1;
+        u = t0 + t1;
         u = u + ring_pair_partner(u);
-        if (LOWER) res = KIND == 0 ? (own[slot] - u) : (own[slot] - u) / dg[slot];      // (divisions, as tri_row: same bits)
-        else res = KIND == 0 ? (own[slot] - u) / dg[slot] : own[slot] - u / dg[slot];
-        if (!__any(rowlane && res != res)) break;        // every operand had arrived
+        if (!__any(rowlane && u != u)) break;        // every operand had arrived
         if ((++tries & 63) == 0 && (*give_up != 0 || tries >= kRingSpinLimit)) { *give_up = 1; break; }
       }
     }
+    if (TRACE) tr_wait += __builtin_amdgcn_s_memtime() - tw0;
     if (rowlane) {
+      double res;
+      if (LOWER) res = KIND == 0 ? (own[slot] - u) : (own[slot] - u) / dg[slot];      // (divisions, as tri_row: same bits)
+      else res = KIND == 0 ? (own[slot] - u) / dg[slot] : own[slot] - u / dg[slot];
       *(lds_double *)(lds + m_slot[slot]) = res;
       *reinterpret_cast<double *>(reinterpret_cast<char *>(dst) + m_dst[slot]) = res;
     }
+    if (TRACE) tr_comp += __builtin_amdgcn_s_memtime() - tw0;
   };
+  // own index j of this group = pass G * j + group
 #pragma unroll
-  for (int d = 0; d < D; ++d) load_hdr(d, d);
+  for (int d = 0; d < D; ++d) load_hdr(d, G * d + group);
   // (scheduling barriers: the loop's waits count the loads issued since a stage's records — the prologue has to issue
   //  them in the loop's order, or the merged count at the loop head is the prologue's and every pass over-waits)
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     __builtin_amdgcn_sched_barrier(0);
     issue(d);
-    load_hdr(d, D + d);
+    load_hdr(d, G * (D + d) + group);
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();
   int next_barrier = R.epoch, epoch_id = 1;
-  for (int q0 = 0; q0 < R.n_pass; q0 += D) {   // n_pass and epoch are multiples of D
+  for (int q0 = 0; q0 < R.n_pass; q0 += G * D) {   // n_pass and epoch are multiples of G * D
     if (q0 == next_barrier) {
       // everything before pass q0 is done by everybody: the slots of the epoch AFTER this one can be set back to NaN
       // (their old occupants were last read before this barrier — the analysis checked it), and nobody looks at them
       // before the next barrier
       __syncthreads();
       const int2 ra = rearm[epoch_id];
-      for (int k = t; k < ra.y; k += kRingThreads) ring_lds[1 + ((ra.x + k) & (kRingSlots - 1))] = nan_v;
+      for (int k = t; k < ra.y; k += kThreads) ring_lds[1 + ((ra.x + k) & (kRingSlots - 1))] = nan_v;
       next_barrier += R.epoch;
       ++epoch_id;
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      compute(d);
+      compute(d);                      // pass q0 + G * d + group
       __builtin_amdgcn_sched_barrier(0);
-      issue(d);                        // pass q0 + d + D
-      load_hdr(d, q0 + d + 2 * D);
+      unsigned long long ti0 = 0;
+      if (TRACE) ti0 = __builtin_amdgcn_s_memtime();
+      issue(d);                        // D of this group's passes later
+      load_hdr(d, q0 + G * (d + 2 * D) + group);
+      if (TRACE) tr_issue += __builtin_amdgcn_s_memtime() - ti0;
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+  if (TRACE && R.trace && lane == 0) {
+    unsigned long long *o = R.trace + 8 * wave;
+    o[0] = tr_wait; o[1] = tr_tries; o[2] = tr_comp; o[3] = tr_issue; o[4] = tr_rows; o[5] = __builtin_amdgcn_s_memtime() - tr_t0;
   }
 }
 
 __global__ __launch_bounds__(BLK) void ring_fill_values_kernel(long n, const int *__restrict__ idx, const double *__restrict__ x,
-                                                               char *__restrict__ ent) {
+                                                               char *__restrict__ dst, int stride) {
   for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
     const double v = idx[i] >= 0 ? x[idx[i]] : 0.0;
-    unsigned *p = reinterpret_cast<unsigned *>(ent + 12 * i);   // (12-byte records: two dword stores)
+    unsigned *p = reinterpret_cast<unsigned *>(dst + (size_t)stride * i);   // (12-byte records: two dword stores)
     p[0] = (unsigned)__double2loint(v);
     p[1] = (unsigned)__double2hiint(v);
   }
@@ -1404,36 +1509,101 @@ void extract_diag(hipStream_t s, const CsrView &A, double *d, double *dinv) {
     hipLaunchKernelGGL((reduce1_kernel<decltype(f__)>), dim3(red_grid(n)), dim3(RBLK), 0, s, n, f__, ws, out, \
                        want_sqrt);                                                                       \
   } while (0)
+// pairs through 16-byte loads when every vector is 16-byte aligned (F2: entries 2 j, 2 j + 1; F1: an odd last entry)
+#define NSK_RED2(n, F2, F1)                                                                                    \
+  do {                                                                                                         \
+    auto f2__ = F2;                                                                                            \
+    auto f1__ = F1;                                                                                            \
+    hipLaunchKernelGGL((reduce2_kernel<decltype(f2__), decltype(f1__)>), dim3(red_grid(((n) + 1) / 2)), dim3(RBLK), 0, s, n, \
+                       f2__, f1__, ws, out, want_sqrt);                                                        \
+  } while (0)
+namespace {
+inline bool aligned16(const void *a, const void *b = nullptr, const void *c = nullptr, const void *d = nullptr) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15u) == 0;
+}
+bool blas1_pairs() {   // NSK_BLAS1_PAIRS=0 restores the 8-byte-per-lane kernels (A/B measurements)
+  static const bool on = [] { const char *e = getenv("NSK_BLAS1_PAIRS"); return !e || atoi(e) != 0; }();
+  return on;
+}
+typedef const double2 *cd2;
+}  // namespace
 
 void vec_dot(hipStream_t s, const ReduceWs &ws, int n, const double *x, const double *y, double *out, int want_sqrt) {
-  NSK_RED(n, [=] __device__(int i) -> double { return x[i] * y[i]; });
+  auto f1 = [=] __device__(int i) -> double { return x[i] * y[i]; };
+  if (blas1_pairs() && aligned16(x, y) && n >= 2) {
+    NSK_RED2(n, ([=] __device__(int j) -> double {
+               const double2 a = cd2(x)[j], b = cd2(y)[j];
+               return a.x * b.x + a.y * b.y;
+             }), f1);
+    return;
+  }
+  NSK_RED(n, f1);
 }
 void vec_axpy_dot(hipStream_t s, const ReduceWs &ws, int n, SRef a, const double *x, double *y, const double *w,
                   double *out, int want_sqrt) {
+  const bool pairs = blas1_pairs() && aligned16(x, y, w) && n >= 2;
   if (w == y) {
-    NSK_RED(n, [=] __device__(int i) -> double {
+    auto f1 = [=] __device__(int i) -> double {
       const double v = y[i] + sval(a) * x[i];
       y[i] = v;
       return v * v;
-    });
+    };
+    if (pairs)
+      NSK_RED2(n, ([=] __device__(int j) -> double {
+                 const double al = sval(a);
+                 const double2 xv = cd2(x)[j];
+                 double2 yv = reinterpret_cast<double2 *>(y)[j];
+                 yv.x += al * xv.x;
+                 yv.y += al * xv.y;
+                 reinterpret_cast<double2 *>(y)[j] = yv;
+                 return yv.x * yv.x + yv.y * yv.y;
+               }), f1);
+    else NSK_RED(n, f1);
   } else {
-    NSK_RED(n, [=] __device__(int i) -> double {
+    auto f1 = [=] __device__(int i) -> double {
       const double v = y[i] + sval(a) * x[i];
       y[i] = v;
       return v * w[i];
-    });
+    };
+    if (pairs)
+      NSK_RED2(n, ([=] __device__(int j) -> double {
+                 const double al = sval(a);
+                 const double2 xv = cd2(x)[j], wv = cd2(w)[j];
+                 double2 yv = reinterpret_cast<double2 *>(y)[j];
+                 yv.x += al * xv.x;
+                 yv.y += al * xv.y;
+                 reinterpret_cast<double2 *>(y)[j] = yv;
+                 return yv.x * wv.x + yv.y * wv.y;
+               }), f1);
+    else NSK_RED(n, f1);
   }
 }
 void vec_cg_update(hipStream_t s, const ReduceWs &ws, int n, SRef a, const double *d, const double *h, double *x,
                    double *g, double *out) {
   const int want_sqrt = 1;
-  NSK_RED(n, [=] __device__(int i) -> double {
+  auto f1 = [=] __device__(int i) -> double {
     const double al = sval(a);
     x[i] += al * d[i];
     const double v = g[i] + al * h[i];
     g[i] = v;
     return v * v;
-  });
+  };
+  if (blas1_pairs() && aligned16(d, h, x, g) && n >= 2) {
+    NSK_RED2(n, ([=] __device__(int j) -> double {
+               const double al = sval(a);
+               const double2 dv = cd2(d)[j], hv = cd2(h)[j];
+               double2 xv = reinterpret_cast<double2 *>(x)[j], gv = reinterpret_cast<double2 *>(g)[j];
+               xv.x += al * dv.x;
+               xv.y += al * dv.y;
+               gv.x += al * hv.x;
+               gv.y += al * hv.y;
+               reinterpret_cast<double2 *>(x)[j] = xv;
+               reinterpret_cast<double2 *>(g)[j] = gv;
+               return gv.x * gv.x + gv.y * gv.y;
+             }), f1);
+    return;
+  }
+  NSK_RED(n, f1);
 }
 
 // ------------------------------------------------------------------ one-launch modified Gram-Schmidt sweep
@@ -1581,13 +1751,36 @@ void vec_cg_fused_update(hipStream_t s, int n, const double *sc, const double *u
   });
 }
 
+namespace {
+bool pack_aligned16(const double *w, const VecPack &P, int m) {
+  uintptr_t a = (uintptr_t)w;
+  for (int k = 0; k < m; ++k) a |= (uintptr_t)P.v[k];
+  return (a & 15u) == 0;
+}
+}  // namespace
 void vec_multi_dot(hipStream_t s, const ReduceWs &ws, int n, const double *w, const VecPack &P, int m, double *out) {
+  if (blas1_pairs() && n >= 2 && pack_aligned16(w, P, m)) {
+#define NSK_MD(M) case M: hipLaunchKernelGGL((multi_dot2_kernel<M>), dim3(red_grid((n + 1) / 2)), dim3(RBLK), 0, s, n, w, P, ws, out); break;
+    switch (m) { NSK_MD(1) NSK_MD(2) NSK_MD(3) NSK_MD(4) NSK_MD(5) NSK_MD(6) NSK_MD(7) NSK_MD(8) default: break; }
+#undef NSK_MD
+    return;
+  }
 #define NSK_MD(M) case M: hipLaunchKernelGGL((multi_dot_kernel<M>), dim3(red_grid(n)), dim3(RBLK), 0, s, n, w, P, ws, out); break;
   switch (m) { NSK_MD(1) NSK_MD(2) NSK_MD(3) NSK_MD(4) NSK_MD(5) NSK_MD(6) NSK_MD(7) NSK_MD(8) default: break; }
 #undef NSK_MD
 }
 void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const VecPack &P, int m, const double *h,
                     double *norm_out) {
+  if (blas1_pairs() && n >= 2 && pack_aligned16(w, P, m)) {
+#define NSK_MA(M)                                                                                                \
+  case M:                                                                                                        \
+    if (norm_out) hipLaunchKernelGGL((multi_axpy2_kernel<M, true>), dim3(red_grid((n + 1) / 2)), dim3(RBLK), 0, s, n, w, P, h, ws, norm_out); \
+    else hipLaunchKernelGGL((multi_axpy2_kernel<M, false>), dim3(red_grid((n + 1) / 2)), dim3(RBLK), 0, s, n, w, P, h, ws, norm_out);         \
+    break;
+    switch (m) { NSK_MA(1) NSK_MA(2) NSK_MA(3) NSK_MA(4) NSK_MA(5) NSK_MA(6) NSK_MA(7) NSK_MA(8) default: break; }
+#undef NSK_MA
+    return;
+  }
 #define NSK_MA(M)                                                                                                \
   case M:                                                                                                        \
     if (norm_out) hipLaunchKernelGGL((multi_axpy_kernel<M, true>), dim3(red_grid(n)), dim3(RBLK), 0, s, n, w, P, h, ws, norm_out); \
@@ -1597,18 +1790,54 @@ void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const V
 #undef NSK_MA
 }
 
-void tri_ring(hipStream_t s, const RingHalf &R, int lower, int kind, const double *own, double *dst) {
-  if (R.n_pass <= 0) return;
-#define NSK_RING(K, L) hipLaunchKernelGGL((tri_ring_kernel<K, L>), dim3(1), dim3(kRingThreads), 0, s, R, R.rearm, own, dst)
+namespace {
+template <int G, int D, bool TRACE>
+void launch_ring(hipStream_t s, const RingHalf &R, int lower, int kind, const double *own, double *dst) {
+#define NSK_RING(K, L) hipLaunchKernelGGL((tri_ring_kernel<K, L, G, D, TRACE>), dim3(1), dim3(64 * kRingWaves * G), 0, s, R, R.rearm, R.hdr, R.ent, R.rowrec, own, dst)
   if (lower) { if (kind == 0) NSK_RING(0, true); else NSK_RING(1, true); }
   else { if (kind == 0) NSK_RING(0, false); else NSK_RING(1, false); }
 #undef NSK_RING
 }
-void ring_fill_values(hipStream_t s, long n, const int *idx, const double *x, char *ent) {
+}  // namespace
+void tri_ring(hipStream_t s, const RingHalf &R0, int lower, int kind, const double *own, double *dst) {
+  if (R0.n_pass <= 0) return;
+  // study switches: NSK_RING_SHAPE = "groups,depth" (1,2 | 1,3 | 1,4 | 2,2 default), NSK_RING_TRACE = 1 prints in-kernel counters
+  static const int shape = [] { const char *e = getenv("NSK_RING_SHAPE"); int g = kRingGroups, d = kRingDepth; if (e) sscanf(e, "%d,%d", &g, &d); return g * 10 + d; }();
+  static const bool trace = getenv("NSK_RING_TRACE") != nullptr;
+  RingHalf R = R0;
+  static unsigned long long *tbuf = nullptr;
+  if (trace) {
+    if (!tbuf) (void)hipMalloc((void **)&tbuf, sizeof(unsigned long long) * 8 * 16);
+    (void)hipMemsetAsync(tbuf, 0, sizeof(unsigned long long) * 8 * 16, s);
+    R.trace = tbuf;
+    switch (shape) {
+      case 14: launch_ring<1, 4, true>(s, R, lower, kind, own, dst); break;
+      case 12: launch_ring<1, 2, true>(s, R, lower, kind, own, dst); break;
+      case 13: launch_ring<1, 3, true>(s, R, lower, kind, own, dst); break;
+      default: launch_ring<2, 2, true>(s, R, lower, kind, own, dst); break;
+    }
+    unsigned long long h[8 * 16];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, tbuf, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[ring trace] %s half, shape %d, %d passes, epoch %d\n", lower ? "lower" : "upper", shape, R.n_pass, R.epoch);
+    for (int w = 0; w < 16; ++w)
+      if (h[8 * w + 5])
+        fprintf(stderr, "  wave %2d: kernel %9llu ticks, compute %9llu (of which waiting for operands incl. first look %9llu, %7llu looks), fetch %9llu, passes with rows %6llu\n",
+                w, h[8 * w + 5], h[8 * w + 2], h[8 * w + 0], h[8 * w + 1], h[8 * w + 3], h[8 * w + 4]);
+    return;
+  }
+  switch (shape) {
+    case 14: launch_ring<1, 4, false>(s, R, lower, kind, own, dst); break;
+    case 12: launch_ring<1, 2, false>(s, R, lower, kind, own, dst); break;
+    case 13: launch_ring<1, 3, false>(s, R, lower, kind, own, dst); break;
+    default: launch_ring<2, 2, false>(s, R, lower, kind, own, dst); break;
+  }
+}
+void ring_fill_values(hipStream_t s, long n, const int *idx, const double *x, char *dst, int stride) {
   if (n <= 0) return;
   long b = (n + BLK - 1) / BLK;
   if (b > 4096) b = 4096;
-  hipLaunchKernelGGL(ring_fill_values_kernel, dim3((unsigned)b), dim3(BLK), 0, s, n, idx, x, ent);
+  hipLaunchKernelGGL(ring_fill_values_kernel, dim3((unsigned)b), dim3(BLK), 0, s, n, idx, x, dst, stride);
 }
 
 void tri_lower_level(hipStream_t s, const TriView &T, int kind, int lpr, const int *rows, int nrows, const double *rhs,

@@ -652,6 +652,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   if (perm.empty() && n >= 4096 && n < kRingMaxRows) {
     struct RingPlan {
       std::vector<int> pos, order, pass_first;   // position of a row; row at a position; first position of a pass (+ end)
+      std::vector<int> wave_first;               // per pass kRingWaves + 1 positions: the rows of its wavefronts
     };
     auto plan_ring = [&](const std::vector<int> &asap, bool lower, RingPlan &P) -> bool {
       // Pass order.  The earliest level of a row (asap) can lie far before its consumers' — rows behind the obstacle
@@ -672,19 +673,39 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       for (int i = 0; i < n; ++i) nl = std::max(nl, tt[i] + 1);
       std::vector<int> lp, lr;
       level_lists(tt, nl, lp, lr);
-      auto len = [&](int i) { return lower ? pdiag[i] - prp[i] : prp[i + 1] - pdiag[i] - 1; };
+      auto regs_of = [&](int i) { return ((lower ? pdiag[i] - prp[i] : prp[i + 1] - pdiag[i] - 1) + kRingLpr - 1) / kRingLpr; };
       P.pos.assign((size_t)n, 0);
       P.order.clear();
       P.order.reserve((size_t)n);
       P.pass_first.clear();
+      P.wave_first.clear();
       for (int l = 0; l < nl; ++l)
         for (int b = lp[l]; b < lp[l + 1]; b += kRingRows) {
           const int cnt = std::min(kRingRows, lp[l + 1] - b);
-          P.pass_first.push_back((int)P.order.size());
-          const size_t o = P.order.size();
+          const int o = (int)P.order.size();
+          P.pass_first.push_back(o);
           P.order.insert(P.order.end(), lr.begin() + b, lr.begin() + b + cnt);
-          // longest rows first (ties: row order): the lanes that own an entry in register r are then a prefix of a wavefront
-          std::stable_sort(P.order.begin() + o, P.order.end(), [&](int x, int y) { return (len(x) + 1) / 2 > (len(y) + 1) / 2; });
+          // longest rows first (ties: row order), and a wavefront's chunk is padded to its longest row: rows of one
+          // length get wavefronts of their own while the pass has wavefronts to spare
+          std::stable_sort(P.order.begin() + o, P.order.end(), [&](int x, int y) { return regs_of(x) > regs_of(y); });
+          int waves_by_class = 0;
+          for (int p = o; p < o + cnt;) {
+            int e = p;
+            while (e < o + cnt && regs_of(P.order[e]) == regs_of(P.order[p])) ++e;
+            waves_by_class += (e - p + kRingRowsPerWave - 1) / kRingRowsPerWave;
+            p = e;
+          }
+          static const bool want_by_class = [] { const char *e = getenv("NSK_RING_BY_CLASS"); return !e || atoi(e) != 0; }();
+          const bool by_class = want_by_class && waves_by_class <= kRingWaves;
+          int p = o;
+          for (int w = 0; w < kRingWaves; ++w) {
+            P.wave_first.push_back(p);
+            int e = std::min(o + cnt, p + kRingRowsPerWave);
+            if (by_class)
+              for (int k = p; k < e; ++k) if (regs_of(P.order[k]) != regs_of(P.order[p])) { e = k; break; }
+            p = e;
+          }
+          P.wave_first.push_back(p);   // (== o + cnt: by class when that needs no more than kRingWaves wavefronts, else 32 rows each)
         }
       P.pass_first.push_back((int)P.order.size());
       for (int p = 0; p < n; ++p) P.pos[P.order[p]] = p;
@@ -692,7 +713,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     };
     auto build_ring = [&](const RingPlan &P, const RingPlan &other, bool lower, Ring &Rg) -> bool {
       const int np_real = (int)P.pass_first.size() - 1;
-      const int np = (np_real + kRingDepth - 1) / kRingDepth * kRingDepth, np_alloc = np + 2 * kRingDepth;
+      const int np = (np_real + kRingStep - 1) / kRingStep * kRingStep, np_alloc = np + kRingStep + 8;
       auto first_pos = [&](int q) { return P.pass_first[std::min(q, np_real)]; };
       // longest dependency (in positions), then the epoch: behind the barrier in front of epoch k the slots of epoch
       // k + 1 are set back to NaN — their old occupants (kRingSlots positions earlier) must have been read for the last
@@ -710,7 +731,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       }
       if (!ok) return false;
       int epoch = 0;
-      for (int B = kRingMaxEpoch; B >= kRingDepth && !epoch; B -= kRingDepth) {
+      for (int B = kRingMaxEpoch; B >= kRingStep && !epoch; B -= kRingStep) {
         bool fits = true;
         for (int q = 0; q < np && fits; q += B) fits = first_pos(q + 2 * B) - first_pos(q) + maxback <= kRingSlots;
         if (fits) epoch = B;
@@ -719,57 +740,54 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       std::vector<int2> rearm((size_t)np / epoch + 2, make_int2(0, 0));
       for (int k = 1; k * epoch < np; ++k) rearm[k] = make_int2(first_pos((k + 1) * epoch), first_pos((k + 2) * epoch) - first_pos((k + 1) * epoch));
       auto slot_off = [](int p) { return (unsigned)(8 + 8 * (p & (kRingSlots - 1))); };
-      // headers and entries
+      // headers and entries: a wavefront's chunk = regs x (2 x rows) entries, register-major
       std::vector<uint4> hdr((size_t)np_alloc * kRingWaves, make_uint4(0, 0, 0, 0));
       std::vector<int> es;
       std::vector<unsigned> eo;
-      es.reserve((size_t)(lower ? nnz / 2 : nnz / 2) + (size_t)n);
+      es.reserve((size_t)nnz / 2 + (size_t)n);
       eo.reserve(es.capacity());
-      for (int q = 0; q < np_real; ++q) {
-        const int p0 = P.pass_first[q], p1 = P.pass_first[q + 1];
+      for (int q = 0; q < np_real; ++q)
         for (int w = 0; w < kRingWaves; ++w) {
-          const int r0 = std::min(p1, p0 + w * kRingRowsPerWave), r1 = std::min(p1, r0 + kRingRowsPerWave);
-          unsigned nl[kRingRegs] = {0, 0, 0, 0, 0, 0, 0, 0};
-          const unsigned ebase = (unsigned)es.size();
-          for (int r = 0; r < kRingRegs; ++r)
+          const int r0 = P.wave_first[(size_t)q * (kRingWaves + 1) + w], r1 = P.wave_first[(size_t)q * (kRingWaves + 1) + w + 1];
+          int regs = 0;
+          for (int p = r0; p < r1; ++p) {
+            const int i = P.order[p];
+            regs = std::max(regs, ((lower ? pdiag[i] - prp[i] : prp[i + 1] - pdiag[i] - 1) + kRingLpr - 1) / kRingLpr);
+          }
+          const size_t ebase = es.size();
+          if (ebase >= (size_t)UINT32_MAX - 4096) return false;
+          for (int r = 0; r < regs; ++r)
             for (int p = r0; p < r1; ++p) {
               const int i = P.order[p];
               const int kb = lower ? prp[i] : pdiag[i] + 1, ke = lower ? pdiag[i] : prp[i + 1];
-              if (ke - kb <= kRingLpr * r) break;   // (sorted: the rows behind are no longer)
-              nl[r] += kRingLpr;
               for (int l = 0; l < kRingLpr; ++l) {
                 const int e = kb + kRingLpr * r + l;   // entry 2 r + l of the row: walker lane (2 r + l) % 8
                 if (e < ke) { es.push_back(e); eo.push_back(slot_off(P.pos[pcol[e]])); }
-                else { es.push_back(-1); eo.push_back(0u); }   // (an odd row's last lane: 0.0 times LDS word 0 = 0.0)
+                else { es.push_back(-1); eo.push_back(0u); }   // (behind a row's last entry: 0.0 times LDS word 0 = 0.0)
               }
             }
-          hdr[(size_t)q * kRingWaves + w] =
-              make_uint4(ebase, (unsigned)r0 | (unsigned)(r1 - r0) << 26, nl[0] | nl[1] << 8 | nl[2] << 16 | nl[3] << 24,
-                         nl[4] | nl[5] << 8 | nl[6] << 16 | nl[7] << 24);
+          hdr[(size_t)q * kRingWaves + w] = make_uint4((unsigned)ebase, (unsigned)r0 | (unsigned)(r1 - r0) << 26, (unsigned)regs, 0u);
         }
-      }
-      if (es.size() >= (size_t)UINT32_MAX) return false;
-      std::vector<char> ent(es.size() * 12 + 16, 0);
+      std::vector<char> ent(es.size() * 12 + 16, 0), rowrec((size_t)n * 16 + 16, 0);
       for (size_t k = 0; k < es.size(); ++k) memcpy(&ent[k * 12 + 8], &eo[k], 4);
       std::vector<int> ds((size_t)n);
-      std::vector<uint2> meta((size_t)n);
       for (int p = 0; p < n; ++p) {
         const int i = P.order[p];
         ds[p] = pdiag[i];
         // the lower half hands its result to the upper half in THAT half's position order, the upper half writes the caller's
-        meta[p] = make_uint2(8u * (unsigned)(lower ? other.pos[i] : i), slot_off(p));
+        const unsigned m[2] = {8u * (unsigned)(lower ? other.pos[i] : i), slot_off(p)};
+        memcpy(&rowrec[(size_t)p * 16 + 8], m, 8);
       }
       Rg.n_pass = np;
       Rg.epoch = epoch;
       Rg.n_ent = (long)es.size();
       Rg.hdr.upload(hdr, s);
       Rg.ent.upload(ent, s);
+      Rg.rowrec.upload(rowrec, s);
       Rg.esrc.upload(es, s);
       Rg.dsrc.upload(ds, s);
       Rg.rowid.upload(P.order, s);
-      Rg.meta.upload(meta, s);
       Rg.rearm.upload(rearm, s);
-      Rg.rdiag.alloc((size_t)n);
       Rg.own.alloc((size_t)n);
       ctx->sync();
       return true;
@@ -828,8 +846,8 @@ void TriSolve::numeric(const double *a_val_dev) {
   }
   if (ring_ready)
     for (Ring *Rg : {&ringL, &ringU}) {
-      ring_fill_values(s, Rg->n_ent, Rg->esrc.p, val.p, Rg->ent.p);
-      vec_gather(s, n, Rg->dsrc.p, val.p, Rg->rdiag.p);
+      ring_fill_values(s, Rg->n_ent, Rg->esrc.p, val.p, Rg->ent.p, 12);
+      ring_fill_values(s, n, Rg->dsrc.p, val.p, Rg->rowrec.p, 16);
     }
 }
 

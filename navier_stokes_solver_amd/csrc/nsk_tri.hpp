@@ -92,12 +92,12 @@ struct TriSolve {
     long n_ent = 0;
     DBuf<uint4> hdr;
     DBuf<char> ent;            // 12-byte entries
+    DBuf<char> rowrec;         // 16-byte row records
     DBuf<int> esrc, dsrc;      // where an entry's value / a position's diagonal sits in the factor (-1: padding)
     DBuf<int> rowid;           // [positions] the row at that position (gathers the right-hand side into position order)
-    DBuf<double> rdiag, own;   // [positions]
-    DBuf<uint2> meta;
+    DBuf<double> own;          // [positions]
     DBuf<int2> rearm;
-    RingHalf view() const { return RingHalf{n_pass, epoch, hdr.p, ent.p, rdiag.p, meta.p, rearm.p}; }
+    RingHalf view() const { return RingHalf{n_pass, epoch, hdr.p, ent.p, rowrec.p, rearm.p, nullptr}; }
   } ringL, ringU;
   bool ring_ready = false;
 

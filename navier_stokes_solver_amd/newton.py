@@ -323,6 +323,7 @@ class MultiRankSimplexBackend(SimplexBackend):
         self.handles = [None] * nranks
         self.queues = [queue.Queue() for _ in range(nranks)]
         self.results = queue.Queue()
+        self.unique_id = unique_id
         devices = devices or [0] * nranks
 
         def worker(r):
@@ -352,12 +353,25 @@ class MultiRankSimplexBackend(SimplexBackend):
         """Run fn(rank) on every rank thread at once (collective calls need all ranks inside) and collect the results."""
         for q in self.queues:
             q.put(fn)
+        import queue
+        import time
         out = [None] * self.nranks
-        err = None
-        for _ in range(self.nranks):
-            r, val, e = self.results.get()
+        err, got, deadline = None, 0, None
+        while got < self.nranks:
+            try:
+                r, val, e = self.results.get(timeout=0.2 if deadline is None else max(0.01, deadline - time.time()))
+            except queue.Empty:
+                if deadline is not None and time.time() >= deadline:
+                    raise RuntimeError(f"a rank failed ({err!r}) and {self.nranks - got} peers are still blocked after the deadline")
+                continue
+            got += 1
             out[r] = val
-            err = err or e
+            if e is not None and err is None:
+                # a rank that failed on its own leaves its peers inside the library's collectives: take the group down
+                # (they return error -25) and give them a deadline instead of waiting for ever
+                err = e
+                self.S.abort_local_group(self.unique_id)
+                deadline = time.time() + 60.0
         if err:
             raise err
         return out

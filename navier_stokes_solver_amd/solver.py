@@ -42,7 +42,7 @@ EXPORTS = [
     "nsk_set_block_csr", "nsk_update_values", "nsk_set_option", "nsk_setup_preconditioner", "nsk_solve",
     "nsk_upload_system", "nsk_solve_resident", "nsk_download_solution", "nsk_spmv", "nsk_jacobian_vmult", "nsk_dot", "nsk_vec_op",
     "nsk_tri_apply", "nsk_amg_info", "nsk_tri_get_perm", "nsk_precond_vmult", "nsk_block_nnz", "nsk_get_block", "nsk_get_stats",
-    "nsk_reset_stats", "nsk_get_history", "nsk_cancel", "nsk_assembly_set_cells", "nsk_assembly_set_simplex", "nsk_assembly_set_dirichlet", "nsk_state_set", "nsk_state_get",
+    "nsk_reset_stats", "nsk_get_history", "nsk_cancel", "nsk_abort_group", "nsk_assembly_set_cells", "nsk_assembly_set_simplex", "nsk_assembly_set_dirichlet", "nsk_state_set", "nsk_state_get",
     "nsk_state_save", "nsk_state_save_old", "nsk_state_update", "nsk_assemble", "nsk_scale_values", "nsk_download_rhs", "nsk_time_assemble", "nsk_time_op", "nsk_profile_begin", "nsk_profile_read", "nsk_profile_end",
 ]
 
@@ -189,6 +189,14 @@ def local_group_id(nranks: int, on_stream: bool = False) -> bytes:
     if L.nsk_local_group_id_mode(nranks, 1 if on_stream else 0, buf) != 0:
         raise RuntimeError("nsk_local_group_id failed")
     return buf.raw
+
+
+def abort_local_group(unique_id: bytes) -> None:
+    """Take an in-process group down by its id: every rendezvous of the group — pending, later, or of a member still inside
+    nsk_create — ends with error -25.  What the thread driving the ranks calls when one of them failed (nsk_internal.h)."""
+    L = lib()
+    L.nsk_abort_local_group.argtypes = [C.c_void_p]
+    L.nsk_abort_local_group(C.c_char_p(unique_id))
 
 
 class LinearSolver:
@@ -474,6 +482,11 @@ class LinearSolver:
     def cancel(self):
         """End the solve running on this handle (callable from another thread)."""
         self.L.nsk_cancel(self.h)
+
+    def abort_group(self):
+        """In-process group only: every collective of this handle's group, pending or later, returns -25 (any thread)."""
+        if self.h:
+            self.L.nsk_abort_group(self.h)
 
     def reset_stats(self):
         self._ck(self.L.nsk_reset_stats(self.h))

@@ -422,9 +422,9 @@ def test_first_cycle_of_all_nine_stationary_pairs_matches_oracle(handles, prec, 
           f"x: {rel_err(np.concatenate([xu, xp]), xo):.2e}, iterations {its} / {info['iters']}")
     assert its == info["iters"] == steps and len(hg) == len(ho) and n >= steps
     # the inner solves stop at the same step on both sides (relative tolerances, far from rounding), so the histories
-    # agree to what the inner recurrences amplify: 1e-8 for the Arnoldi solvers, 1e-6 for BiCGStab's 12 values
-    assert dev <= (1e-6 if solver == 2 else 1e-8), dev
-    assert rel_err(np.concatenate([xu, xp]), xo) <= (1e-5 if solver == 2 else 1e-7)
+    # agree to rounding (measured on MI355X, round 4: 1e-15 ... 3e-12 over the nine pairs, x to 1e-14 ... 6e-12)
+    assert dev <= 1e-10, dev
+    assert rel_err(np.concatenate([xu, xp]), xo) <= 1e-10
 
 
 def test_vector_ops_directly(handles):

@@ -182,6 +182,54 @@ def test_multi_rank_path_on_gpu_local_group(world, prec, variant, ordering, name
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("where", ["inside the library", "on the caller's side", "before it had a handle"])
+def test_a_failing_rank_does_not_leave_its_peers_waiting(where):
+    """the in-process transport's rendezvous had no way out — one rank failing on its own left the
+    other rank threads blocked in the library for ever.  Now a failure inside a collective entry point, nsk_destroy of a
+    member, nsk_abort_group and nsk_abort_local_group all take the group down: the peers' collectives return -25."""
+    import time
+    from navier_stokes_solver_amd import solver as S
+    world, name = 3, "ns16"
+    case = CASES[name]
+    parts = [P.generate(**case, nranks=world, rank=r) for r in range(world)]
+    plans = [{S.SPACE_U: PT.build_halo_plan(r, parts[0].u_ranges, [p.ghost_u for p in parts]),
+              S.SPACE_P: PT.build_halo_plan(r, parts[0].p_ranges, [p.ghost_p for p in parts])} for r in range(world)]
+    uid = S.local_group_id(world, True)
+    outcome = [None] * world
+
+    def run(r):
+        ls = None
+        try:
+            if where == "before it had a handle" and r == 1:
+                raise ValueError("rank 1 fails before nsk_create")
+            ls = S.LinearSolver(r, world, 0, uid)
+            ls.set_problem(parts[r], plans[r])
+            if where == "inside the library" and r == 1:
+                ls.setup_preconditioner(7, 0, 0.5)          # invalid type: error -4x on this rank only
+            if where == "on the caller's side" and r == 1:
+                raise ValueError("rank 1 fails between two calls")
+            ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)   # collective: D^-1 halo exchange, all-reduces
+            ls.solve(S.FGMRES, 1e-8, 50, parts[r].rhs_u, parts[r].rhs_p, parts[r].x0_u, parts[r].x0_p)
+            outcome[r] = "finished"
+        except Exception as e:  # noqa: BLE001
+            outcome[r] = repr(e)
+            if where != "inside the library":
+                S.abort_local_group(uid)       # what cli.run_ranks / MultiRankSimplexBackend do for a rank of theirs
+        finally:
+            if ls is not None:
+                ls.close()
+
+    th = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    t0 = time.time()
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not any(t.is_alive() for t in th), ("rank threads still blocked", outcome)
+    assert time.time() - t0 < 100
+    assert "finished" not in outcome, outcome
+    assert all("aborted" in outcome[r] for r in (0, 2)), outcome      # error -25's text
+
+
+@pytest.mark.gpu
 def test_both_local_transports_give_the_same_bits():
     """Host-staged and on-stream collectives sum in rank order and move the same ghost values: J x, one preconditioner
     application and twelve outer iterations must agree bit for bit (a race in the on-stream ordering would not)."""
