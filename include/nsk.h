@@ -30,7 +30,8 @@
  *   -40..-47 missing blocks, bad preconditioner / solver type, call order
  *   -50..-59 bad arguments of the hand-off calls           -60..-66 device assembly / Newton state
  *   -70 single-launch triangular solve gave up waiting AND the per-colour retry failed too (see NSK_OPT_TRI_SYNC_FREE)
- *   -80 AMG level operator too large for 32-bit indices     -1 any other exception
+ *   -80..-84 AMG set-up (operator too large for 32-bit indices, rows too wide, rounds / estimates that do not end)
+ *   -1 any other exception
  */
 #ifndef NSK_H
 #define NSK_H
@@ -105,7 +106,7 @@ enum {
                                  on the quality of that one application: the caller's order reproduces
                                  the factor one MPI rank of the reference builds (same iteration counts as the CPU
                                  restatement: 241 / 403 at 100x70), at O(nx + ny) dependent levels per application */
-  NSK_OPT_SCHUR_SIGN = 14      /* +1 (default): aSIMPLE's S = B~ D^-1 B~^T exactly as the reference forms it
+  NSK_OPT_SCHUR_SIGN = 14,     /* +1 (default): aSIMPLE's S = B~ D^-1 B~^T exactly as the reference forms it
                                  (NSSolverStationary.hpp:275, NSSolver.hpp:288).  -1: S = -B~ D^-1 B~^T, the Schur-complement
                                  approximation SIMPLE is derived with for J = [[F, B~^T], [B~, 0]] — a LABELLED DEVIATION from
                                  the reference, off by default: with the reference's sign the pressure correction comes out
@@ -113,6 +114,14 @@ enum {
                                  (pressure), and restarted FGMRES(30) crawls on the indefinite spectrum (3 062
                                  against 580 outer iterations to 1e-10 at 60x20 in the CPU restatement).  Every parity test,
                                  the drivers and the bench headline keep +1 */
+  NSK_OPT_BLAS1_PAIRS = 15     /* dot products / norms / fused Gram-Schmidt sums read PAIRS of entries through 16-byte loads
+                                 (6.3+ TB/s instead of 4.0-5.4 with 8 bytes per lane): 1 on, 0 off, -1 (default) on in the
+                                 STATIONARY preconditioner variant, off in the unsteady one.  Another lane decomposition is
+                                 another summation order, i.e. other last bits in every Krylov coefficient — harmless where
+                                 solves converge with room (stationary: iteration counts within a per cent), decisive where
+                                 restarted FGMRES sits on an edge: BASELINE config 5's first time step at 600x200 (-p 0) takes
+                                 1 061 / 865 / 1 363 outer iterations with the 8-byte sums and 1 162 / no convergence in 100 000
+                                 with the 16-byte ones (profiles/r04_cli_first_level_*) */
 };
 
 typedef struct {

@@ -219,17 +219,43 @@ def run_gmsh(cfg, unsteady: bool) -> int:
     return 0
 
 
-def run_ranks(cfg, unsteady: bool, nranks: int) -> int:
-    """`mpirun -n N StationaryNSSolver / NSSolver -m X,Y` (NSSolverStationary.cpp:226-242: DoFs distributed by mesh
-    partition): N ranks own x-strips of the mesh, each with its own handle, device-resident state and the SAME driver
-    loop — assembly, halo exchanges, global reductions and the rank-local preconditioners are the library's multi-rank
-    path.  The ranks are threads of this process joined by the in-process transport (one GPU each when the process sees
-    several, else sharing the one there is): what `NSK_RANKS=N` selects.  Every rank writes its VTU piece, rank 0 the
-    .pvtu record; lift / drag are summed over the ranks' shares (Utilities::MPI::sum, .cpp:895-896)."""
-    import threading
+class _ThreadGroup:
+    """Control plane of `NSK_RANKS=N`: the ranks are threads of this process."""
 
+    def __init__(self, n):
+        import threading
+        self.n, self.meet, self.slots = n, threading.Barrier(n), [None] * n
+
+    def allgather(self, r, obj):
+        self.slots[r] = obj
+        self.meet.wait()
+        out = list(self.slots)
+        self.meet.wait()
+        return out
+
+    def abort(self):
+        self.meet.abort()
+
+
+class _ProcessGroup:
+    """Control plane of one process per rank (torch.distributed.run): gloo; the data path is RCCL inside the library."""
+
+    def __init__(self, dist, n):
+        self.dist, self.n = dist, n
+
+    def allgather(self, r, obj):
+        out = [None] * self.n
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def abort(self):
+        pass
+
+
+def _rank_main(cfg, unsteady, r, nranks, grp, make_handle, say):
+    """One rank of `mpirun -n N StationaryNSSolver / NSSolver -m X,Y`: its x-strip of the mesh, its handle, device-resident
+    state and the reference's driver loop; `grp` is the control plane (ghost lists, VTU pieces, lift / drag sums)."""
     import numpy as np
-    import torch
 
     from . import newton as N
     from . import partition as PT
@@ -237,74 +263,90 @@ def run_ranks(cfg, unsteady: bool, nranks: int) -> int:
     from . import problem as P
     from . import solver as S
     nx, ny = cfg["mx"], cfg["my"]
-    if nranks > nx:
+    U = 0.3 if unsteady else 0.1
+    nu0 = 1.0 if unsteady else 0.1
+    first = P.generate(nx, ny, nu=nu0, mode=0, state=0, inlet_bc=1, U=U, nranks=nranks, rank=r)
+    ghosts = grp.allgather(r, (first.ghost_u, first.ghost_p))
+    ur, prg = first.u_ranges, first.p_ranges
+    plan = {S.SPACE_U: PT.build_halo_plan(r, ur, [g[0] for g in ghosts]),
+            S.SPACE_P: PT.build_halo_plan(r, prg, [g[1] for g in ghosts])}
+    n_u, n_p = int(ur[-1]), int(prg[-1])
+    ls = make_handle()
+    try:
+        ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
+        backend = N.DeviceBackend(ls, first, cfg["solver"], cfg["prec"], cfg["tol"],
+                                  max_iter=100000 if unsteady else 20000, inv_dt=1.0 / cfg["dt"] if unsteady else 0.0,
+                                  plan=plan)
+
+        def report(nu, inlet_u, name, counter, n_digits):
+            # the ranks' owned pieces side by side are the global vectors (x-strips own contiguous ranges)
+            pieces = grp.allgather(r, backend.solution())
+            u, p = np.concatenate([q[0] for q in pieces]), np.concatenate([q[1] for q in pieces])
+            say("===============================================")
+            PP.write_vtu(os.environ.get("NSK_OUTPUT_DIR", "./"), name, counter, nx, ny, u, p, n_digits=n_digits, rank=r,
+                         nranks=nranks)
+            say("Output written to output-stokes")
+            say("===============================================")
+            say("===============================================\nComputing lift and drag forces")
+            forces = grp.allgather(r, PP.lift_drag(nx, ny, u, p, nu, rank=r, nranks=nranks))   # (Utilities::MPI::sum)
+            drag, lift = sum(f[0] for f in forces), sum(f[1] for f in forces)
+            cd, cl = PP.coefficients(drag, lift, inlet_u)
+            say(f"===============================================\nLift coefficient: {cl:g}")
+            say(f"===============================================\nDrag coefficient: {cd:g}")
+
+        t0 = time.time()
+        if unsteady:
+            nu_last = 1.0 / max(_levels(1.0, 10.0, cfg["Re"]))
+            N.time_loop(backend, cfg["T"], cfg["dt"], cfg["Re"], log=say,
+                        after_step=lambda step: report(nu_last, 0.3, "output", step, 3))
+        else:
+            N.solve_newton(backend, cfg["Re"], log=say)
+            report(1.0 / max(_levels(10.0, 20.0, cfg["Re"])), 1.0, "output-stokes", 0, None)
+        dt = time.time() - t0
+        its = backend.total_linear_iterations
+        say(f"[nsk] {nranks} ranks, {backend.assemblies} assemblies, {its} outer iterations of solve_system(), {dt:.3f} s in "
+            f"{'the time loop' if unsteady else 'solve_newton'} -> {(n_u + n_p) * its / max(dt, 1e-12):.4g} DoF*iters/s")
+    finally:
+        ls.close()
+
+
+def _say_ranks(nx, nranks):
+    from . import postprocess as PP
+    cols = PP.cell_columns(nx, nranks)
+    print(f"  Number of ranks            = {nranks} (cell columns per rank: "
+          f"{' '.join(str(b - a) for a, b in zip(cols[:-1], cols[1:]))})")
+
+
+def run_ranks(cfg, unsteady: bool, nranks: int) -> int:
+    """`mpirun -n N StationaryNSSolver / NSSolver -m X,Y` (NSSolverStationary.cpp:226-242: DoFs distributed by mesh
+    partition) with the ranks as THREADS of this process joined by the in-process transport (one GPU each when the
+    process sees several, else sharing the one there is): what `NSK_RANKS=N` selects — the way a one-GPU box runs the
+    multi-rank drivers.  `run_processes` is the same driver with one process per rank over RCCL.  Every rank writes its
+    VTU piece, rank 0 the .pvtu record; lift / drag are summed over the ranks' shares (Utilities::MPI::sum, .cpp:895-896)."""
+    import threading
+
+    import torch
+
+    from . import solver as S
+    if nranks > cfg["mx"]:
         raise ValueError("more ranks than cell columns")
     ndev = max(1, torch.cuda.device_count())
     uid = S.local_group_id(nranks, on_stream=(ndev == 1))
-    U = 0.3 if unsteady else 0.1
-    nu0 = 1.0 if unsteady else 0.1
-    firsts = [P.generate(nx, ny, nu=nu0, mode=0, state=0, inlet_bc=1, U=U, nranks=nranks, rank=r) for r in range(nranks)]
-    ur, prg = firsts[0].u_ranges, firsts[0].p_ranges
-    plans = [{S.SPACE_U: PT.build_halo_plan(r, ur, [q.ghost_u for q in firsts]),
-              S.SPACE_P: PT.build_halo_plan(r, prg, [q.ghost_p for q in firsts])} for r in range(nranks)]
-    n_u, n_p = int(ur[-1]), int(prg[-1])
-    meet = threading.Barrier(nranks)
-    shared = {"u": [None] * nranks, "p": [None] * nranks, "f": [None] * nranks, "stats": [None] * nranks}
+    grp = _ThreadGroup(nranks)
     errs = []
 
     def rank_main(r):
-        say = print if r == 0 else (lambda *_a, **_k: None)
-        ls = None
         try:
-            ls = S.LinearSolver(r, nranks, r % ndev, uid)
-            ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
-            backend = N.DeviceBackend(ls, firsts[r], cfg["solver"], cfg["prec"], cfg["tol"],
-                                      max_iter=100000 if unsteady else 20000, inv_dt=1.0 / cfg["dt"] if unsteady else 0.0,
-                                      plan=plans[r])
-
-            def report(nu, inlet_u, name, counter, n_digits):
-                # the ranks' owned pieces side by side are the global vectors (x-strips own contiguous ranges)
-                shared["u"][r], shared["p"][r] = backend.solution()
-                meet.wait()
-                u, p = np.concatenate(shared["u"]), np.concatenate(shared["p"])
-                say("===============================================")
-                PP.write_vtu(os.environ.get("NSK_OUTPUT_DIR", "./"), name, counter, nx, ny, u, p, n_digits=n_digits, rank=r,
-                             nranks=nranks)
-                say("Output written to output-stokes")
-                say("===============================================")
-                say("===============================================\nComputing lift and drag forces")
-                shared["f"][r] = PP.lift_drag(nx, ny, u, p, nu, rank=r, nranks=nranks)
-                meet.wait()
-                drag, lift = sum(f[0] for f in shared["f"]), sum(f[1] for f in shared["f"])
-                cd, cl = PP.coefficients(drag, lift, inlet_u)
-                say(f"===============================================\nLift coefficient: {cl:g}")
-                say(f"===============================================\nDrag coefficient: {cd:g}")
-                meet.wait()
-
-            t0 = time.time()
-            if unsteady:
-                nu_last = 1.0 / max(_levels(1.0, 10.0, cfg["Re"]))
-                N.time_loop(backend, cfg["T"], cfg["dt"], cfg["Re"], log=say,
-                            after_step=lambda step: report(nu_last, 0.3, "output", step, 3))
-            else:
-                N.solve_newton(backend, cfg["Re"], log=say)
-                report(1.0 / max(_levels(10.0, 20.0, cfg["Re"])), 1.0, "output-stokes", 0, None)
-            dt = time.time() - t0
-            its = backend.total_linear_iterations
-            say(f"[nsk] {nranks} ranks, {backend.assemblies} assemblies, {its} outer iterations of solve_system(), {dt:.3f} s in "
-                f"{'the time loop' if unsteady else 'solve_newton'} -> {(n_u + n_p) * its / max(dt, 1e-12):.4g} DoF*iters/s")
+            _rank_main(cfg, unsteady, r, nranks, grp, lambda: S.LinearSolver(r, nranks, r % ndev, uid),
+                       print if r == 0 else (lambda *_a, **_k: None))
         except Exception as e:  # noqa: BLE001
             errs.append((r, repr(e)))
             # a rank that fails on its own must not leave the others waiting: the Python rendezvous AND the library's
             # collectives (the peers may be inside nsk_solve's all-reduce) are taken down; the peers get error -25
-            meet.abort()
+            grp.abort()
             S.abort_local_group(uid)
-        finally:
-            if ls is not None:
-                ls.close()
 
-    print(f"  Number of ranks            = {nranks} (cell columns per rank: "
-          f"{' '.join(str(b - a) for a, b in zip(PP.cell_columns(nx, nranks)[:-1], PP.cell_columns(nx, nranks)[1:]))})")
+    _say_ranks(cfg["mx"], nranks)
     th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(nranks)]
     [t.start() for t in th]
     while any(t.is_alive() for t in th) and not errs:
@@ -316,6 +358,36 @@ def run_ranks(cfg, unsteady: bool, nranks: int) -> int:
         [t.join(max(0.0, deadline - time.time())) for t in th]
         stuck = [r for r, t in enumerate(th) if t.is_alive()]
         raise RuntimeError(f"rank failures: {sorted(errs)}" + (f"; ranks still blocked after the deadline: {stuck}" if stuck else ""))
+    return 0
+
+
+def run_processes(cfg, unsteady: bool) -> int:
+    """The same drivers with ONE PROCESS PER RANK, as the reference runs under mpirun:
+        python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 -m navier_stokes_solver_amd.cli StationaryNSSolver -m X,Y ...
+    Control plane (ghost lists, VTU pieces, lift / drag sums, the RCCL id): torch.distributed over gloo, initialised
+    before anything touches the GPU; data path: RCCL inside the library, one GPU per process (LOCAL_RANK)."""
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > cfg["mx"]:
+        raise ValueError("more ranks than cell columns")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch
+
+        from . import solver as S
+        if local_rank >= torch.cuda.device_count():
+            raise RuntimeError(f"rank {rank}: no GPU {local_rank} on this node (one process per GPU)")
+        torch.cuda.set_device(local_rank)
+        box = [S.get_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        if rank == 0:
+            _say_ranks(cfg["mx"], world)
+        _rank_main(cfg, unsteady, rank, world, _ProcessGroup(dist, world),
+                   lambda: S.LinearSolver(rank, world, local_rank, box[0]),
+                   print if rank == 0 else (lambda *_a, **_k: None))
+    finally:
+        dist.destroy_process_group()
     return 0
 
 
@@ -335,6 +407,8 @@ def run(cfg, unsteady: bool) -> int:
     print(f"    velocity = {info['n_u_global']}\n    pressure = {info['n_p_global']}\n"
           f"    total    = {info['n_u_global'] + info['n_p_global']}")
     print("-----------------------------------------------")
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ and "TORCHELASTIC_RUN_ID" in os.environ:
+        return run_processes(cfg, unsteady)      # launched by torch.distributed.run: one process per rank
     if int(os.environ.get("NSK_RANKS", "1")) > 1:
         return run_ranks(cfg, unsteady, int(os.environ["NSK_RANKS"]))
     if not unsteady:
@@ -387,6 +461,11 @@ def main(argv=None) -> int:
     cfg, rc = parse(argv[1:], unsteady)
     if cfg is None:
         return rc
+    if "TORCHELASTIC_RUN_ID" in os.environ and int(os.environ.get("RANK", "0")) != 0:
+        import contextlib
+        with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):   # pcout: rank 0 speaks (errors go to stderr)
+            echo(cfg, unsteady)
+            return run(cfg, unsteady)
     echo(cfg, unsteady)
     return run(cfg, unsteady)
 

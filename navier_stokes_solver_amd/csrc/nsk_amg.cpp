@@ -151,7 +151,9 @@ void row_product(Scratch &S, const amgk::RowProduct &P, int product, int n_cols,
   const ProductPlan pl = product_rows(S, P, product, first_tier, C.rowptr.p);
   C.col.alloc((size_t)std::max<int64_t>(pl.nnz, 1));
   C.val.alloc((size_t)std::max<int64_t>(pl.nnz, 1));
+  S.zero_counter(1);
   amgk::product_fill(S.ctx->stream, P, product, pl.tier, C.rowptr.p, C.col.p, C.val.p, S.counters.p + 1);
+  if (S.read_counter(1) != 0) throw Error(-84, "AMG set-up: the fill of a row product found a row its count had not");
   finish_csr(S.ctx, C, n, n_cols, pl.nnz);
 }
 // the same into scratch: an intermediate product that is never multiplied with a vector
@@ -161,7 +163,9 @@ amgk::Mat row_product_scratch(Scratch &S, const amgk::RowProduct &P, int product
   const ProductPlan pl = product_rows(S, P, product, first_tier, rp);
   int *col = S.take<int>((size_t)pl.nnz);
   double *val = S.take<double>((size_t)pl.nnz);
+  S.zero_counter(1);
   amgk::product_fill(S.ctx->stream, P, product, pl.tier, rp, col, val, S.counters.p + 1);
+  if (S.read_counter(1) != 0) throw Error(-84, "AMG set-up: the fill of a row product found a row its count had not");
   return amgk::Mat{n, n_cols, rp, col, val};
 }
 

@@ -392,7 +392,8 @@ template <int H>
 __device__ inline int set_find(const int *tab, int cc) {   // cc is in the set
   constexpr int SHIFT = 32 - __builtin_ctz(H);
   unsigned h = ((unsigned)cc * 2654435761u) >> SHIFT;
-  while (tab[h] != cc) h = (h + 1) & (H - 1);
+  // (bounded: should count and fill ever disagree about a row, the fill writes a wrong entry instead of spinning for ever)
+  for (int probes = 0; probes < H && tab[h] != cc; ++probes) h = (h + 1) & (H - 1);
   return (int)h;
 }
 // the set as a list (any order); returns the number of distinct columns.  Called by all threads of the workgroup.

@@ -113,7 +113,10 @@ struct nsk_handle_s {
   // hand-offs (600x200: ILU(S) apply -30 %, ILU(F) -7 %), and cost where it is bandwidth-bound (1200x400: ILU(F) +8 %)
   static constexpr int kGroupRowsU = 4000000, kGroupRowsP = 1000000;
   const double *xy(int space) const {
-    if (!line_groups || support[space].empty()) return nullptr;
+    if (!line_groups || support[space].size() != 2 * (size_t)sp[space].n) return nullptr;
+    // line groups exist in the single-launch kernels only (the per-colour kernels do not know the chains): a handle that
+    // runs — or has fallen back to — one launch per colour orders its factors without them
+    if (sync_free_mode < (space == 0 ? 2 : 1)) return nullptr;
     if (line_groups == 2 && sp[space].n > (space == 0 ? kGroupRowsU : kGroupRowsP)) return nullptr;
     return support[space].data();
   }
@@ -130,6 +133,7 @@ struct nsk_handle_s {
   Amg amgF;                 // velocity AMG of the stationary block-triangular preconditioner
   int velocity_amg = 1;     // NSK_OPT_VELOCITY_AMG
   int schur_sign = 1;       // NSK_OPT_SCHUR_SIGN: +1 the reference's S = B D^-1 Bt, -1 the negated (SIMPLE's) one
+  int blas1_pairs = -1;     // NSK_OPT_BLAS1_PAIRS: -1 by variant (stationary on, unsteady off), 0, 1
   bool amg_active = false;  // the current setup preconditions F with amgF instead of tF
   // The hierarchy is built on first use: PreconditionAMG::initialize is called before every solve (NSSolverStationary.hpp:231),
   // also before the many solves of a Newton run that stop at step 0 without ever applying the preconditioner; building it
@@ -404,6 +408,7 @@ void H::schur_symbolic() {
 void H::setup(int type, int variant_, double alpha_) {
   if (type < 0 || type > 2) throw Error(-44, "Invalid preconditioner type. Use 0: blockDiagonal, 1: blockTriangular, 2: aSIMPLE.");
   ensure_pools();
+  ctx.ws.pairs = blas1_pairs < 0 ? (variant_ == 0) : blas1_pairs;   // NSK_OPT_BLAS1_PAIRS
   tMp.sync_free = tS.sync_free = sync_free_mode >= 1;
   tF.sync_free = sync_free_mode == 2;
   tMp.sf_fault = tS.sf_fault = (fault_inject & 1) != 0;
@@ -645,7 +650,8 @@ int H::solve_resident(int solver, double tol, int max_iter, int *iters, double *
     ++sync_free_fallbacks;
     ctx.warn("single-launch triangular solve: a producer/consumer wait ran out of spins (workgroups not resident in "
              "dispatch order: another process on the GPU?); the solve is redone from the caller's initial guess with one "
-             "launch per colour, and this handle keeps that slower path (NSK_OPT_TRI_SYNC_FREE = 0)");
+             "launch per colour — factors re-ordered WITHOUT line groups, which only the single-launch kernels know — and "
+             "this handle keeps that slower path (NSK_OPT_TRI_SYNC_FREE = 0)");
     setup(prec_type, variant, alpha);
     vec_copy(s(), N(), x_keep, x_b);
     outer_iters = undo;
@@ -856,6 +862,9 @@ int nsk_set_partition(nsk_handle h, int space, int64_t b, int64_t e, int n_ghost
   S.gbegin = b;
   S.gend = e;
   S.ghost_gid.assign(gids, gids + n_ghost);
+  // support points handed over for another row count are void (xy() would hand the ordering an array sized for it)
+  h->support[space].clear();
+  h->tF_ok = h->tMp_ok = h->tS_ok = false;
   return 0;
   NSK_CATCH(h)
 }
@@ -987,6 +996,11 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
     case NSK_IOPT_TINY_BYTES: h->tF.tiny_bytes = h->tMp.tiny_bytes = h->tS.tiny_bytes = v; break;
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
     case NSK_OPT_VELOCITY_AMG: h->velocity_amg = v != 0.0; break;
+    case NSK_OPT_BLAS1_PAIRS:
+      if (v != -1.0 && v != 0.0 && v != 1.0) throw Error(-61, "NSK_OPT_BLAS1_PAIRS: -1, 0 or 1");
+      h->blas1_pairs = (int)v;
+      h->ctx.ws.pairs = v < 0.0 ? (h->variant == 0) : (int)v;
+      break;
     case NSK_OPT_SCHUR_SIGN:
       if (v != 1.0 && v != -1.0) throw Error(-61, "NSK_OPT_SCHUR_SIGN: +1 or -1");
       h->schur_sign = (int)v;

@@ -352,6 +352,7 @@ void Ctx::init(int device_id) {
   NSK_HIP(hipMemsetAsync(ws_ticket.p, 0, sizeof(unsigned), stream));
   ws.partials = ws_partials.p;
   ws.ticket = ws_ticket.p;
+  ws.pairs = 1;   // (nsk_setup_preconditioner sets it by variant, NSK_OPT_BLAS1_PAIRS)
   d_scal.alloc(kSlots);
   NSK_HIP(hipMemsetAsync(d_scal.p, 0, sizeof(double) * kSlots, stream));
   NSK_HIP(hipHostMalloc((void **)&h_scal, sizeof(double) * kSlots, hipHostMallocDefault));

@@ -22,6 +22,7 @@ inline SRef sref(double c, const double *num, const double *den) { return SRef{c
 struct ReduceWs {
   double *partials;   // >= kMaxReduceBlocks * kMaxReduceOut
   unsigned *ticket;   // zero-initialised, reset by the last block
+  int pairs;          // host side only: 1 = reductions read pairs of entries through 16-byte loads (NSK_OPT_BLAS1_PAIRS)
 };
 constexpr int kMaxReduceBlocks = 512;
 constexpr int kMaxReduceOut = 8;

@@ -1521,16 +1521,16 @@ namespace {
 inline bool aligned16(const void *a, const void *b = nullptr, const void *c = nullptr, const void *d = nullptr) {
   return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15u) == 0;
 }
-bool blas1_pairs() {   // NSK_BLAS1_PAIRS=0 restores the 8-byte-per-lane kernels (A/B measurements)
-  static const bool on = [] { const char *e = getenv("NSK_BLAS1_PAIRS"); return !e || atoi(e) != 0; }();
-  return on;
+bool blas1_pairs(const ReduceWs &ws) {   // the handle's choice (NSK_OPT_BLAS1_PAIRS); NSK_BLAS1_PAIRS=0/1 overrides it (A/B measurements)
+  static const int forced = [] { const char *e = getenv("NSK_BLAS1_PAIRS"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  return forced >= 0 ? forced != 0 : ws.pairs != 0;
 }
 typedef const double2 *cd2;
 }  // namespace
 
 void vec_dot(hipStream_t s, const ReduceWs &ws, int n, const double *x, const double *y, double *out, int want_sqrt) {
   auto f1 = [=] __device__(int i) -> double { return x[i] * y[i]; };
-  if (blas1_pairs() && aligned16(x, y) && n >= 2) {
+  if (blas1_pairs(ws) && aligned16(x, y) && n >= 2) {
     NSK_RED2(n, ([=] __device__(int j) -> double {
                const double2 a = cd2(x)[j], b = cd2(y)[j];
                return a.x * b.x + a.y * b.y;
@@ -1541,7 +1541,7 @@ void vec_dot(hipStream_t s, const ReduceWs &ws, int n, const double *x, const do
 }
 void vec_axpy_dot(hipStream_t s, const ReduceWs &ws, int n, SRef a, const double *x, double *y, const double *w,
                   double *out, int want_sqrt) {
-  const bool pairs = blas1_pairs() && aligned16(x, y, w) && n >= 2;
+  const bool pairs = blas1_pairs(ws) && aligned16(x, y, w) && n >= 2;
   if (w == y) {
     auto f1 = [=] __device__(int i) -> double {
       const double v = y[i] + sval(a) * x[i];
@@ -1588,7 +1588,7 @@ void vec_cg_update(hipStream_t s, const ReduceWs &ws, int n, SRef a, const doubl
     g[i] = v;
     return v * v;
   };
-  if (blas1_pairs() && aligned16(d, h, x, g) && n >= 2) {
+  if (blas1_pairs(ws) && aligned16(d, h, x, g) && n >= 2) {
     NSK_RED2(n, ([=] __device__(int j) -> double {
                const double al = sval(a);
                const double2 dv = cd2(d)[j], hv = cd2(h)[j];
@@ -1759,7 +1759,7 @@ bool pack_aligned16(const double *w, const VecPack &P, int m) {
 }
 }  // namespace
 void vec_multi_dot(hipStream_t s, const ReduceWs &ws, int n, const double *w, const VecPack &P, int m, double *out) {
-  if (blas1_pairs() && n >= 2 && pack_aligned16(w, P, m)) {
+  if (blas1_pairs(ws) && n >= 2 && pack_aligned16(w, P, m)) {
 #define NSK_MD(M) case M: hipLaunchKernelGGL((multi_dot2_kernel<M>), dim3(red_grid((n + 1) / 2)), dim3(RBLK), 0, s, n, w, P, ws, out); break;
     switch (m) { NSK_MD(1) NSK_MD(2) NSK_MD(3) NSK_MD(4) NSK_MD(5) NSK_MD(6) NSK_MD(7) NSK_MD(8) default: break; }
 #undef NSK_MD
@@ -1771,7 +1771,8 @@ void vec_multi_dot(hipStream_t s, const ReduceWs &ws, int n, const double *w, co
 }
 void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const VecPack &P, int m, const double *h,
                     double *norm_out) {
-  if (blas1_pairs() && n >= 2 && pack_aligned16(w, P, m)) {
+  // (without the norm the update is entry by entry: the same bits in pairs, whatever the handle chose for the sums)
+  if ((!norm_out || blas1_pairs(ws)) && n >= 2 && pack_aligned16(w, P, m)) {
 #define NSK_MA(M)                                                                                                \
   case M:                                                                                                        \
     if (norm_out) hipLaunchKernelGGL((multi_axpy2_kernel<M, true>), dim3(red_grid((n + 1) / 2)), dim3(RBLK), 0, s, n, w, P, h, ws, norm_out); \

@@ -1,7 +1,10 @@
 // nsk_tri.cpp — host symbolic analysis + device numeric/apply of ILU(0) and SGS.
 #include "nsk_tri.hpp"
 
+#include <omp.h>
+
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 
@@ -335,8 +338,17 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   kind = kind_;
   ordering = ordering_;
   if ((int)A.h_rowptr.size() != n + 1) throw Error(-30, "TriSolve::analyze: host pattern missing");
+  static const bool chatty = [] { const char *e = getenv("NSK_VERBOSE"); return e && atoi(e) != 0; }();
+  double t_last = omp_get_wtime();
+  auto tick = [&](const char *what) {   // NSK_VERBOSE=1: where the host-side analysis spends its time
+    if (!chatty) return;
+    const double t = omp_get_wtime();
+    fprintf(stderr, "[nsk]   analysis: %-30s %9.1f ms\n", what, 1e3 * (t - t_last));
+    t_last = t;
+  };
   TriOrdering O;
   O.build(n, A.h_rowptr.data(), A.h_col.data(), ordering, sub_off, want_block2, xy, group);
+  tick("ordering (colouring)");
   nnz = O.nnz;
   n_colors = O.n_colors;
   gmax = O.gmax;
@@ -391,6 +403,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   max_row_nnz = maxw;
   if (max_row_nnz > 448) throw Error(-32, "TriSolve::analyze: row too long for the LDS-staged ILU kernel");
 
+  tick("permuted pattern");
   // level schedule of the lower and upper dependency DAGs
   std::vector<int> levL(n, 0), levU(n, 0);
   n_levels_L = n_levels_U = 0;
@@ -436,6 +449,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   lpr = mean_half <= 6 ? 4 : (mean_half <= 14 ? 8 : (mean_half <= 48 ? 16 : 32));
 
   hipStream_t s = ctx->stream;
+  tick("level schedule");
   block2_ready = false;
   stream_ready = false;
   sf_armed = false;
@@ -645,6 +659,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       stream_ready = true;
     }
   }
+  tick("split factors, runs, uploads");
   // Natural ordering: per-(pass, wavefront) records for the LDS-ring solve (nsk_kernels.h).  A pass = at most kRingRows
   // rows of one level (independent), sorted by length; positions = the order the passes walk the rows in; an entry names
   // the ring slot of its column's POSITION.
@@ -796,6 +811,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     ring_ready = plan_ring(levL, true, PL) && plan_ring(levU, false, PU) && build_ring(PL, PU, true, ringL) &&
                  build_ring(PU, PL, false, ringU);
   }
+  if (ring_ready) tick("ring records");
   rowptr.upload(prp, s);
   col.upload(pcol, s);
   srcpos.upload(psrc, s);
@@ -808,6 +824,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   val.alloc((size_t)nnz);
   y.alloc((size_t)n + 1);
   ctx->sync();  // host staging vectors die at scope exit
+  tick("combined factor upload");
 }
 
 

@@ -32,6 +32,7 @@ OPT_CG_SINGLE_REDUCTION = 11
 IOPT_TRI_X_LAYOUT, IOPT_FAULT_INJECT, IOPT_TINY_BYTES = 6, 100, 102
 OPT_TRI_LINE_GROUPS, IOPT_GROUP_U, IOPT_GROUP_P = 12, 103, 104
 OPT_MASS_ORDERING = 13
+OPT_BLAS1_PAIRS = 15  # 16-byte loads in the reductions: 1 / 0 / -1 (default: stationary on, unsteady off), see include/nsk.h
 OPT_SCHUR_SIGN = 14   # +1 the reference's S (default); -1: labelled deviation, see include/nsk.h
 IOPT_FUSED_MGS, IOPT_OVERLAP_HALO = 106, 107
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1

@@ -188,3 +188,75 @@ def test_drivers_on_two_ranks_follow_the_one_rank_run(tmp_path, monkeypatch, dri
     stem = "output-stokes_0" if driver == "StationaryNSSolver" else "output_001"
     assert all(os.path.exists(tmp_path / "r2" / f"{stem}.{r}.vtu") for r in range(2))
     assert os.path.exists(tmp_path / "r2" / f"{stem}.pvtu")
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _torchrun_cli(nproc, driver, args, outdir, timeout=600):
+    """`mpirun -n N <driver> ...` of the reference = one process per rank under torch.distributed.run; started BEFORE this
+    process touches a GPU (a child process: nothing is exec'ed over an initialised one)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NSK_OUTPUT_DIR=str(outdir), PYTHONPATH=root)
+    env.pop("NSK_RANKS", None)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                           "-m", "navier_stokes_solver_amd.cli", driver] + args,
+                          capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("driver,args", [("StationaryNSSolver", ["-m", "16,10", "-r", "30", "-s", "1", "-p", "2", "-t", "1e-10"]),
+                                         ("NSSolver", ["-T", "0.02,0.01", "-m", "16,10", "-r", "1", "-s", "1", "-p", "2", "-t", "1e-10"])])
+def test_process_per_rank_driver_with_one_process_follows_the_plain_run(tmp_path, monkeypatch, driver, args):
+    """The drivers as ONE PROCESS PER RANK (torch.distributed.run: gloo control plane, RCCL data path — cli.run_processes),
+    world size 1 on this box's one GPU: the collectives of the whole Newton / time loop go through a real (one-rank) RCCL
+    communicator.  Newton residuals and coefficients against the plain in-process run of the same command."""
+    import re
+    d1, d2 = tmp_path / "plain", tmp_path / "torchrun"
+    d1.mkdir()
+    d2.mkdir()
+    res = _torchrun_cli(1, driver, args, d2)
+    assert res.returncode == 0, res.stderr[-3000:]
+    monkeypatch.setenv("NSK_OUTPUT_DIR", str(d1))
+    out = io.StringIO()
+    with redirect_stdout(out):
+        assert cli.main([driver] + args) == 0
+    assert "Number of ranks            = 1" in res.stdout
+    pat = r"Newton iteration \d+/\d+ - \|\|r\|\| = ([0-9.e+-]+)"
+    a, b = [float(v) for v in re.findall(pat, out.getvalue())], [float(v) for v in re.findall(pat, res.stdout)]
+    assert len(a) == len(b) >= 3
+    for x, y in zip(a, b):
+        assert abs(x - y) <= 1e-6 * x + 1e-9, (x, y)
+    for key in ("Lift coefficient:", "Drag coefficient:"):
+        ca = [float(v) for v in re.findall(key + r" ([0-9.e+-]+)", out.getvalue())]
+        cb = [float(v) for v in re.findall(key + r" ([0-9.e+-]+)", res.stdout)]
+        assert len(ca) == len(cb) >= 1 and all(abs(x - y) <= 1e-6 * max(1.0, abs(x)) for x, y in zip(ca, cb)), (key, ca, cb)
+
+
+@pytest.mark.gpu
+def test_process_per_rank_driver_on_two_gpus(tmp_path):
+    """`mpirun -n 2 StationaryNSSolver` as two processes on two GPUs over RCCL; skipped where fewer than two GPUs are visible
+    (everywhere so far: the development boxes have one)."""
+    import re
+
+    import torch
+    if torch.cuda.device_count() < 2:       # (device_count() does not initialise the GPU on this image)
+        pytest.skip("needs two GPUs")
+    args = ["-m", "16,10", "-r", "30", "-s", "1", "-p", "2", "-t", "1e-10"]
+    one, two = tmp_path / "n1", tmp_path / "n2"
+    one.mkdir()
+    two.mkdir()
+    r1, r2 = _torchrun_cli(1, "StationaryNSSolver", args, one), _torchrun_cli(2, "StationaryNSSolver", args, two)
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr[-2000:], r2.stderr[-2000:])
+    pat = r"Newton iteration \d+/\d+ - \|\|r\|\| = ([0-9.e+-]+)"
+    a, b = [float(v) for v in re.findall(pat, r1.stdout)], [float(v) for v in re.findall(pat, r2.stdout)]
+    assert len(a) == len(b) >= 3 and all(abs(x - y) <= 1e-6 * x + 1e-9 for x, y in zip(a, b))
+    assert "Number of ranks            = 2" in r2.stdout

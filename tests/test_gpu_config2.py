@@ -32,7 +32,8 @@ def test_config2_converges_to_the_direct_solution():
         # velocity / pressure against J^-1 r.  What a residual of 1e-10 leaves of the error depends on the residual's
         # direction, i.e. on the ordering of the ILU factors (0.9e-7 with single-DoF colours, 1.14e-7 with line groups):
         # the figure to hold is that the error FOLLOWS the residual — a tenth of the residual, a tenth of the error
-        assert err <= 3e-7, err
+        print(f"config 2: relative error against the direct solution {err:.3e} at residual {np.linalg.norm(b - J @ x):.2e}")
+        assert err <= 1.5e-7, err
         assert 100 <= its <= 5000, its
         hist = ls.history()
         assert len(hist) >= its and hist[-1] <= 1e-10 and hist[0] > 1e-3

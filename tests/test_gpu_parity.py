@@ -119,6 +119,41 @@ def test_ilu_apply(handles, name, ordering, subdomains):
         assert 0 < c <= 64 and st["n_levels_u"] in (c, 2 * c, 3 * c, 4 * c, 6 * c)
 
 
+def test_line_groups_are_dropped_where_the_per_colour_kernels_run():
+    """with NSK_OPT_TRI_SYNC_FREE = 0 (also: after the fallback of a single-launch solve) a factor ordered with
+    line groups would fall to the generic level walker — the per-colour kernels do not know the chains.  Such a handle
+    orders its factors WITHOUT groups instead: the colour counts are those of the plain colouring, the applies run the
+    per-colour stream kernels and agree with the oracle under the library's permutation."""
+    S, O = _S(), _O()
+    import scipy.sparse as sp
+    pr = problem("ns60")
+    ls = S.LinearSolver()
+    try:
+        ls.set_option(S.OPT_TRI_ORDERING, 1)
+        ls.set_option(S.OPT_TRI_LINE_GROUPS, 1)
+        ls.set_option(S.OPT_TRI_SYNC_FREE, 0)
+        ls.set_option(S.IOPT_TINY_BYTES, 0)
+        ls.set_problem(pr)
+        ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+        st = ls.stats()
+        assert st["n_colors_u"] >= 16 and st["n_colors_p"] >= 26, (st["n_colors_u"], st["n_colors_p"])   # (12 / 17-18 with groups)
+        assert st["n_levels_u"] == 2 * st["n_colors_u"]            # node colouring: two dependent rows per node, no chains
+        rp, col, val = ls.get_block(S.BLK_S)
+        Sm = sp.csr_matrix((val, col, rp), shape=(pr.n_p, pr.n_p))
+        triF = O.Tri(O.CsrHolder.from_block(pr.F), kind=0, perm=ls.tri_perm(S.TRI_VELOCITY))
+        triS = O.Tri(O.CsrHolder.from_scipy(Sm), kind=0, perm=ls.tri_perm(S.TRI_PRESSURE))
+        bu, bp = rng_vec(pr.n_u, 77), rng_vec(pr.n_p, 78)
+        assert rel_err(ls.tri_apply(S.TRI_VELOCITY, bu), triF.apply(bu)) <= 1e-11
+        assert rel_err(ls.tri_apply(S.TRI_PRESSURE, bp), triS.apply(bp)) <= 1e-11
+        # the same handle with the single-launch solves switched on again: groups are back
+        ls.set_option(S.OPT_TRI_SYNC_FREE, 2)
+        ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY)
+        st = ls.stats()
+        assert st["n_colors_u"] <= 13 and st["n_colors_p"] <= 22, (st["n_colors_u"], st["n_colors_p"])
+    finally:
+        ls.close()
+
+
 @pytest.mark.parametrize("group_u,group_p,subdomains", [(2, 3, 1), (3, 2, 1), (1, 3, 1), (2, 1, 1), (2, 3, 3)])
 def test_line_group_sizes_in_the_single_launch_solves(group_u, group_p, subdomains):
     """Every chain length of the single-launch kernels (tri_blk_sf_kernel / tri_stream_sf_kernel<..., GMAX = 1, 2, 3>):

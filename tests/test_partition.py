@@ -226,7 +226,8 @@ def test_a_failing_rank_does_not_leave_its_peers_waiting(where):
     assert not any(t.is_alive() for t in th), ("rank threads still blocked", outcome)
     assert time.time() - t0 < 100
     assert "finished" not in outcome, outcome
-    assert all("aborted" in outcome[r] for r in (0, 2)), outcome      # error -25's text
+    # error -25's text — or, for peers that were still joining the group inside nsk_create, that call's failure
+    assert all("aborted" in outcome[r] or "nsk_create failed" in outcome[r] for r in (0, 2)), outcome
 
 
 @pytest.mark.gpu
