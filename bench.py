@@ -86,10 +86,16 @@ def parse():
     ap.add_argument("--line-groups", type=int, default=2,
                     help="NSK_OPT_TRI_LINE_GROUPS: 1 colour pairs of velocity nodes / triples of pressure DoFs along the lattice "
                          "lines in the triangular factors' orderings (fewer colours), 0 colour single DoFs, 2 (default) by size")
+    ap.add_argument("--schur-sign", type=int, default=1,
+                    help="NSK_OPT_SCHUR_SIGN of the --converge solve ONLY: -1 negates aSIMPLE's S (labelled deviation from the "
+                         "reference, off by default; the timed region always runs the reference's +1)")
+    ap.add_argument("--blas1-pairs", type=int, default=-1, help="NSK_OPT_BLAS1_PAIRS: -1 by variant (default), 0, 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-mesh", type=str, default="",
                     help="mesh of the CPU baseline's first sample; default: the bench mesh itself (1200,400 at N = 1)")
-    ap.add_argument("--cpu-steps", type=int, default=3, help="outer iterations of the CPU baseline's first sample")
+    ap.add_argument("--cpu-steps", type=int, default=1,
+                    help="outer iterations of the CPU baseline's first sample (the oracle needs ~60-90 s for ONE at 1200x400 on "
+                         "16 cores; three took 277 s, profiles/r04_bench_line_K20_cpu_sample_K3.json)")
     ap.add_argument("--cpu-mesh2", type=str, default="300,100", help="second, smaller CPU sample ('' = none)")
     ap.add_argument("--cpu-steps2", type=int, default=12)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
@@ -145,6 +151,7 @@ def make_solver(S, PT, P, dist, args, nx, ny, nu, inv_dt, world, rank, local_ran
     ls.set_option(S.OPT_TRI_LINE_GROUPS, args.line_groups)
     ls.set_option(S.OPT_CG_SINGLE_REDUCTION, int(args.cg_single_reduction if args.cg_single_reduction >= 0 else world > 1))
     ls.set_option(S.OPT_INNER_FUSED_GS, int(args.inner_gs if args.inner_gs >= 0 else (2 if world > 1 else 1)))
+    ls.set_option(S.OPT_BLAS1_PAIRS, args.blas1_pairs)
     t0 = time.time()
     ls.set_problem(pr, plan)
     say(f"blocks on the device ({time.time() - t0:.1f} s)")
@@ -222,6 +229,8 @@ def converged_solve(S, PT, P, dist, args, world, rank, local_rank, sync):
     nu = P.reynolds_to_nu(100.0, stationary=True)
     ls, pr, n_global, _, _ = make_solver(S, PT, P, dist, args, nx, ny, nu, 0.0, world, rank, local_rank)
     prec = args.converge_preconditioner
+    if args.schur_sign != 1:
+        ls.set_option(S.OPT_SCHUR_SIGN, args.schur_sign)
     ls.setup_preconditioner(prec, 0, 0.5)
     ls.upload_system(pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
     sync()
@@ -246,11 +255,13 @@ def converged_solve(S, PT, P, dist, args, world, rank, local_rank, sync):
     sync()
     dt = time.perf_counter() - t0
     done.set()
-    out = {"workload": f"stationary {nx}x{ny} Re=100 (nu=1/90) Newton system, {NAMES_S[args.solver]} + {NAMES_P[prec]}",
+    out = {"workload": f"stationary {nx}x{ny} Re=100 (nu=1/90) Newton system, {NAMES_S[args.solver]} + {NAMES_P[prec]}"
+                       + ("" if args.schur_sign == 1 else " with NSK_OPT_SCHUR_SIGN = -1 (S negated: a LABELLED DEVIATION from the reference)"),
+           "schur_sign": args.schur_sign,
            "dofs": n_global, "tol": args.converge, "iters": its, "final_res": res, "status": rc, "seconds": dt,
            "cancelled_after_budget_s": args.converge_budget if cancelled[0] else None,
            "dof_iters_per_s": n_global * its / dt}
-    if world == 1 and rc == 0 and n_global <= 1_000_000:
+    if world == 1 and rc == 0 and n_global <= 20_000_000:
         xu, xp = ls.download_solution()
         J = pr.jacobian_scipy()
         out["true_residual"] = float(np.linalg.norm(np.concatenate([pr.rhs_u, pr.rhs_p]) - J @ np.concatenate([xu, xp])))
@@ -448,6 +459,8 @@ def main():
                                                                       else world > 1) else "deal.II recurrence",
                 "inner_gram_schmidt": ["modified", "fused classical", "fused classical, one reduction per iteration"][
                     int(args.inner_gs if args.inner_gs >= 0 else (2 if world > 1 else 1))],
+                "blas1_reductions": "16-byte loads (pairs)" if (args.blas1_pairs if args.blas1_pairs >= 0 else int(args.variant == 0))
+                                    else "8-byte loads",
             },
             "roofline": {
                 "bound": "hbm", "kernel": D["kernel"], "time_share": D["time_share"],

@@ -88,7 +88,43 @@ template <int VEC>
 __device__ __forceinline__ void stream_products(const int *__restrict__ col, const double *__restrict__ val, int k0,
                                                 int k1, int n_own, const double *__restrict__ xo,
                                                 const double *__restrict__ xg, double *prod) {
-  if (VEC == 2) {
+  if (VEC == 3) {
+    // pairs of consecutive entries through one 8-byte index load and one 16-byte value load, lanes on CONSECUTIVE pairs
+    // (as VEC == 2, which needs every row pointer even; here the loads are only 4- / 8-byte aligned).  Half the
+    // streaming instructions of the entry-by-entry form.  (Eight consecutive entries per thread — two 16-byte index and
+    // four 16-byte value loads — were measured on the triangular kernel and are SLOWER, 0.46 -> 0.64 ms per ILU(S)
+    // apply: an instruction whose lanes sit 64 bytes apart touches 32 lines instead of 8.)
+    constexpr int U = kStreamNnz / (2 * BLK);
+    typedef int vi2 __attribute__((ext_vector_type(2)));
+    typedef double vd2 __attribute__((ext_vector_type(2)));
+    typedef vi2 vi2u __attribute__((aligned(4)));
+    typedef vd2 vd2u __attribute__((aligned(8)));
+    int c0[U], c1[U];
+    double v0[U], v1[U], x0[U], x1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 2 * ((int)threadIdx.x + u * BLK);
+      if (k + 1 < k1) {
+        const vi2 ci = *reinterpret_cast<const vi2u *>(col + k);
+        const vd2 vi = *reinterpret_cast<const vd2u *>(val + k);
+        c0[u] = ci[0]; c1[u] = ci[1]; v0[u] = vi[0]; v1[u] = vi[1];
+      } else {   // the run's odd last entry (nothing may be read behind it), or nothing
+        const bool ok = k < k1;
+        c0[u] = ok ? col[k] : 0; v0[u] = ok ? val[k] : 0.0; c1[u] = 0; v1[u] = 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      x0[u] = *(c0[u] < n_own ? xo + c0[u] : xg + (c0[u] - n_own));
+      x1[u] = *(c1[u] < n_own ? xo + c1[u] : xg + (c1[u] - n_own));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 2 * ((int)threadIdx.x + u * BLK);
+      if (k < k1) prod[k - k0] = v0[u] * x0[u];
+      if (k + 1 < k1) prod[k - k0 + 1] = v1[u] * x1[u];
+    }
+  } else if (VEC == 2) {
     constexpr int U = kStreamNnz / (2 * BLK);
     int2 c[U];
     double2 v[U];
@@ -471,7 +507,12 @@ __device__ __forceinline__ double sf_wait(const double *p, unsigned long long fi
   return __longlong_as_double((long long)v);
 }
 
-template <int LOWER, int KIND, int NNZ, int GMAX>
+// WIDE = 2 (study switch NSK_TRI_WIDE): a lane takes PAIRS of consecutive entries (one 8-byte index load + one 16-byte value
+// load per pair, lanes on consecutive pairs) instead of one 4- / 8-byte load per entry — half the streaming instructions;
+// the products land in the same LDS words, the row sums read them in the same order: same bits.  Round 4 also measured a
+// thread taking its 8 entries CONSECUTIVELY (two 16-byte index + four 16-byte value loads): ILU(S) apply 0.459 -> 0.637 ms
+// at 1200x400, lanes 32 / 64 bytes apart touch four times the lines per instruction; removed again.
+template <int LOWER, int KIND, int NNZ, int GMAX, int WIDE>
 __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const int4 *__restrict__ desc, int nb, int wrong_order,
                                                             const double *__restrict__ dinv,
                                                             const int *__restrict__ perm,
@@ -509,16 +550,35 @@ __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const 
     unsigned o[U];   // byte offset of the gathered entry (32 bits on top of the uniform base)
     unsigned open = 0;   // bit u: entry u still shows the sentinel
     const char *wb = reinterpret_cast<const char *>(w);
+    // entry u of this thread is entry idx(u) of the run
+    const int tb = (int)threadIdx.x;
+    auto idx = [&](int u) { return WIDE == 2 ? 2 * (tb + (u >> 1) * BLK) + (u & 1) : tb + u * BLK; };
     {
       double v[U];
       unsigned long long g[U];
+      if (WIDE == 2) {
+        // pairs of consecutive entries, lanes on consecutive pairs: U / 2 index loads of 8 bytes + U / 2 value loads of 16
+        typedef int vi2 __attribute__((ext_vector_type(2)));
+        typedef double vd2 __attribute__((ext_vector_type(2)));
+        typedef vi2 vi2u __attribute__((aligned(4)));
+        typedef vd2 vd2u __attribute__((aligned(8)));
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        // loads without branches or arithmetic on their results: all 2 U stay in flight.  A tail lane re-reads the
-        // run's first entry and is masked out below
-        const int k = k0 + (int)threadIdx.x + u * BLK, kk = k < k1 ? k : kz;
-        o[u] = (unsigned)__builtin_nontemporal_load(colp + kk);
-        v[u] = __builtin_nontemporal_load(valp + kk);
+        for (int c = 0; c < U / 2; ++c) {
+          const int k = k0 + 2 * (tb + c * BLK), kk = (any && k < k1) ? k : kz;   // (the arrays end with spare entries)
+          const vi2 q = __builtin_nontemporal_load(reinterpret_cast<const vi2u *>(colp + kk));
+          const vd2 t = __builtin_nontemporal_load(reinterpret_cast<const vd2u *>(valp + kk));
+          o[2 * c] = (unsigned)q[0]; o[2 * c + 1] = (unsigned)q[1];
+          v[2 * c] = t[0]; v[2 * c + 1] = t[1];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          // loads without branches or arithmetic on their results: all 2 U stay in flight.  A tail lane re-reads the
+          // run's first entry and is masked out below
+          const int k = k0 + (int)threadIdx.x + u * BLK, kk = k < k1 ? k : kz;
+          o[u] = (unsigned)__builtin_nontemporal_load(colp + kk);
+          v[u] = __builtin_nontemporal_load(valp + kk);
+        }
       }
       // row bounds, perm and the row's own right-hand side (which hangs on perm[r]) are asked for AFTER the streaming
       // loads have been issued, so that no wait stands between the descriptor and the stream: three dependent trips
@@ -545,9 +605,11 @@ __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const 
       // matrix value in the same LDS word, so that only its offset stays in registers while it is polled
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int k = (int)threadIdx.x + u * BLK;
+        const int k = idx(u);
         const bool op = g[u] == kSentinel && k < k1 - k0;
         open |= op ? 1u << u : 0u;
+        // (WIDE: unconditional, so that a thread's consecutive words go out as 16-byte LDS stores; words behind the run's
+        //  last entry are never read)
         if (k < k1 - k0) prod[k] = op ? v[u] : v[u] * __longlong_as_double((long long)g[u]);
       }
     }
@@ -561,7 +623,7 @@ __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const 
       if (!sf_keep_polling(spins, err)) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          if (open >> u & 1u) prod[(int)threadIdx.x + u * BLK] = __longlong_as_double((long long)kSentinel);
+          if (open >> u & 1u) prod[idx(u)] = __longlong_as_double((long long)kSentinel);
         break;
       }
       unsigned long long t[U];
@@ -571,7 +633,7 @@ __global__ __launch_bounds__(BLK, 8) void tri_stream_sf_kernel(TriHalf M, const 
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if ((open >> u & 1u) && t[u] != kSentinel) {
-          prod[(int)threadIdx.x + u * BLK] *= __longlong_as_double((long long)t[u]);
+          prod[idx(u)] *= __longlong_as_double((long long)t[u]);
           open &= ~(1u << u);
         }
     }
@@ -1276,7 +1338,11 @@ void spmv_stream(hipStream_t s, const CsrView &A, const int *rowblk, int nblk, i
                  const double *xg, double *y, int mode, const double *z) {
   if (nblk <= 0) return;
 #define NSK_SS(V, M) hipLaunchKernelGGL((spmv_stream_kernel<V, M>), dim3(nblk), dim3(BLK), 0, s, A, rowblk, xo, xg, y, z)
-  if (even_rows) {
+  // NSK_SPMV_WIDE=1: unaligned pairs where the row pointers are not all even (study switch, A/B measurements)
+  static const bool wide = [] { const char *e = getenv("NSK_SPMV_WIDE"); return e && atoi(e) != 0; }();
+  if (wide && !even_rows) {
+    if (mode == 0) NSK_SS(3, 0); else if (mode == 1) NSK_SS(3, 1); else NSK_SS(3, 2);
+  } else if (even_rows) {
     if (mode == 0) NSK_SS(2, 0); else if (mode == 1) NSK_SS(2, 1); else NSK_SS(2, 2);
   } else {
     if (mode == 0) NSK_SS(1, 0); else if (mode == 1) NSK_SS(1, 1); else NSK_SS(1, 2);
@@ -1420,7 +1486,13 @@ void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int
                          const double *dinv, const int *perm, const double *rhs, const double *own, double *w,
                          double *reset, int *err, long long *dbg, TriChain ch) {
   if (nb <= 0) return;
-#define NSK_SF(L, K, N, G) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N, G>), dim3(nb), dim3(BLK), 0, s, M, M.desc, nb, wrong_order, dinv, perm, rhs, own, w, reset, err, dbg, ch.chain, ch.cpl)
+  // NSK_TRI_WIDE (study switch): 0 (default) one 4- / 8-byte load per entry; 2: pairs of consecutive entries per lane
+  static const int wide = [] { const char *e = getenv("NSK_TRI_WIDE"); return e ? atoi(e) : 0; }();
+#define NSK_SF(L, K, N, G)                                                                                                  \
+  do {                                                                                                                      \
+    if (wide == 2) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N, G, 2>), dim3(nb), dim3(BLK), 0, s, M, M.desc, nb, wrong_order, dinv, perm, rhs, own, w, reset, err, dbg, ch.chain, ch.cpl); \
+    else hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N, G, 0>), dim3(nb), dim3(BLK), 0, s, M, M.desc, nb, wrong_order, dinv, perm, rhs, own, w, reset, err, dbg, ch.chain, ch.cpl);          \
+  } while (0)
 #define NSK_SFG(L, K, N)                                   \
   do {                                                     \
     if (ch.gmax <= 1) NSK_SF(L, K, N, 1);                  \

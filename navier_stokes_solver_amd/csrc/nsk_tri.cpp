@@ -645,10 +645,16 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       const std::vector<int4> lsf = sf_dispatch_order(ld, LB, true), usf = sf_dispatch_order(ud, UB, false);
       n_Lsf = (int)lsf.size();
       n_Usf = (int)usf.size();
+      // (8 spare entries behind the index and value arrays: the wide loads of the single-launch kernels take a thread's 8
+      //  consecutive entries at once and may read past a run's — the array's — last one)
+      lcol.resize(lcol.size() + 8, 0);
+      ucol.resize(ucol.size() + 8, 0);
       Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Ldesc.upload(ld, s); Lsf.upload(lsf, s);
       Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Udesc.upload(ud, s); Usf.upload(usf, s);
-      Lval.alloc((size_t)nnzL);
-      Uval.alloc((size_t)nnzU);
+      Lval.alloc((size_t)nnzL + 8);
+      Uval.alloc((size_t)nnzU + 8);
+      NSK_HIP(hipMemsetAsync(Lval.p + nnzL, 0, 8 * sizeof(double), s));
+      NSK_HIP(hipMemsetAsync(Uval.p + nnzU, 0, 8 * sizeof(double), s));
       dinv.alloc((size_t)n);
       if (grouped) {
         chain.upload(hchain, s);
@@ -700,8 +706,10 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
           const int o = (int)P.order.size();
           P.pass_first.push_back(o);
           P.order.insert(P.order.end(), lr.begin() + b, lr.begin() + b + cnt);
-          // longest rows first (ties: row order), and a wavefront's chunk is padded to its longest row: rows of one
-          // length get wavefronts of their own while the pass has wavefronts to spare
+          // longest rows first (ties: row order); a wavefront's chunk is padded to its longest row.  Rows of one length CAN
+          // get wavefronts of their own while the pass has wavefronts to spare (NSK_RING_BY_CLASS=1: no padding at all) —
+          // measured slower, 2.86 against 2.79 ms per application at 600x200: seven thinly filled wavefronts per level
+          // issue more loads than five full ones, and the loads are what a level costs
           std::stable_sort(P.order.begin() + o, P.order.end(), [&](int x, int y) { return regs_of(x) > regs_of(y); });
           int waves_by_class = 0;
           for (int p = o; p < o + cnt;) {
@@ -710,7 +718,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
             waves_by_class += (e - p + kRingRowsPerWave - 1) / kRingRowsPerWave;
             p = e;
           }
-          static const bool want_by_class = [] { const char *e = getenv("NSK_RING_BY_CLASS"); return !e || atoi(e) != 0; }();
+          static const bool want_by_class = [] { const char *e = getenv("NSK_RING_BY_CLASS"); return e && atoi(e) != 0; }();
           const bool by_class = want_by_class && waves_by_class <= kRingWaves;
           int p = o;
           for (int w = 0; w < kRingWaves; ++w) {
