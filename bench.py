@@ -397,7 +397,7 @@ def main():
         value = n_global * args.steps / dt
         lu, lp = st["n_colors_u"] or st["n_levels_u"], st["n_colors_p"] or st["n_levels_p"]
         names = {0: "spmv_blk_kernel<2,2>: SpMV with F (inner FGMRES), 2x2 node blocks",
-                 3: "spmv_stream_kernel<1,0>: SpMV with Mp (inner CG)", 5: "spmv_stream_kernel<1,0>: SpMV with S (inner CG)",
+                 3: "spmv_stream_kernel<3,0>: SpMV with Mp (inner CG), pairs of entries per lane", 5: "spmv_stream_kernel<3,0>: SpMV with S (inner CG), pairs of entries per lane",
                  20: (f"tri_blk_kernel: ILU(0)/SGS apply on F ({lu}+{lu} node-colour level launches "
                       "of one apply)" if args.sync_free != 2 else
                       "tri_blk_sf_kernel: ILU(0)/SGS apply on F (one launch per half, in-kernel hand-off)"),
@@ -423,7 +423,7 @@ def main():
         import hashlib
         ksrc = [os.path.join(ROOT, "navier_stokes_solver_amd", "csrc", f) for f in ("nsk_kernels.hip", "nsk_tri.cpp")]
         sha_now = hashlib.sha256(b"".join(open(f, "rb").read() for f in ksrc)).hexdigest()
-        for pmc_name in ("r03_pmc_traffic_1200x400.json", "r02_pmc_traffic_1200x400.json"):
+        for pmc_name in ("r04_pmc_traffic_1200x400.json", "r03_pmc_traffic_1200x400.json", "r02_pmc_traffic_1200x400.json"):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if (nx, ny, world, args.lx) == (1200, 400, 1, 2.2) and os.path.exists(pmc):
                 rec = json.load(open(pmc))

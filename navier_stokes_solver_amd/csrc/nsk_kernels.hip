@@ -507,7 +507,7 @@ __device__ __forceinline__ double sf_wait(const double *p, unsigned long long fi
   return __longlong_as_double((long long)v);
 }
 
-// WIDE = 2 (study switch NSK_TRI_WIDE): a lane takes PAIRS of consecutive entries (one 8-byte index load + one 16-byte value
+// WIDE = 2 (default; NSK_TRI_WIDE=0 switches back): a lane takes PAIRS of consecutive entries (one 8-byte index load + one 16-byte value
 // load per pair, lanes on consecutive pairs) instead of one 4- / 8-byte load per entry — half the streaming instructions;
 // the products land in the same LDS words, the row sums read them in the same order: same bits.  Round 4 also measured a
 // thread taking its 8 entries CONSECUTIVELY (two 16-byte index + four 16-byte value loads): ILU(S) apply 0.459 -> 0.637 ms
@@ -1338,8 +1338,9 @@ void spmv_stream(hipStream_t s, const CsrView &A, const int *rowblk, int nblk, i
                  const double *xg, double *y, int mode, const double *z) {
   if (nblk <= 0) return;
 #define NSK_SS(V, M) hipLaunchKernelGGL((spmv_stream_kernel<V, M>), dim3(nblk), dim3(BLK), 0, s, A, rowblk, xo, xg, y, z)
-  // NSK_SPMV_WIDE=1: unaligned pairs where the row pointers are not all even (study switch, A/B measurements)
-  static const bool wide = [] { const char *e = getenv("NSK_SPMV_WIDE"); return e && atoi(e) != 0; }();
+  // pairs of entries per lane also where the row pointers are not all even (S: 0.271 -> 0.264 ms at 1200x400);
+  // NSK_SPMV_WIDE=0: one entry per load there, as in rounds 1-3 (A/B measurements)
+  static const bool wide = [] { const char *e = getenv("NSK_SPMV_WIDE"); return !e || atoi(e) != 0; }();
   if (wide && !even_rows) {
     if (mode == 0) NSK_SS(3, 0); else if (mode == 1) NSK_SS(3, 1); else NSK_SS(3, 2);
   } else if (even_rows) {
@@ -1486,8 +1487,9 @@ void tri_stream_syncfree(hipStream_t s, const TriHalf &M, int nb, int lower, int
                          const double *dinv, const int *perm, const double *rhs, const double *own, double *w,
                          double *reset, int *err, long long *dbg, TriChain ch) {
   if (nb <= 0) return;
-  // NSK_TRI_WIDE (study switch): 0 (default) one 4- / 8-byte load per entry; 2: pairs of consecutive entries per lane
-  static const int wide = [] { const char *e = getenv("NSK_TRI_WIDE"); return e ? atoi(e) : 0; }();
+  // pairs of consecutive entries per lane (ILU(S) apply 0.449 -> 0.422 ms at 1200x400, same bits); NSK_TRI_WIDE=0: one 4- /
+  // 8-byte load per entry, the kernels of rounds 1-3 (A/B measurements)
+  static const int wide = [] { const char *e = getenv("NSK_TRI_WIDE"); return e ? atoi(e) : 2; }();
 #define NSK_SF(L, K, N, G)                                                                                                  \
   do {                                                                                                                      \
     if (wide == 2) hipLaunchKernelGGL((tri_stream_sf_kernel<L, K, N, G, 2>), dim3(nb), dim3(BLK), 0, s, M, M.desc, nb, wrong_order, dinv, perm, rhs, own, w, reset, err, dbg, ch.chain, ch.cpl); \

@@ -16,7 +16,7 @@ CLASSES = [  # (label, substring(s) of the kernel name, launches per unit, op id
     ("vec_axpy (calibration)", ["vec_axpy"], 1, None),
     ("vec_dot (calibration)", ["vec_dot"], 1, None),
     ("spmv_blk_kernel<2,2> on F", ["spmv_blk_kernel<2, 2>"], 1, 0),
-    ("spmv_stream_kernel<1,0> on S", ["spmv_stream_kernel<1, 0>"], 1, 5),
+    ("spmv_stream_kernel on S", ["spmv_stream_kernel<1, 0>", "spmv_stream_kernel<3, 0>"], 1, 5),
     ("tri_blk_kernel lower, one ILU(F) apply", ["tri_blk_kernel<1,"], None, 20),
     ("tri_blk_kernel upper, one ILU(F) apply", ["tri_blk_kernel<0,"], None, 20),
     ("tri_blk_sf_kernel lower, one ILU(F) apply", ["tri_blk_sf_kernel<1,"], 1, 20),

@@ -125,3 +125,34 @@ def test_ilu_apply_inverts_its_own_factors(big):
     assert np.abs(x12 - (2.0 * x1 - 3.0 * x2)).max() <= 1e-11 * np.abs(x12).max()
     ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
     assert np.array_equal(ls.tri_apply(S.TRI_VELOCITY, b1), x1)    # same values -> bitwise the same factors
+
+
+def test_headline_kernels_match_the_oracle_at_the_headline_size(big):
+    """the single-launch triangular solves met the oracle only on meshes whose colours fit the GPU at
+    once; here a colour holds thousands of workgroups and consumers wait on producers that have not been dispatched.
+    ILU(0) of F and of S (the library's Schur complement) by the ORACLE with the library's permutations against
+    nsk_tri_apply (<= 1e-11), oracle SpMV of F, S, B~, B~^T against the library's (<= 1e-13), the Schur complement itself
+    against the oracle's B~ D^-1 B~^T on its own pattern.  (tests/studies/oracle_parity_full_size.py is the same as a
+    script; profiles/r04_oracle_parity_1200x400.log: 5e-16 ... 1e-15.)"""
+    from oracle import oracle as O
+    pr, ls, S = big
+    ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+    st = ls.stats()
+    assert st["n_colors_u"] >= 16 and st["n_colors_p"] >= 26        # no line groups at this size: colours overfill the GPU
+    rng = np.random.default_rng(2024)
+    bu, bp = rng.uniform(-1, 1, pr.n_u), rng.uniform(-1, 1, pr.n_p)
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())  # noqa: E731
+    before = ls.stats()["sync_free_fallbacks"]
+    xF, xS = ls.tri_apply(S.TRI_VELOCITY, bu), ls.tri_apply(S.TRI_PRESSURE, bp)
+    assert ls.stats()["sync_free_fallbacks"] == before
+    srp, scol, sval = ls.get_block(S.BLK_S)
+    F, Bt, B = (O.CsrHolder.from_block(b) for b in (pr.F, pr.Bt, pr.B))
+    Sm = O.CsrHolder(srp, scol, sval, pr.n_p, pr.n_p)
+    assert rel(ls.spmv(S.BLK_F, bu), O.spmv(F, bu)) <= 1e-13
+    assert rel(ls.spmv(S.BLK_BT, bp), O.spmv(Bt, bp)) <= 1e-13
+    assert rel(ls.spmv(S.BLK_B, bu), O.spmv(B, bu)) <= 1e-13
+    assert rel(ls.spmv(S.BLK_S, bp), O.spmv(Sm, bp)) <= 1e-13
+    orp, ocol, oval = O.spgemm_adb(B, 1.0 / pr.F.to_scipy().diagonal(), Bt)
+    assert np.array_equal(srp, orp) and np.array_equal(scol, ocol) and rel(sval, oval) <= 1e-13
+    assert rel(xS, O.Tri(Sm, kind=0, perm=ls.tri_perm(S.TRI_PRESSURE)).apply(bp)) <= 1e-11
+    assert rel(xF, O.Tri(F, kind=0, perm=ls.tri_perm(S.TRI_VELOCITY)).apply(bu)) <= 1e-11
