@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -663,7 +664,9 @@ double *VecPool::get(bool zero) {
     p = free_list.back();
     free_list.pop_back();
   } else {
-    // whole 128-byte lines plus one
+    // whole 128-byte lines plus one.  (Round 4 measured every vector of a pool at another offset into its allocation — 17
+    // steps of 4 352 bytes, against nine identically aligned streams of the fused Gram-Schmidt passes sitting on the same
+    // memory channels: multi_dot2_kernel<8> 135.3 -> 134.2 us, nothing; removed again.)
     NSK_HIP(hipMalloc((void **)&p, sizeof(double) * (((size_t)n + ng + 15) / 16 * 16 + 16)));
     all.push_back(p);
     zero = true;

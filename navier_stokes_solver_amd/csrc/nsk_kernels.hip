@@ -1045,7 +1045,6 @@ __global__ __launch_bounds__(64 * kRingWaves * G) void tri_ring_kernel(RingHalf 
   constexpr int E = kRingRegs, kThreads = 64 * kRingWaves * G;
   unsigned long long tr_wait = 0, tr_tries = 0, tr_comp = 0, tr_issue = 0, tr_rows = 0, tr_t0 = 0;
   if (TRACE) tr_t0 = __builtin_amdgcn_s_memtime();
-  constexpr bool DIAG = !(KIND == 0 && LOWER);   // (the unit lower factor of ILU(0) has no diagonal to divide by)
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int group = wave / kRingWaves, wslot = wave % kRingWaves;   // this wavefront takes the passes q = group (mod G)
@@ -1061,10 +1060,9 @@ __global__ __launch_bounds__(64 * kRingWaves * G) void tri_ring_kernel(RingHalf 
   volatile lds_int *const give_up = (volatile lds_int *)(lds + 8 * (kRingSlots + 1));
 
   // per stage: the records of one pass (registers); per stage one header in flight for the pass D of this group's later
-  unsigned e_lo[D][E], e_hi[D][E], e_off[D][E], m_dst[D], m_slot[D], n_lanes[D];
-  double own[D], dg[D];
+  unsigned e_lo[D][E], e_hi[D][E], e_off[D][E], rr[D][4], n_lanes[D];
   unsigned hx[D], hy[D], hz[D];
-  const unsigned vo12 = (unsigned)lane * 12u, vo8 = (unsigned)(lane >> 1) * 8u, vo16 = (unsigned)(lane >> 1) * 16u;
+  const unsigned vo12 = (unsigned)lane * 12u;
   auto load_hdr = [&](int slot, int q) {   // (uniform address, read-only, restrict: a scalar load)
     const uint4 h = hdr[q * kRingWaves + wslot];
     hx[slot] = h.x; hy[slot] = h.y; hz[slot] = h.z;
@@ -1094,17 +1092,16 @@ __global__ __launch_bounds__(64 * kRingWaves * G) void tri_ring_kernel(RingHalf 
         e_lo[slot][r] = 0u; e_hi[slot][r] = 0u; e_off[slot][r] = 0u;
       }
     }
-    const auto o = __builtin_amdgcn_raw_buffer_load_b64(ring_rsrc(own_src + pos0, rows * 8u), vo8, 0, 0);
-    own[slot] = __hiloint2double((int)o[1], (int)o[0]);
-    const __amdgpu_buffer_rsrc_t rrs = ring_rsrc(rowrec + (size_t)pos0 * 16u, rows * 16u);
-    if (DIAG) {
-      const auto g = __builtin_amdgcn_raw_buffer_load_b128(rrs, vo16, 0, 0);
-      dg[slot] = __hiloint2double((int)g[1], (int)g[0]);
-      m_dst[slot] = g[2]; m_slot[slot] = g[3];
-    } else {
-      const auto g = __builtin_amdgcn_raw_buffer_load_b64(rrs, vo16 + 8u, 0, 0);
-      m_dst[slot] = g[0]; m_slot[slot] = g[1];
-    }
+    // ONE load for both per-row records: a pair's even lane takes the row record (diagonal, where the result goes, the
+    // row's slot), its odd lane the row's own value (+ the word behind it); pairs beyond the wavefront's rows re-read
+    // its last row
+    const unsigned kk = (unsigned)(lane >> 1) < rows ? (unsigned)(lane >> 1) : rows - 1u;
+    const char *ra = (lane & 1) ? reinterpret_cast<const char *>(own_src) + ((size_t)pos0 + kk) * 8u
+                                : rowrec + ((size_t)pos0 + kk) * 16u;
+    typedef unsigned vu4 __attribute__((ext_vector_type(4)));
+    typedef vu4 vu4u __attribute__((aligned(8)));
+    const vu4 g = *reinterpret_cast<const vu4u *>(ra);
+    rr[slot][0] = g[0]; rr[slot][1] = g[1]; rr[slot][2] = g[2]; rr[slot][3] = g[3];
   };
   auto compute = [&](int slot) {
     const unsigned nl = n_lanes[slot];
@@ -1132,12 +1129,15 @@ __global__ __launch_bounds__(64 * kRingWaves * G) void tri_ring_kernel(RingHalf 
       }
     }
     if (TRACE) tr_wait += __builtin_amdgcn_s_memtime() - tw0;
+    // the row's own value sits in the pair's odd lane, the row record in its even one
+    const double own = ring_pair_partner(__hiloint2double((int)rr[slot][1], (int)rr[slot][0]));
     if (rowlane) {
+      const double dg = __hiloint2double((int)rr[slot][1], (int)rr[slot][0]);
       double res;
-      if (LOWER) res = KIND == 0 ? (own[slot] - u) : (own[slot] - u) / dg[slot];      // (divisions, as tri_row: same bits)
-      else res = KIND == 0 ? (own[slot] - u) / dg[slot] : own[slot] - u / dg[slot];
-      *(lds_double *)(lds + m_slot[slot]) = res;
-      *reinterpret_cast<double *>(reinterpret_cast<char *>(dst) + m_dst[slot]) = res;
+      if (LOWER) res = KIND == 0 ? (own - u) : (own - u) / dg;      // (divisions, as tri_row: same bits)
+      else res = KIND == 0 ? (own - u) / dg : own - u / dg;
+      *(lds_double *)(lds + rr[slot][3]) = res;
+      *reinterpret_cast<double *>(reinterpret_cast<char *>(dst) + rr[slot][2]) = res;
     }
     if (TRACE) tr_comp += __builtin_amdgcn_s_memtime() - tw0;
   };

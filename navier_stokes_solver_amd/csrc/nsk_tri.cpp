@@ -811,7 +811,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       Rg.dsrc.upload(ds, s);
       Rg.rowid.upload(P.order, s);
       Rg.rearm.upload(rearm, s);
-      Rg.own.alloc((size_t)n);
+      Rg.own.alloc((size_t)n + 2);   // (the kernel's 16-byte load of a row's own value takes the word behind it along)
       ctx->sync();
       return true;
     };

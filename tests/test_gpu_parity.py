@@ -332,8 +332,15 @@ def test_solve_matches_oracle_and_direct(handles, name, solver, prec, variant, t
         # runs still track each other, and x / the iteration count of a solve that ends inside that window.
         return
     xs = spl.splu(J).solve(b)
-    assert rel_err(x, xo) <= 1e-7, (rel_err(x, xo), its, info["iters"])
-    assert rel_err(x, xs) <= 1e-7
+    e_or, e_dir, e_od = rel_err(x, xo), rel_err(x, xs), rel_err(xo, xs)
+    print(f"PARITY {name} solver {solver} prec {prec} variant {variant} ordering {ordering}: |x_gpu - x_oracle| {e_or:.2e}, "
+          f"|x_gpu - x_direct| {e_dir:.2e}, |x_oracle - x_direct| {e_od:.2e}, iterations {its} / {info['iters']}, tol {tol:g}")
+    # SURVEY 8(c) tier 2 asks for 1e-8 between the two solutions: measured on MI355X (round 4, all 17 cases that run here)
+    # 1e-15 ... 1.9e-9, the largest on the unsteady systems whose solves end after thousands of restarted iterations.
+    # Against the sparse-direct solution both sides sit at kappa * tol = 2e-11 ... 5.5e-9 (the oracle's own distance
+    # from it is the same to two digits: the error is the stopping criterion's, not the implementation's).
+    assert e_or <= 1e-8, (e_or, its, info["iters"])
+    assert e_dir <= 2e-8 and abs(e_dir - e_od) <= max(0.5 * e_od, 1e-10), (e_dir, e_od)
     # The unsteady systems (mass-dominated, fixed or nearly switched-off preconditioners: absolute inner tolerance
     # 1e-1, NSSolver.hpp:159-169) make restarted FGMRES(30) stagnate for thousands of iterations; the count then
     # depends on the last bits of the matrix (10 831 ... 14 028 and 2 095 ... 2 754 seen for the same two systems
@@ -426,6 +433,49 @@ def test_first_restart_cycle_matches_oracle(handles, prec, solver):
         return
     assert len(hg) >= n and len(ho) >= n, (len(hg), len(ho))
     assert np.abs(hg[:n] - ho[:n]).max() <= 1e-8 * np.abs(ho[:n]).max(), np.abs(hg[:n] / ho[:n] - 1).max()
+
+
+def test_negated_schur_sign_is_opt_in_and_follows_the_oracle_study_switch():
+    """NSK_OPT_SCHUR_SIGN: the default forms S = B~ D^-1 B~^T exactly as the reference does; -1 is a
+    labelled deviation that negates it.  With -1 the library's S is minus the oracle's product, a FGMRES + aSIMPLE solve
+    agrees with the oracle run under the same study switch, and it needs far fewer outer iterations than the
+    reference's sign (whose preconditioned operator has n_p eigenvalues with negative real part)."""
+    S, O = _S(), _O()
+    import scipy.sparse.linalg as spl
+    pr = problem("ns16")
+    b = np.concatenate([pr.rhs_u, pr.rhs_p])
+    x0 = np.concatenate([pr.x0_u, pr.x0_p])
+    orp, ocol, oval = O.spgemm_adb(O.CsrHolder.from_block(pr.B), 1.0 / pr.F.to_scipy().diagonal(), O.CsrHolder.from_block(pr.Bt))
+    its = {}
+    for sign in (+1, -1):
+        ls = S.LinearSolver()
+        try:
+            ls.set_option(S.OPT_TRI_ORDERING, 1)
+            if sign < 0:
+                ls.set_option(S.OPT_SCHUR_SIGN, -1)
+            ls.set_problem(pr)
+            ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+            rp, col, val = ls.get_block(S.BLK_S)
+            assert np.array_equal(rp, orp) and np.array_equal(col, ocol) and rel_err(val, sign * oval) <= 1e-13
+            op = O.OracleProblem.from_local(pr, perm_F=ls.tri_perm(S.TRI_VELOCITY), perm_S=ls.tri_perm(S.TRI_PRESSURE))
+            ls.setup_preconditioner(S.ASIMPLE, S.STATIONARY, 0.5)
+            xu, xp, n_it, res, rc = ls.solve(S.FGMRES, 1e-10, 20000, pr.rhs_u, pr.rhs_p, pr.x0_u, pr.x0_p)
+            xo, info = op.solve(b, x0, solver=1, prec=2, variant=0, tol=1e-10, schur_sign=sign)
+            assert rc == 0 and info["status"] == 0
+            x = np.concatenate([xu, xp])
+            assert rel_err(x, xo) <= 1e-7 and rel_err(x, spl.splu(pr.jacobian_scipy().tocsc()).solve(b)) <= 1e-7
+            assert abs(n_it - info["iters"]) <= max(3, 0.2 * info["iters"]), (sign, n_it, info["iters"])
+            its[sign] = n_it
+        finally:
+            ls.close()
+    print(f"outer iterations to 1e-10 at 16x10: reference's S {its[+1]}, S negated {its[-1]}")
+    assert its[-1] < 0.6 * its[+1], its
+    with pytest.raises(RuntimeError, match="NSK_OPT_SCHUR_SIGN"):
+        ls2 = S.LinearSolver()
+        try:
+            ls2.set_option(S.OPT_SCHUR_SIGN, 0)
+        finally:
+            ls2.close()
 
 
 @pytest.mark.parametrize("prec", [0, 1, 2])
