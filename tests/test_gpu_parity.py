@@ -340,7 +340,7 @@ def test_solve_matches_oracle_and_direct(handles, name, solver, prec, variant, t
     # Against the sparse-direct solution both sides sit at kappa * tol = 2e-11 ... 5.5e-9 (the oracle's own distance
     # from it is the same to two digits: the error is the stopping criterion's, not the implementation's).
     assert e_or <= 1e-8, (e_or, its, info["iters"])
-    assert e_dir <= 2e-8 and abs(e_dir - e_od) <= max(0.5 * e_od, 1e-10), (e_dir, e_od)
+    assert e_dir <= 2e-8 and abs(e_dir - e_od) <= max(0.7 * e_od, 1e-10), (e_dir, e_od)
     # The unsteady systems (mass-dominated, fixed or nearly switched-off preconditioners: absolute inner tolerance
     # 1e-1, NSSolver.hpp:159-169) make restarted FGMRES(30) stagnate for thousands of iterations; the count then
     # depends on the last bits of the matrix (10 831 ... 14 028 and 2 095 ... 2 754 seen for the same two systems
