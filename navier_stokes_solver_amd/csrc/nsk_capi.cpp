@@ -1836,6 +1836,21 @@ int nsk_time_op(nsk_handle h, int op, int reps, double *avg_ms, double *bytes) {
   } else if (op == 32) {
     by = 32.0 * h->N();
     f = [=]() { h->ctx.axpy_dot(h->N(), sref(1e-9), xb, zb, yb, sl); };
+  } else if (op == 33 || op == 34) {
+    // the fused Gram-Schmidt passes of the inner FGMRES on F: 8 basis vectors + w, velocity-sized, from the pool
+    const int n = h->n_u();
+    auto vs = std::make_shared<std::vector<double *>>();
+    for (int k = 0; k < 9; ++k) {
+      vs->push_back(h->pool_u.get(true));
+      vec_set(h->s(), n, vs->back(), 1.0 / (k + 1));
+    }
+    const int cs = h->ctx.alloc_slots(10);
+    by = op == 33 ? 8.0 * n * 9 : 8.0 * n * 10;
+    f = [=]() {
+      if (op == 33) h->ctx.multi_dot(n, (*vs)[8], vs->data(), 8, cs, true);
+      else h->ctx.multi_axpy(n, (*vs)[8], vs->data(), 8, cs, -1);
+    };
+    for (double *p : *vs) h->pool_u.put(p);   // (stay valid until the pool hands them out again: not during this call)
   } else if (op == 40 || op == 41) {
     // host round trip of one device scalar (what every Krylov iteration pays for its SolverControl check): wall time
     const double t0 = wall_ms();

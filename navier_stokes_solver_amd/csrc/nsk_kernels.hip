@@ -47,6 +47,16 @@ inline int red_grid(int n) {
   if (b > kMaxReduceBlocks) b = kMaxReduceBlocks;
   return (int)b;
 }
+// The pair forms (16-byte loads) take fewer workgroups still: measured at 1200x400 (scripts/time_gs_passes.py), 512 / 256 /
+// 128 workgroups: dot 39.6 / 33.5 / 30.7 us, add_and_dot 66.2 / 58.3 / 53.4, multi_dot<8> 134.7 / 121.9 / 130.6 — the
+// tail of serialised tickets is 6 us at 512, and 128 fat workgroups already stream at the full rate.  (The 8-byte forms
+// keep their grid: they are the arithmetic of the unsteady variant, whose convergence hangs on the last bits.)
+inline int red_grid_pairs(int n, int cap) {
+  long b = (((long)n + 1) / 2 + RBLK * 4 - 1) / (RBLK * 4);
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
 
 // ------------------------------------------------------------------ SpMV (CSR, LPR lanes per row)
 template <int LPR, int MODE>
@@ -892,8 +902,28 @@ __global__ __launch_bounds__(RBLK) void multi_dot2_kernel(int n, const double *_
   double acc[M];
 #pragma unroll
   for (int k = 0; k < M; ++k) acc[k] = 0.0;
-  const long np = n >> 1;
-  for (long i = (long)blockIdx.x * RBLK + threadIdx.x; i < np; i += (long)gridDim.x * RBLK) {
+  const long np = n >> 1, stride = (long)gridDim.x * RBLK;
+  long i = (long)blockIdx.x * RBLK + threadIdx.x;
+  // two trips' loads in flight (2 (M + 1) 16-byte loads per thread); the sums keep the order of the plain loop.  (A tiled
+  // form — w's tile in registers, the M vectors one after the other over it, one stream open at a time — was measured at
+  // 125.6 us with 2 pairs per thread and 204 with 4, against 120.1: removed.  Nine streams read at 5.1 TB/s here.)
+  for (; i + stride < np; i += 2 * stride) {
+    const double2 wa = reinterpret_cast<const double2 *>(w)[i], wb = reinterpret_cast<const double2 *>(w)[i + stride];
+    double2 va[M], vb[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      va[k] = reinterpret_cast<const double2 *>(P.v[k])[i];
+      vb[k] = reinterpret_cast<const double2 *>(P.v[k])[i + stride];
+    }
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      acc[k] += wa.x * va[k].x;
+      acc[k] += wa.y * va[k].y;
+      acc[k] += wb.x * vb[k].x;
+      acc[k] += wb.y * vb[k].y;
+    }
+  }
+  for (; i < np; i += stride) {
     const double2 wi = reinterpret_cast<const double2 *>(w)[i];
 #pragma unroll
     for (int k = 0; k < M; ++k) {
@@ -1588,7 +1618,7 @@ void extract_diag(hipStream_t s, const CsrView &A, double *d, double *dinv) {
   do {                                                                                                         \
     auto f2__ = F2;                                                                                            \
     auto f1__ = F1;                                                                                            \
-    hipLaunchKernelGGL((reduce2_kernel<decltype(f2__), decltype(f1__)>), dim3(red_grid(((n) + 1) / 2)), dim3(RBLK), 0, s, n, \
+    hipLaunchKernelGGL((reduce2_kernel<decltype(f2__), decltype(f1__)>), dim3(red_grid_pairs(n, 128)), dim3(RBLK), 0, s, n, \
                        f2__, f1__, ws, out, want_sqrt);                                                        \
   } while (0)
 namespace {
@@ -1834,7 +1864,7 @@ bool pack_aligned16(const double *w, const VecPack &P, int m) {
 }  // namespace
 void vec_multi_dot(hipStream_t s, const ReduceWs &ws, int n, const double *w, const VecPack &P, int m, double *out) {
   if (blas1_pairs(ws) && n >= 2 && pack_aligned16(w, P, m)) {
-#define NSK_MD(M) case M: hipLaunchKernelGGL((multi_dot2_kernel<M>), dim3(red_grid((n + 1) / 2)), dim3(RBLK), 0, s, n, w, P, ws, out); break;
+#define NSK_MD(M) case M: hipLaunchKernelGGL((multi_dot2_kernel<M>), dim3(red_grid_pairs(n, 256)), dim3(RBLK), 0, s, n, w, P, ws, out); break;
     switch (m) { NSK_MD(1) NSK_MD(2) NSK_MD(3) NSK_MD(4) NSK_MD(5) NSK_MD(6) NSK_MD(7) NSK_MD(8) default: break; }
 #undef NSK_MD
     return;
@@ -1849,8 +1879,8 @@ void vec_multi_axpy(hipStream_t s, const ReduceWs &ws, int n, double *w, const V
   if ((!norm_out || blas1_pairs(ws)) && n >= 2 && pack_aligned16(w, P, m)) {
 #define NSK_MA(M)                                                                                                \
   case M:                                                                                                        \
-    if (norm_out) hipLaunchKernelGGL((multi_axpy2_kernel<M, true>), dim3(red_grid((n + 1) / 2)), dim3(RBLK), 0, s, n, w, P, h, ws, norm_out); \
-    else hipLaunchKernelGGL((multi_axpy2_kernel<M, false>), dim3(red_grid((n + 1) / 2)), dim3(RBLK), 0, s, n, w, P, h, ws, norm_out);         \
+    if (norm_out) hipLaunchKernelGGL((multi_axpy2_kernel<M, true>), dim3(red_grid_pairs(n, 256)), dim3(RBLK), 0, s, n, w, P, h, ws, norm_out); \
+    else hipLaunchKernelGGL((multi_axpy2_kernel<M, false>), dim3(red_grid_pairs(n, 256)), dim3(RBLK), 0, s, n, w, P, h, ws, norm_out);         \
     break;
     switch (m) { NSK_MA(1) NSK_MA(2) NSK_MA(3) NSK_MA(4) NSK_MA(5) NSK_MA(6) NSK_MA(7) NSK_MA(8) default: break; }
 #undef NSK_MA
