@@ -401,6 +401,7 @@ void H::schur_symbolic() {
   S.nnz = rp[np];
   S.h_rowptr = rp;
   S.h_col.resize((size_t)S.nnz);
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < np; ++i) std::copy(rows[i].begin(), rows[i].end(), S.h_col.begin() + rp[i]);
   S.rowptr.upload(S.h_rowptr, s());
   S.col.upload(S.h_col, s());

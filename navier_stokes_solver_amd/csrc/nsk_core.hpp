@@ -38,6 +38,22 @@ struct Error : std::runtime_error {
                                   std::to_string(__LINE__));                                       \
   } while (0)
 
+// Host vector whose elements are NOT zeroed when it is sized: the symbolic phases fill arrays of 10^8-10^9 ints in
+// parallel loops, and std::vector's value-initialisation was a serial pass (and the first touch) over every one of them —
+// the largest single item of the first set-up (round 4: "restricted pattern" 0.54 s of an ordering's 0.76 s at 600x200).
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind { using other = DefaultInitAlloc<U>; };
+  template <class U, class... A>
+  void construct(U *p, A &&...a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+    else ::new ((void *)p) U(std::forward<A>(a)...);
+  }
+};
+template <class T>
+using UVec = std::vector<T, DefaultInitAlloc<T>>;
+
 template <class T>
 struct DBuf {  // owning device buffer
   T *p = nullptr;
@@ -65,7 +81,8 @@ struct DBuf {  // owning device buffer
     if (count != n) alloc(count);
     if (count) NSK_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
   }
-  void upload(const std::vector<T> &h, hipStream_t s) { upload(h.data(), h.size(), s); }
+  template <class A>
+  void upload(const std::vector<T, A> &h, hipStream_t s) { upload(h.data(), h.size(), s); }
 };
 
 // Local-group transport, on-stream mode: send buffers and events of one space (see Comm::local_exchange_on_stream)

@@ -43,7 +43,7 @@ void level_lists(const std::vector<int> &level, int n_levels, std::vector<int> &
 }  // namespace
 
 // greedy distance-1 colouring on the graph of G + G^T, vertices visited in natural order
-int greedy_color(int nv, const std::vector<int> &grp, const std::vector<int> &gcol, std::vector<int> &color) {
+int greedy_color(int nv, const std::vector<int> &grp, const UVec<int> &gcol, std::vector<int> &color) {
   const int64_t ne = grp[nv];
   // A structurally symmetric graph with sorted rows (finite-element patterns) is its own transpose: checked in parallel
   // (one binary search per edge), which is cheaper than the serial transposition it saves (1200x400: 210 M edges)
@@ -98,7 +98,7 @@ int greedy_color(int nv, const std::vector<int> &grp, const std::vector<int> &gc
 // and so does the natural ordering the ILU quality comes from.  Without support points, or on meshes without such
 // lines, every group has one member and this is the plain greedy colouring.
 // Output: members of group q are grp_items[grp_ptr[q] .. grp_ptr[q+1]) in +x order; groups ordered by first member.
-static void line_groups(int ni, const std::vector<int> &irp, const std::vector<int> &icol, const double *xy, int xy_stride,
+static void line_groups(int ni, const std::vector<int> &irp, const UVec<int> &icol, const double *xy, int xy_stride,
                         const int *shard_of_item, int g, std::vector<int> &grp_ptr, std::vector<int> &grp_items) {
   grp_ptr.clear();
   grp_items.clear();
@@ -190,6 +190,14 @@ static std::vector<int4> sf_dispatch_order(const std::vector<int4> &desc, const 
 // Host-only part of the analysis: restricted pattern, node structure, line groups, colouring, permutation.
 void TriOrdering::build(int n, const int *rp, const int *cl, int ordering, const std::vector<int> &sub_off, bool want_block2,
                         const double *xy, int group) {
+  static const bool chatty = [] { const char *e = getenv("NSK_VERBOSE"); return e && atoi(e) > 1; }();
+  double t_last = omp_get_wtime();
+  auto tick = [&](const char *what) {   // NSK_VERBOSE=2: inside the ordering
+    if (!chatty) return;
+    const double t = omp_get_wtime();
+    fprintf(stderr, "[nsk]     ordering: %-28s %9.1f ms\n", what, 1e3 * (t - t_last));
+    t_last = t;
+  };
 
   // emulated-rank id of every row (additive Schwarz, overlap 0, inside this GPU)
   shard.clear();
@@ -220,6 +228,7 @@ void TriOrdering::build(int n, const int *rp, const int *cl, int ordering, const
       if (keep(i, cl[k])) { rcol[w] = cl[k]; rpos[w] = k; ++w; }
   }
 
+  tick("restricted pattern");
   perm.clear();
   pcolor.clear();
   n_colors = 0;
@@ -240,6 +249,7 @@ void TriOrdering::build(int n, const int *rp, const int *cl, int ordering, const
     }
     block2 = ok;
   }
+  tick("node structure check");
   // chain position / length of every permuted ITEM (row, or velocity node when block2) inside its line group
   cpos.clear();
   clen.clear();
@@ -247,8 +257,9 @@ void TriOrdering::build(int n, const int *rp, const int *cl, int ordering, const
   if (ordering == ORDER_MULTICOLOR) {
     // item graph: velocity nodes (block2) or rows
     const int ni = block2 ? n / 2 : n;
-    std::vector<int> irp, icol_own;
-    const std::vector<int> *icolp = &rcol;
+    std::vector<int> irp;
+    UVec<int> icol_own;
+    const UVec<int> *icolp = &rcol;
     if (block2) {
       irp.assign(ni + 1, 0);
       for (int r = 0; r < ni; ++r) irp[r + 1] = irp[r] + (rrp[2 * r + 1] - rrp[2 * r]) / 2;
@@ -258,17 +269,19 @@ void TriOrdering::build(int n, const int *rp, const int *cl, int ordering, const
         for (int k = 0; k < irp[r + 1] - irp[r]; ++k) icol_own[(size_t)irp[r] + k] = rcol[rrp[2 * r] + 2 * k] / 2;
       icolp = &icol_own;
     } else irp.assign(rrp.begin(), rrp.end());
-    const std::vector<int> &icol = *icolp;
+    const UVec<int> &icol = *icolp;
     std::vector<int> ishard;
     if (sharded) {
       ishard.resize(ni);
       for (int r = 0; r < ni; ++r) ishard[r] = shard[block2 ? 2 * r : r];
     }
+    tick("item graph");
     // line groups (one member each without support points or with group == 1)
     std::vector<int> gptr, gitems;
     line_groups(ni, irp, icol, xy, block2 ? 4 : 2, sharded ? ishard.data() : nullptr, std::max(1, std::min(group, kTriGroupMax)),
                 gptr, gitems);
     const int ng = (int)gptr.size() - 1;
+    tick("line groups");
     std::vector<int> gcolor;
     if (ng == ni) {
       n_colors = greedy_color(ni, irp, icol, gcolor);   // gitems is the identity then
@@ -291,12 +304,13 @@ void TriOrdering::build(int n, const int *rp, const int *cl, int ordering, const
         v.erase(std::unique(v.begin(), v.end()), v.end());
       }
       for (int q = 0; q < ng; ++q) qrp[q + 1] = qrp[q] + (int)qrows[q].size();
-      std::vector<int> qcol((size_t)qrp[ng]);
+      UVec<int> qcol((size_t)qrp[ng]);
 #pragma omp parallel for schedule(static)
       for (int q = 0; q < ng; ++q) std::copy(qrows[q].begin(), qrows[q].end(), qcol.begin() + qrp[q]);
       std::vector<std::vector<int>>().swap(qrows);
       n_colors = greedy_color(ng, qrp, qcol, gcolor);
     }
+    tick("greedy colouring (+ symmetry check)");
     // perm: colours ascending; inside a colour the groups in their order, members in +x order; a node's two rows adjacent
     std::vector<int> cptr(n_colors + 1, 0);
     for (int q = 0; q < ng; ++q) cptr[gcolor[q] + 1] += gptr[q + 1] - gptr[q];
@@ -328,6 +342,7 @@ void TriOrdering::build(int n, const int *rp, const int *cl, int ordering, const
         } else { perm[w] = it; pcolor[w] = color_of_item[it]; }
       }
     }
+    tick("permutation");
   }
 }
 
@@ -354,7 +369,8 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   gmax = O.gmax;
   grouped = gmax > 1;
   perm = O.perm;
-  const std::vector<int> &rrp = O.rrp, &rcol = O.rcol, &rpos = O.rpos, &pcolor = O.pcolor;
+  const std::vector<int> &rrp = O.rrp, &pcolor = O.pcolor;
+  const UVec<int> &rcol = O.rcol, &rpos = O.rpos;
   const std::vector<unsigned char> &cpos = O.cpos, &clen = O.clen;
   const bool block2 = O.block2;
 
@@ -364,7 +380,8 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     iperm.resize(n);
     for (int i = 0; i < n; ++i) iperm[perm[i]] = i;
   }
-  std::vector<int> prp(n + 1, 0), pcol((size_t)nnz), psrc((size_t)nnz), pdiag(n, -1);
+  std::vector<int> prp(n + 1, 0), pdiag(n, -1);
+  UVec<int> pcol((size_t)nnz), psrc((size_t)nnz);   // (not zeroed: filled in the parallel loop below)
   for (int i = 0; i < n; ++i) {
     const int r = perm.empty() ? i : perm[i];
     prp[i + 1] = prp[i] + (rrp[r + 1] - rrp[r]);
@@ -472,7 +489,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     }
     nnzL = (int64_t)lrp[nn] * 4;
     nnzU = (int64_t)urp[nn] * 4;
-    std::vector<int> lcol((size_t)lrp[nn]), lsrc((size_t)lrp[nn] * 4), ucol((size_t)urp[nn]), usrc((size_t)urp[nn] * 4);
+    UVec<int> lcol((size_t)lrp[nn]), lsrc((size_t)lrp[nn] * 4), ucol((size_t)urp[nn]), usrc((size_t)urp[nn] * 4);
     std::vector<int> hpermn(nn), isrc((size_t)nn * 4);  // per node row: positions of l10, u01, d0, d1
     // couplings inside a line group: per node row and half up to kTriGroupMax - 1 blocks (nearest member first), -1: none
     constexpr int CW = (kTriGroupMax - 1) * 4;
@@ -594,7 +611,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     for (int i = 0; i < n; ++i) { lrp[i + 1] += lrp[i]; urp[i + 1] += urp[i]; }
     nnzL = lrp[n];
     nnzU = urp[n];
-    std::vector<int> lcol((size_t)nnzL), lsrc((size_t)nnzL), ucol((size_t)nnzU), usrc((size_t)nnzU);
+    UVec<int> lcol((size_t)nnzL), lsrc((size_t)nnzL), ucol((size_t)nnzU), usrc((size_t)nnzU);
     // column ids go back to the caller's numbering, sorted, so that a row's gathers are runs of neighbours
 #pragma omp parallel
     {

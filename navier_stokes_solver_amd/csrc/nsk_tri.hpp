@@ -21,14 +21,15 @@ enum { ORDER_NATURAL = 0, ORDER_MULTICOLOR = 1 };
 
 // greedy distance-1 colouring of the graph of G + G^T (CSR grp/gcol, nv vertices, visited in natural order);
 // returns the number of colours
-int greedy_color(int nv, const std::vector<int> &grp, const std::vector<int> &gcol, std::vector<int> &color);
+int greedy_color(int nv, const std::vector<int> &grp, const UVec<int> &gcol, std::vector<int> &color);
 
 // Host-only analysis of one factor's ordering (no device work: also behind nsk_debug_tri_ordering for the CPU tests)
 struct TriOrdering {
   int64_t nnz = 0;
   int n_colors = 0, gmax = 1;
   bool block2 = false, sharded = false;
-  std::vector<int> shard, rrp, rcol, rpos;      // restricted pattern (ghost / cross-shard columns dropped), positions in A
+  std::vector<int> shard, rrp;
+  UVec<int> rcol, rpos;                         // restricted pattern (ghost / cross-shard columns dropped), positions in A
   std::vector<int> perm, pcolor;                // perm[new] = old (empty: natural order); colour of every permuted row
   std::vector<unsigned char> cpos, clen;        // per permuted item (row, or node when block2): position / length in its group
   void build(int n, const int *rowptr, const int *col, int ordering, const std::vector<int> &sub_off, bool want_block2,
