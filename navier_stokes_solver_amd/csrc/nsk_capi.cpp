@@ -957,8 +957,10 @@ int nsk_set_block_csr(nsk_handle h, int b, int n_rows, int n_cols, const int32_t
   const int64_t nnz = rowptr[n_rows];
   for (int i = 0; i < n_rows; ++i)
     if (rowptr[i + 1] < rowptr[i]) throw Error(-58, "nsk_set_block_csr: rowptr not monotone");
-  for (int64_t k = 0; k < nnz; ++k)
-    if (col[k] < 0 || col[k] >= n_cols) throw Error(-59, "nsk_set_block_csr: column id out of range");
+  bool bad_col = false;
+#pragma omp parallel for schedule(static) reduction(|| : bad_col)
+  for (int64_t k = 0; k < nnz; ++k) bad_col = bad_col || col[k] < 0 || col[k] >= n_cols;
+  if (bad_col) throw Error(-59, "nsk_set_block_csr: column id out of range");
   Csr &A = h->blk[b];
   Phase ph("hand-off of one block");
   A.n_rows = n_rows;
@@ -966,7 +968,10 @@ int nsk_set_block_csr(nsk_handle h, int b, int n_rows, int n_cols, const int32_t
   A.n_own_cols = Cc.n;
   A.nnz = nnz;
   A.h_rowptr.assign(rowptr, rowptr + n_rows + 1);
-  A.h_col.assign(col, col + nnz);
+  A.h_col.resize((size_t)nnz);
+#pragma omp parallel for schedule(static)
+  for (int64_t c = 0; c < (nnz + (1 << 20) - 1) >> 20; ++c)   // (1.7 GB at 1200x400: a serial copy was a third of the hand-off)
+    std::memcpy(A.h_col.data() + (c << 20), col + (c << 20), sizeof(int) * (size_t)std::min<int64_t>(1 << 20, nnz - (c << 20)));
   A.rowptr.upload(rowptr, (size_t)n_rows + 1, h->s());
   A.col.upload(col, (size_t)nnz, h->s());
   A.val.upload(val, (size_t)nnz, h->s());

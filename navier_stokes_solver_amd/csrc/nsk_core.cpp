@@ -622,7 +622,8 @@ void Csr::build_blocked(int R, int C, hipStream_t s) {
   if (!ok) return;
   for (int r = 0; r < nr; ++r) rp[r + 1] += rp[r];
   blk_count = rp[nr];
-  std::vector<int> bcol((size_t)blk_count), bsrc((size_t)blk_count * R * C), rb;
+  UVec<int> bcol((size_t)blk_count), bsrc((size_t)blk_count * R * C);   // (not zeroed: filled in the parallel loop below)
+  std::vector<int> rb;
 #pragma omp parallel for schedule(static)
   for (int r = 0; r < nr; ++r)
     for (int k = 0; k < rp[r + 1] - rp[r]; ++k) {

@@ -123,7 +123,8 @@ struct DVec {
 struct Csr {  // device CSR block with host copy of the pattern
   int n_rows = 0, n_cols = 0, n_own_cols = 0;
   int64_t nnz = 0;
-  std::vector<int> h_rowptr, h_col;  // host pattern (symbolic phases)
+  std::vector<int> h_rowptr;  // host pattern (symbolic phases)
+  UVec<int> h_col;            // (not zeroed when sized: filled by parallel copies)
   DBuf<int> rowptr, col;
   DBuf<double> val;
   int lpr = 16;  // lanes per row chosen from the mean row length (CSR-vector fallback kernel)
