@@ -1046,6 +1046,10 @@ int nsk_set_option(nsk_handle h, int opt, double v) {
     case NSK_IOPT_TINY_BYTES: h->tF.tiny_bytes = h->tMp.tiny_bytes = h->tS.tiny_bytes = v; break;
     case NSK_OPT_BSR_VELOCITY: h->use_bsr = v != 0.0; break;
     case NSK_OPT_VELOCITY_AMG: h->velocity_amg = v != 0.0; break;
+    case NSK_IOPT_HOST_ANALYSIS:
+      h->tF.host_analysis = h->tS.host_analysis = h->tMp.host_analysis = v != 0.0;
+      h->tF_ok = h->tS_ok = h->tMp_ok = false;
+      break;
     case NSK_OPT_BLAS1_PAIRS:
       if (v != -1.0 && v != 0.0 && v != 1.0) throw Error(-61, "NSK_OPT_BLAS1_PAIRS: -1, 0 or 1");
       h->blas1_pairs = (int)v;

@@ -16,6 +16,9 @@ enum {
                                 // all levels; the tests set 0 to run the streamed kernels on small meshes
   NSK_IOPT_OVERLAP_HALO = 107,  // 1 (default): several ranks — interior rows of the inner solvers' SpMVs (F, S, Mp) run on a
                                 // second stream while the halo exchange is in flight; 0: exchange first, then one launch
+  NSK_IOPT_HOST_ANALYSIS = 108, // 1: the symbolic set-up of the multicolour triangular factors (permuted pattern, split halves)
+                                // on the host as in rounds 1-3; 0 (default): on the device (nsk_setup_kernels.hip) wherever
+                                // it applies — no line groups, no sub-domains, no ghost columns.  Same arrays either way
   NSK_IOPT_FUSED_MGS = 106      // 1 (default): the modified Gram-Schmidt chain of an Arnoldi step in ONE launch when the
                                 // vector fits the registers of the co-resident grid (single rank); 0: one launch per link
 };

@@ -265,6 +265,21 @@ void spgemm_bdbt_numeric(hipStream_t s, const CsrView &B, const double *dinv_own
                          const CsrView &Bt, const CsrView &Btg, const int *s_rowptr, const int *s_col, double *s_val,
                          int n_rows, int max_row_nnz);
 
+// ---- symbolic set-up of the multicolour triangular factors on the device (nsk_setup_kernels.hip) ----
+// permuted pattern: row i = row perm[i] of A, columns renamed by iperm and sorted; psrc = the entry's place in A; pdiag =
+// the diagonal's place; *err |= 1 when a row has none.  max_row: longest row (LDS staging).
+void setup_permute_rows(hipStream_t s, int n, const int *a_rowptr, const int *a_col, const int *perm, const int *iperm,
+                        const int *prp, int *pcol, int *psrc, int *pdiag, int max_row, int *err);
+// 2x2 node-block split (no line groups): blocks of node row r towards earlier / later nodes, counted, then filled behind
+// the row pointers lrp / urp (block-column id = colour-order node id when x_layout, else the caller-order one; blocks of
+// a row sorted by it); isrc: the node's own block {l10, u01, d0, d1}; permn: caller-order node of the row
+void setup_blk_count(hipStream_t s, int nn, const int *prp, const int *pcol, int max_blocks, int *cnt_l, int *cnt_u);
+void setup_blk_fill(hipStream_t s, int nn, const int *prp, const int *pcol, const int *perm, int x_layout, int max_blocks,
+                    const int *lrp, const int *urp, int *lcol, int *lsrc, int *ucol, int *usrc, int *isrc, int *permn);
+// scalar split (no line groups): strict-lower / strict-upper CSR halves, column ids in the caller's numbering, sorted
+void setup_csr_fill(hipStream_t s, int n, const int *prp, const int *pcol, const int *pdiag, const int *perm, int max_row,
+                    const int *lrp, const int *urp, int *lcol, int *lsrc, int *ucol, int *usrc);
+
 // ---- halo pack ----
 void halo_pack(hipStream_t s, int n, const int *idx, const double *x, double *buf);
 // out[i] = sum over r < n of src[r][i] in this order (all-reduce of the in-process test transport, on-stream mode)

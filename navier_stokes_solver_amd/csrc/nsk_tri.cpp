@@ -43,7 +43,7 @@ void level_lists(const std::vector<int> &level, int n_levels, std::vector<int> &
 }  // namespace
 
 // greedy distance-1 colouring on the graph of G + G^T, vertices visited in natural order
-int greedy_color(int nv, const std::vector<int> &grp, const UVec<int> &gcol, std::vector<int> &color) {
+int greedy_color(int nv, const std::vector<int> &grp, const int *gcol, std::vector<int> &color) {
   const int64_t ne = grp[nv];
   // A structurally symmetric graph with sorted rows (finite-element patterns) is its own transpose: checked in parallel
   // (one binary search per edge), which is cheaper than the serial transposition it saves (1200x400: 210 M edges)
@@ -54,7 +54,7 @@ int greedy_color(int nv, const std::vector<int> &grp, const UVec<int> &gcol, std
     for (int k = grp[i]; k < grp[i + 1] && ok; ++k) {
       const int j = gcol[k];
       if (k > grp[i] && gcol[k - 1] >= j) { ok = false; break; }   // rows must be sorted for the searches
-      ok = std::binary_search(gcol.begin() + grp[j], gcol.begin() + grp[j + 1], i);
+      ok = std::binary_search(gcol + grp[j], gcol + grp[j + 1], i);
     }
     symmetric = symmetric && ok;
   }
@@ -98,7 +98,7 @@ int greedy_color(int nv, const std::vector<int> &grp, const UVec<int> &gcol, std
 // and so does the natural ordering the ILU quality comes from.  Without support points, or on meshes without such
 // lines, every group has one member and this is the plain greedy colouring.
 // Output: members of group q are grp_items[grp_ptr[q] .. grp_ptr[q+1]) in +x order; groups ordered by first member.
-static void line_groups(int ni, const std::vector<int> &irp, const UVec<int> &icol, const double *xy, int xy_stride,
+static void line_groups(int ni, const std::vector<int> &irp, const int *icol, const double *xy, int xy_stride,
                         const int *shard_of_item, int g, std::vector<int> &grp_ptr, std::vector<int> &grp_items) {
   grp_ptr.clear();
   grp_items.clear();
@@ -209,23 +209,47 @@ void TriOrdering::build(int n, const int *rp, const int *cl, int ordering, const
   }
   auto keep = [&](int i, int cc) { return cc < n && (!sharded || shard[cc] == shard[i]); };
 
-  // restricted pattern R (local square block, cross-shard couplings dropped) and where each entry sits in A
-  rrp.assign(n + 1, 0);
-#pragma omp parallel for schedule(static)
-  for (int i = 0; i < n; ++i) {
-    int cnt = 0;
-    for (int k = rp[i]; k < rp[i + 1]; ++k) cnt += keep(i, cl[k]) ? 1 : 0;
-    rrp[i + 1] = cnt;
+  // restricted pattern R (local square block, cross-shard couplings dropped) and where each entry sits in A.  One rank
+  // without sub-domains and without ghost columns drops nothing: R is the block's own pattern and is not copied (3.4 GB of
+  // freshly mapped memory for F at 1200x400).
+  identity = !sharded;
+  if (identity) {
+    bool all_local = true;
+#pragma omp parallel for schedule(static) reduction(&& : all_local)
+    for (int i = 0; i < n; ++i) {
+      bool ok = true;
+      for (int k = rp[i]; k < rp[i + 1]; ++k) ok = ok && cl[k] < n;
+      all_local = all_local && ok;
+    }
+    identity = all_local;
   }
-  for (int i = 0; i < n; ++i) rrp[i + 1] += rrp[i];
-  nnz = rrp[n];
-  rcol.resize((size_t)nnz);
-  rpos.resize((size_t)nnz);
+  if (identity) {
+    rrp.assign(rp, rp + n + 1);
+    nnz = rrp[n];
+    UVec<int>().swap(rcol);
+    UVec<int>().swap(rpos);
+    rc = cl;
+    rpo = nullptr;
+  } else {
+    rrp.assign(n + 1, 0);
 #pragma omp parallel for schedule(static)
-  for (int i = 0; i < n; ++i) {
-    int w = rrp[i];
-    for (int k = rp[i]; k < rp[i + 1]; ++k)
-      if (keep(i, cl[k])) { rcol[w] = cl[k]; rpos[w] = k; ++w; }
+    for (int i = 0; i < n; ++i) {
+      int cnt = 0;
+      for (int k = rp[i]; k < rp[i + 1]; ++k) cnt += keep(i, cl[k]) ? 1 : 0;
+      rrp[i + 1] = cnt;
+    }
+    for (int i = 0; i < n; ++i) rrp[i + 1] += rrp[i];
+    nnz = rrp[n];
+    rcol.resize((size_t)nnz);
+    rpos.resize((size_t)nnz);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+      int w = rrp[i];
+      for (int k = rp[i]; k < rp[i + 1]; ++k)
+        if (keep(i, cl[k])) { rcol[w] = cl[k]; rpos[w] = k; ++w; }
+    }
+    rc = rcol.data();
+    rpo = rpos.data();
   }
 
   tick("restricted pattern");
@@ -242,8 +266,8 @@ void TriOrdering::build(int n, const int *rp, const int *cl, int ordering, const
       const int a0 = rrp[2 * r], a1 = rrp[2 * r + 1], len = a1 - a0;
       bool good = (rrp[2 * r + 2] - a1 == len) && (len % 2 == 0);
       for (int k = 0; good && k < len; k += 2) {
-        const int cc = rcol[a0 + k];
-        good = (cc % 2 == 0) && rcol[a0 + k + 1] == cc + 1 && rcol[a1 + k] == cc && rcol[a1 + k + 1] == cc + 1;
+        const int cc = rc[a0 + k];
+        good = (cc % 2 == 0) && rc[a0 + k + 1] == cc + 1 && rc[a1 + k] == cc && rc[a1 + k + 1] == cc + 1;
       }
       ok = ok && good;
     }
@@ -259,17 +283,16 @@ void TriOrdering::build(int n, const int *rp, const int *cl, int ordering, const
     const int ni = block2 ? n / 2 : n;
     std::vector<int> irp;
     UVec<int> icol_own;
-    const UVec<int> *icolp = &rcol;
+    const int *icol = rc;
     if (block2) {
       irp.assign(ni + 1, 0);
       for (int r = 0; r < ni; ++r) irp[r + 1] = irp[r] + (rrp[2 * r + 1] - rrp[2 * r]) / 2;
       icol_own.resize((size_t)irp[ni]);
 #pragma omp parallel for schedule(static)
       for (int r = 0; r < ni; ++r)
-        for (int k = 0; k < irp[r + 1] - irp[r]; ++k) icol_own[(size_t)irp[r] + k] = rcol[rrp[2 * r] + 2 * k] / 2;
-      icolp = &icol_own;
+        for (int k = 0; k < irp[r + 1] - irp[r]; ++k) icol_own[(size_t)irp[r] + k] = rc[rrp[2 * r] + 2 * k] / 2;
+      icol = icol_own.data();
     } else irp.assign(rrp.begin(), rrp.end());
-    const UVec<int> &icol = *icolp;
     std::vector<int> ishard;
     if (sharded) {
       ishard.resize(ni);
@@ -308,7 +331,7 @@ void TriOrdering::build(int n, const int *rp, const int *cl, int ordering, const
 #pragma omp parallel for schedule(static)
       for (int q = 0; q < ng; ++q) std::copy(qrows[q].begin(), qrows[q].end(), qcol.begin() + qrp[q]);
       std::vector<std::vector<int>>().swap(qrows);
-      n_colors = greedy_color(ng, qrp, qcol, gcolor);
+      n_colors = greedy_color(ng, qrp, qcol.data(), gcolor);
     }
     tick("greedy colouring (+ symmetry check)");
     // perm: colours ascending; inside a colour the groups in their order, members in +x order; a node's two rows adjacent
@@ -370,7 +393,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   grouped = gmax > 1;
   perm = O.perm;
   const std::vector<int> &rrp = O.rrp, &pcolor = O.pcolor;
-  const UVec<int> &rcol = O.rcol, &rpos = O.rpos;
+  const int *const rcol = O.rc, *const rpos = O.rpo;   // (rpos == nullptr: entry k of the restricted pattern is entry k of A)
   const std::vector<unsigned char> &cpos = O.cpos, &clen = O.clen;
   const bool block2 = O.block2;
 
@@ -380,14 +403,41 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     iperm.resize(n);
     for (int i = 0; i < n; ++i) iperm[perm[i]] = i;
   }
-  std::vector<int> prp(n + 1, 0), pdiag(n, -1);
-  UVec<int> pcol((size_t)nnz), psrc((size_t)nnz);   // (not zeroed: filled in the parallel loop below)
+  std::vector<int> prp(n + 1, 0), pdiag;
+  UVec<int> pcol, psrc;
+  int maxw = 0;
   for (int i = 0; i < n; ++i) {
     const int r = perm.empty() ? i : perm[i];
     prp[i + 1] = prp[i] + (rrp[r + 1] - rrp[r]);
+    maxw = std::max(maxw, rrp[r + 1] - rrp[r]);
   }
-  int maxw = 0;
+  // Multicolour factors without line groups, nothing dropped from the block: the permuted pattern and the split halves
+  // are built ON THE DEVICE from the block's own pattern, which is there already (nsk_setup_kernels.hip) — the host
+  // builds no array of the factor's size.  NSK_HOST_ANALYSIS=1: the host path below (A/B, and what the tests compare with)
+  static const bool host_only = [] { const char *e = getenv("NSK_HOST_ANALYSIS"); return e && atoi(e) != 0; }();
+  const bool dev = !host_only && !host_analysis && !perm.empty() && gmax == 1 && O.identity && A.rowptr.p && A.col.p && (int64_t)A.nnz == (int64_t)nnz &&
+                   maxw <= 448 && n > 0;
+  hipStream_t s = ctx->stream;
   bool missing_diag = false;
+  if (dev) {
+    DBuf<int> d_iperm, d_err;
+    d_perm.upload(perm, s);
+    d_iperm.upload(iperm, s);
+    d_err.alloc(1);
+    NSK_HIP(hipMemsetAsync(d_err.p, 0, sizeof(int), s));
+    rowptr.upload(prp, s);
+    col.alloc((size_t)nnz);
+    srcpos.alloc((size_t)nnz);
+    diag.alloc((size_t)n);
+    setup_permute_rows(s, n, A.rowptr.p, A.col.p, d_perm.p, d_iperm.p, rowptr.p, col.p, srcpos.p, diag.p, std::max(1, maxw), d_err.p);
+    int herr = 0;
+    NSK_HIP(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    ctx->sync();
+    missing_diag = herr != 0;
+  } else {
+  pdiag.assign(n, -1);
+  pcol.resize((size_t)nnz);   // (not zeroed: filled in the parallel loop below)
+  psrc.resize((size_t)nnz);
 #pragma omp parallel
   {
     std::vector<std::pair<int, int>> buf;
@@ -398,7 +448,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       const int r = perm.empty() ? i : perm[i];
       buf.clear();
       for (int k = rrp[r]; k < rrp[r + 1]; ++k)
-        buf.emplace_back(perm.empty() ? rcol[k] : iperm[rcol[k]], rpos[k]);
+        buf.emplace_back(perm.empty() ? rcol[k] : iperm[rcol[k]], rpos ? rpos[k] : k);
       std::sort(buf.begin(), buf.end());
       int w = prp[i];
       for (auto &e : buf) {
@@ -415,6 +465,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       maxw = std::max(maxw, lmax);
       missing_diag = missing_diag || lmiss;
     }
+  }
   }
   if (missing_diag) throw Error(-31, "TriSolve::analyze: a row has no diagonal entry");
   max_row_nnz = maxw;
@@ -465,7 +516,6 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   const double mean_half = n > 0 ? 0.5 * (double)nnz / n : 0.0;
   lpr = mean_half <= 6 ? 4 : (mean_half <= 14 ? 8 : (mean_half <= 48 ? 16 : 32));
 
-  hipStream_t s = ctx->stream;
   tick("level schedule");
   block2_ready = false;
   stream_ready = false;
@@ -477,6 +527,16 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     // (blocks towards the other members of the node's own line group are not part of the streamed lists: the kernels
     //  apply them from `cpl` once the member before has been solved)
     auto own_group = [&](int r, int m) { return m >= r - (int)cpos[r] && m <= r + ((int)clen[r] - 1 - (int)cpos[r]); };
+    if (dev) {   // counts on the device, row pointers by a host prefix sum (the run plans below need them here anyway)
+      DBuf<int> cl_, cu_;
+      cl_.alloc((size_t)nn);
+      cu_.alloc((size_t)nn);
+      setup_blk_count(s, nn, rowptr.p, col.p, std::max(1, maxw / 2), cl_.p, cu_.p);
+      NSK_HIP(hipMemcpyAsync(lrp.data() + 1, cl_.p, sizeof(int) * (size_t)nn, hipMemcpyDeviceToHost, s));
+      NSK_HIP(hipMemcpyAsync(urp.data() + 1, cu_.p, sizeof(int) * (size_t)nn, hipMemcpyDeviceToHost, s));
+      ctx->sync();
+      for (int r = 0; r < nn; ++r) { lrp[r + 1] += lrp[r]; urp[r + 1] += urp[r]; }
+    } else
     for (int r = 0; r < nn; ++r) {
       int nl = 0, nu = 0;
       for (int k = prp[2 * r]; k < prp[2 * r + 1]; k += 2) {
@@ -489,12 +549,28 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     }
     nnzL = (int64_t)lrp[nn] * 4;
     nnzU = (int64_t)urp[nn] * 4;
-    UVec<int> lcol((size_t)lrp[nn]), lsrc((size_t)lrp[nn] * 4), ucol((size_t)urp[nn]), usrc((size_t)urp[nn] * 4);
-    std::vector<int> hpermn(nn), isrc((size_t)nn * 4);  // per node row: positions of l10, u01, d0, d1
+    UVec<int> lcol, lsrc, ucol, usrc;
+    std::vector<int> hpermn, isrc;  // per node row: caller-order node; positions of l10, u01, d0, d1
     // couplings inside a line group: per node row and half up to kTriGroupMax - 1 blocks (nearest member first), -1: none
     constexpr int CW = (kTriGroupMax - 1) * 4;
-    std::vector<int> lcs((size_t)nn * CW, -1), ucs((size_t)nn * CW, -1);
-    std::vector<unsigned char> hchain((size_t)nn);
+    std::vector<int> lcs, ucs;
+    std::vector<unsigned char> hchain;
+    if (dev) {
+      Lrp.upload(lrp, s);
+      Urp.upload(urp, s);
+      Lcol.alloc((size_t)lrp[nn]);
+      Lsrc.alloc((size_t)lrp[nn] * 4);
+      Ucol.alloc((size_t)urp[nn]);
+      Usrc.alloc((size_t)urp[nn] * 4);
+      permn.alloc((size_t)nn);
+      intra_src.alloc((size_t)nn * 4);
+      setup_blk_fill(s, nn, rowptr.p, col.p, d_perm.p, x_layout, std::max(1, maxw / 2), Lrp.p, Urp.p, Lcol.p, Lsrc.p, Ucol.p, Usrc.p,
+                     intra_src.p, permn.p);
+    } else {
+    lcol.resize((size_t)lrp[nn]); lsrc.resize((size_t)lrp[nn] * 4); ucol.resize((size_t)urp[nn]); usrc.resize((size_t)urp[nn] * 4);
+    hpermn.resize(nn); isrc.resize((size_t)nn * 4);
+    lcs.assign((size_t)nn * CW, -1); ucs.assign((size_t)nn * CW, -1);
+    hchain.resize((size_t)nn);
     for (int r = 0; r < nn; ++r) hchain[r] = (unsigned char)(cpos[r] | (clen[r] << 4));
 #pragma omp parallel
     {
@@ -541,6 +617,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
         }
       }
     }
+    }
     // node-colour boundaries in node rows
     std::vector<int> ncuts, cstart(n_colors + 1, nn);
     for (int r = nn - 1; r >= 0; --r) cstart[pcolor[2 * r]] = r;
@@ -571,10 +648,14 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       const std::vector<int4> lsf = sf_dispatch_order(ld, LB, true), usf = sf_dispatch_order(ud, UB, false);
       n_Lsf = (int)lsf.size();
       n_Usf = (int)usf.size();
-      Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Ldesc.upload(ld, s); Lsf.upload(lsf, s);
-      Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Udesc.upload(ud, s); Usf.upload(usf, s);
-      permn.upload(hpermn, s);
-      intra_src.upload(isrc, s);
+      if (!dev) {
+        Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s);
+        Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s);
+        permn.upload(hpermn, s);
+        intra_src.upload(isrc, s);
+      }
+      Ldesc.upload(ld, s); Lsf.upload(lsf, s);
+      Udesc.upload(ud, s); Usf.upload(usf, s);
       Lval.alloc((size_t)nnzL);
       Uval.alloc((size_t)nnzU);
       intra.alloc((size_t)nn * 4);
@@ -593,8 +674,17 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
     // (entries towards the other members of the row's own line group: applied from `cpl`, not streamed)
     auto own_group = [&](int r, int m) { return m >= r - (int)cpos[r] && m <= r + ((int)clen[r] - 1 - (int)cpos[r]); };
     constexpr int CW = kTriGroupMax - 1;
-    std::vector<int> lcs((size_t)n * CW, -1), ucs((size_t)n * CW, -1);
-    std::vector<unsigned char> hchain((size_t)n);
+    std::vector<int> lcs, ucs;
+    std::vector<unsigned char> hchain;
+    if (dev) {   // strict lower / upper counts from the diagonal positions the device found
+      pdiag.resize(n);
+      NSK_HIP(hipMemcpyAsync(pdiag.data(), diag.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+      ctx->sync();
+      for (int i = 0; i < n; ++i) { lrp[i + 1] = pdiag[i] - prp[i]; urp[i + 1] = prp[i + 1] - pdiag[i] - 1; }
+    } else {
+    lcs.assign((size_t)n * CW, -1);
+    ucs.assign((size_t)n * CW, -1);
+    hchain.resize((size_t)n);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) {
       hchain[i] = (unsigned char)(cpos[i] | (clen[i] << 4));
@@ -608,11 +698,25 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       lrp[i + 1] = nl;
       urp[i + 1] = nu;
     }
+    }
     for (int i = 0; i < n; ++i) { lrp[i + 1] += lrp[i]; urp[i + 1] += urp[i]; }
     nnzL = lrp[n];
     nnzU = urp[n];
-    UVec<int> lcol((size_t)nnzL), lsrc((size_t)nnzL), ucol((size_t)nnzU), usrc((size_t)nnzU);
+    UVec<int> lcol, lsrc, ucol, usrc;
     // column ids go back to the caller's numbering, sorted, so that a row's gathers are runs of neighbours
+    if (dev) {
+      // (8 spare entries behind the index arrays: see below)
+      Lrp.upload(lrp, s);
+      Urp.upload(urp, s);
+      Lcol.alloc((size_t)nnzL + 8);
+      Lsrc.alloc((size_t)nnzL);
+      Ucol.alloc((size_t)nnzU + 8);
+      Usrc.alloc((size_t)nnzU);
+      NSK_HIP(hipMemsetAsync(Lcol.p + nnzL, 0, 8 * sizeof(int), s));
+      NSK_HIP(hipMemsetAsync(Ucol.p + nnzU, 0, 8 * sizeof(int), s));
+      setup_csr_fill(s, n, rowptr.p, col.p, diag.p, d_perm.p, std::max(1, maxw), Lrp.p, Urp.p, Lcol.p, Lsrc.p, Ucol.p, Usrc.p);
+    } else {
+    lcol.resize((size_t)nnzL); lsrc.resize((size_t)nnzL); ucol.resize((size_t)nnzU); usrc.resize((size_t)nnzU);
 #pragma omp parallel
     {
       std::vector<std::pair<int, int>> buf;
@@ -631,6 +735,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
         w = urp[i];
         for (auto &e : buf) { ucol[w] = e.first; usrc[w] = e.second; ++w; }
       }
+    }
     }
     // colour boundaries (the rows are sorted by colour)
     std::vector<int> cfirst(n_colors + 1, n), cuts;
@@ -664,10 +769,14 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
       n_Usf = (int)usf.size();
       // (8 spare entries behind the index and value arrays: the wide loads of the single-launch kernels take a thread's 8
       //  consecutive entries at once and may read past a run's — the array's — last one)
-      lcol.resize(lcol.size() + 8, 0);
-      ucol.resize(ucol.size() + 8, 0);
-      Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s); Ldesc.upload(ld, s); Lsf.upload(lsf, s);
-      Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s); Udesc.upload(ud, s); Usf.upload(usf, s);
+      if (!dev) {
+        lcol.resize(lcol.size() + 8, 0);
+        ucol.resize(ucol.size() + 8, 0);
+        Lrp.upload(lrp, s); Lcol.upload(lcol, s); Lsrc.upload(lsrc, s);
+        Urp.upload(urp, s); Ucol.upload(ucol, s); Usrc.upload(usrc, s);
+      }
+      Ldesc.upload(ld, s); Lsf.upload(lsf, s);
+      Udesc.upload(ud, s); Usf.upload(usf, s);
       Lval.alloc((size_t)nnzL + 8);
       Uval.alloc((size_t)nnzU + 8);
       NSK_HIP(hipMemsetAsync(Lval.p + nnzL, 0, 8 * sizeof(double), s));
@@ -837,11 +946,13 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
                  build_ring(PU, PL, false, ringU);
   }
   if (ring_ready) tick("ring records");
-  rowptr.upload(prp, s);
-  col.upload(pcol, s);
-  srcpos.upload(psrc, s);
-  diag.upload(pdiag, s);
-  if (!perm.empty()) d_perm.upload(perm, s);
+  if (!dev) {
+    rowptr.upload(prp, s);
+    col.upload(pcol, s);
+    srcpos.upload(psrc, s);
+    diag.upload(pdiag, s);
+    if (!perm.empty()) d_perm.upload(perm, s);
+  }
   lvlL_ptr.upload(hLp, s);
   lvlL_rows.upload(hLr, s);
   lvlU_ptr.upload(hUp, s);

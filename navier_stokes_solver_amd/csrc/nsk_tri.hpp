@@ -21,7 +21,7 @@ enum { ORDER_NATURAL = 0, ORDER_MULTICOLOR = 1 };
 
 // greedy distance-1 colouring of the graph of G + G^T (CSR grp/gcol, nv vertices, visited in natural order);
 // returns the number of colours
-int greedy_color(int nv, const std::vector<int> &grp, const UVec<int> &gcol, std::vector<int> &color);
+int greedy_color(int nv, const std::vector<int> &grp, const int *gcol, std::vector<int> &color);
 
 // Host-only analysis of one factor's ordering (no device work: also behind nsk_debug_tri_ordering for the CPU tests)
 struct TriOrdering {
@@ -29,7 +29,10 @@ struct TriOrdering {
   int n_colors = 0, gmax = 1;
   bool block2 = false, sharded = false;
   std::vector<int> shard, rrp;
-  UVec<int> rcol, rpos;                         // restricted pattern (ghost / cross-shard columns dropped), positions in A
+  UVec<int> rcol, rpos;                         // restricted pattern (ghost / cross-shard columns dropped), positions in A —
+                                                // materialised only when something IS dropped (identity == false)
+  bool identity = false;                        // nothing dropped: the restricted pattern is the block's own (rc = its columns)
+  const int *rc = nullptr, *rpo = nullptr;      // restricted columns; their positions in A (nullptr: position k is k)
   std::vector<int> perm, pcolor;                // perm[new] = old (empty: natural order); colour of every permuted row
   std::vector<unsigned char> cpos, clen;        // per permuted item (row, or node when block2): position / length in its group
   void build(int n, const int *rowptr, const int *col, int ordering, const std::vector<int> &sub_off, bool want_block2,
@@ -59,6 +62,7 @@ struct TriSolve {
   // split factors for the streamed kernels (multicolour ordering: one colour = one contiguous level)
   bool use_stream = true, stream_ready = false;
   double tiny_bytes = 4.0e6;  // factors below this size take the single-workgroup path (NSK_IOPT_TINY_BYTES)
+  bool host_analysis = false;  // NSK_IOPT_HOST_ANALYSIS: build the permuted pattern and the split halves on the host (A/B, tests)
   bool sync_free = false;  // one launch per half with in-kernel producer/consumer hand-off (see nsk_kernels.h)
   bool sf_armed = false;   // y holds the sentinel everywhere (left so by every completed single-launch apply)
   bool sf_fault = false;   // test hook: wrong workgroup order in the upper half of the single-launch solves
