@@ -250,6 +250,25 @@ int aggregate(Scratch &S, const Csr &A, const double *ad, int *&agg, double *&pw
 
 }  // namespace
 
+int64_t device_product_pattern(Ctx *ctx, const Csr &A, const Csr &B, DBuf<int> &rp, DBuf<int> &col) {
+  DBuf<char> no_arena;   // (work arrays come from individual allocations: this runs once per sparsity pattern)
+  size_t want = 0;
+  Scratch S(ctx, no_arena, want);
+  amgk::RowProduct P{};
+  P.A = amgk::Mat{A.n_rows, A.n_cols, A.rowptr.p, A.col.p, A.val.p};
+  P.B = amgk::Mat{B.n_rows, B.n_cols, B.rowptr.p, B.col.p, B.val.p};
+  rp.alloc((size_t)A.n_rows + 1);
+  const ProductPlan pl = product_rows(S, P, 0, 0, rp.p);
+  col.alloc((size_t)std::max<int64_t>(pl.nnz, 1));
+  DBuf<double> val;   // (the kernels form the values too; only the pattern is wanted)
+  val.alloc((size_t)std::max<int64_t>(pl.nnz, 1));
+  S.zero_counter(1);
+  amgk::product_fill(ctx->stream, P, 0, pl.tier, rp.p, col.p, val.p, S.counters.p + 1);
+  if (S.read_counter(1) != 0) throw Error(-84, "device_product_pattern: the fill found a row its count had not");
+  ctx->sync();
+  return pl.nnz;
+}
+
 // lambda = kEigBoost x ||(D^-1 A)^k x0|| / ||(D^-1 A)^(k-1) x0|| after kEigIts steps, x0(i) = start_entry(i), on the device
 double Amg::estimate_lambda_device(AmgLevel &L) {
   const int n = L.n;

@@ -67,4 +67,9 @@ struct Amg {
   void mv(Csr &A, const double *x, double *y, int mode = 0, const double *z = nullptr);
 };
 
+// Structural pattern of C = A B on the device, rows sorted by column (the row-product kernels of the AMG set-up: hash sets
+// in LDS, at most 512 distinct columns per row, Error -81 beyond).  A and B without ghost columns.  rp: n_rows + 1 row
+// pointers, col: the columns; returns the number of entries.  Used for aSIMPLE's Schur pattern B~ [D^-1] B~^T (round 4).
+int64_t device_product_pattern(Ctx *ctx, const Csr &A, const Csr &B, DBuf<int> &rp, DBuf<int> &col);
+
 }  // namespace nsk

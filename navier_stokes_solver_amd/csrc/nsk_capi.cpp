@@ -368,6 +368,36 @@ void H::schur_symbolic() {
   if (!Bt.present) throw Error(-41, "aSIMPLE needs block (0,1)");
   if (sp[0].ng > 0 && !Btg.present) throw Error(-42, "aSIMPLE on several ranks needs NSK_BLK_BT_GHOST");
   const int np = B.n_rows, ncols = sp[1].n + sp[1].ng;
+  // One rank (no ghost columns): the structural product on the device, with the row-product kernels of the AMG set-up
+  // (hash sets in LDS, rows sorted) — 0.73 s of host work at 1200x400 otherwise, the longest item of the first set-up
+  // once the factors' analysis had moved to the device.  NSK_IOPT_HOST_ANALYSIS / NSK_HOST_ANALYSIS=1: the host loop.
+  static const bool host_only = [] { const char *e = getenv("NSK_HOST_ANALYSIS"); return e && atoi(e) != 0; }();
+  if (!host_only && !tS.host_analysis && sp[0].ng == 0 && sp[1].ng == 0 && B.n_cols == Bt.n_rows && np > 0) {
+    DBuf<int> rp_d, col_d;
+    const int64_t nnz_s = device_product_pattern(&ctx, B, Bt, rp_d, col_d);
+    S.n_rows = np;
+    S.n_cols = ncols;
+    S.n_own_cols = sp[1].n;
+    S.nnz = nnz_s;
+    S.h_rowptr.resize((size_t)np + 1);
+    S.h_col.resize((size_t)nnz_s);
+    NSK_HIP(hipMemcpyAsync(S.h_rowptr.data(), rp_d.p, sizeof(int) * ((size_t)np + 1), hipMemcpyDeviceToHost, s()));
+    NSK_HIP(hipMemcpyAsync(S.h_col.data(), col_d.p, sizeof(int) * (size_t)nnz_s, hipMemcpyDeviceToHost, s()));
+    ctx.sync();
+    s_max_row = 0;
+    for (int i = 0; i < np; ++i) s_max_row = std::max(s_max_row, S.h_rowptr[i + 1] - S.h_rowptr[i]);
+    if (s_max_row > 448) throw Error(-43, "Schur row too long for the LDS-staged SpGEMM kernel");
+    S.rowptr = std::move(rp_d);
+    S.col = std::move(col_d);
+    S.col.n = (size_t)nnz_s;
+    S.val.alloc((size_t)S.nnz);
+    S.lpr = pick_lpr(S.nnz, S.n_rows);
+    S.present = true;
+    S.build_stream_plan(s());
+    ctx.sync();
+    s_symbolic = true;
+    return;
+  }
   std::vector<int> rp(np + 1, 0);
   std::vector<std::vector<int>> rows(np);
 #pragma omp parallel
