@@ -148,6 +148,7 @@ def run_gmsh(cfg, unsteady: bool) -> int:
     if nranks <= 1 or unsteady:
         ls = S.LinearSolver()
         ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
+        _env_options(ls, S)
 
     def report(name, nu, inlet_u):
         u, p = backend.solution()
@@ -219,6 +220,16 @@ def run_gmsh(cfg, unsteady: bool) -> int:
     return 0
 
 
+def _env_options(ls, S):
+    """Opt-in switches of the drivers.  NSK_SCHUR_SIGN=-1: aSIMPLE with the Schur approximation negated — a labelled
+    deviation from the reference (include/nsk.h); unset: the reference's S = B~ D^-1 B~^T."""
+    v = os.environ.get("NSK_SCHUR_SIGN")
+    if v is not None:
+        ls.set_option(S.OPT_SCHUR_SIGN, float(v))
+        if float(v) < 0 and ls.rank == 0:
+            print("[nsk] NSK_SCHUR_SIGN=-1: aSIMPLE's Schur approximation negated (deviation from the reference)")
+
+
 class _ThreadGroup:
     """Control plane of `NSK_RANKS=N`: the ranks are threads of this process."""
 
@@ -274,6 +285,7 @@ def _rank_main(cfg, unsteady, r, nranks, grp, make_handle, say):
     ls = make_handle()
     try:
         ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
+        _env_options(ls, S)
         backend = N.DeviceBackend(ls, first, cfg["solver"], cfg["prec"], cfg["tol"],
                                   max_iter=100000 if unsteady else 20000, inv_dt=1.0 / cfg["dt"] if unsteady else 0.0,
                                   plan=plan)
@@ -416,6 +428,7 @@ def run(cfg, unsteady: bool) -> int:
         from . import newton as N
         ls = S.LinearSolver()
         ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
+        _env_options(ls, S)
         first_system = P.generate(nx, ny, nu=0.1, mode=0, state=0, inlet_bc=1, U=0.1)   # first level: nu = 1/10
         backend = N.DeviceBackend(ls, first_system, cfg["solver"], cfg["prec"], cfg["tol"])
         t0 = time.time()
@@ -434,6 +447,7 @@ def run(cfg, unsteady: bool) -> int:
     from . import newton as N
     ls = S.LinearSolver()
     ls.set_option(S.OPT_TRI_ORDERING, S.ORDER_MULTICOLOR)
+    _env_options(ls, S)
     first_system = P.generate(nx, ny, nu=1.0, mode=0, state=0, inlet_bc=1, U=0.3)        # first level: nu = 1/1
     backend = N.DeviceBackend(ls, first_system, cfg["solver"], cfg["prec"], cfg["tol"], max_iter=100000,
                               inv_dt=1.0 / cfg["dt"])

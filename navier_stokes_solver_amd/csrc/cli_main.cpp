@@ -307,6 +307,12 @@ int main(int argc, char *argv[]) {
       // factorises, O(nx + ny) dependent levels; default 1: the library's multicolour ordering
       if (const char *e = std::getenv("NSK_TRI_ORDERING")) check(h, nsk_set_option(h, NSK_OPT_TRI_ORDERING, std::atof(e)), "nsk_set_option");
       if (const char *e = std::getenv("NSK_MASS_ORDERING")) check(h, nsk_set_option(h, NSK_OPT_MASS_ORDERING, std::atof(e)), "nsk_set_option");
+      // NSK_SCHUR_SIGN=-1: aSIMPLE with the Schur approximation negated — a LABELLED DEVIATION from the reference (nsk.h,
+      // DESIGN.md 5e.2); unset / +1: the reference's S = B~ D^-1 B~^T
+      if (const char *e = std::getenv("NSK_SCHUR_SIGN")) {
+        check(h, nsk_set_option(h, NSK_OPT_SCHUR_SIGN, std::atof(e)), "nsk_set_option");
+        if (std::atof(e) < 0) std::printf("[nsk] NSK_SCHUR_SIGN=-1: aSIMPLE's Schur approximation negated (deviation from the reference)\n");
+      }
       const int blks[4] = {NSP_BLK_F, NSP_BLK_BT, NSP_BLK_B, NSP_BLK_MP};
       for (int b : blks)
         check(h, nsk_set_block_csr(h, b, (int)nsp_block_rows(mesh, b), (int)nsp_block_cols(mesh, b),

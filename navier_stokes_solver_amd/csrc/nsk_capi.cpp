@@ -372,9 +372,18 @@ void H::schur_symbolic() {
   // (hash sets in LDS, rows sorted) — 0.73 s of host work at 1200x400 otherwise, the longest item of the first set-up
   // once the factors' analysis had moved to the device.  NSK_IOPT_HOST_ANALYSIS / NSK_HOST_ANALYSIS=1: the host loop.
   static const bool host_only = [] { const char *e = getenv("NSK_HOST_ANALYSIS"); return e && atoi(e) != 0; }();
-  if (!host_only && !tS.host_analysis && sp[0].ng == 0 && sp[1].ng == 0 && B.n_cols == Bt.n_rows && np > 0) {
-    DBuf<int> rp_d, col_d;
-    const int64_t nnz_s = device_product_pattern(&ctx, B, Bt, rp_d, col_d);
+  bool on_device = !host_only && !tS.host_analysis && sp[0].ng == 0 && sp[1].ng == 0 && B.n_cols == Bt.n_rows && np > 0;
+  DBuf<int> rp_d, col_d;
+  int64_t nnz_s = 0;
+  if (on_device) {
+    try {
+      nnz_s = device_product_pattern(&ctx, B, Bt, rp_d, col_d);
+    } catch (const Error &e) {   // (a row with more than 512 distinct columns, say: the host loop below has no such limit)
+      if (verbose()) fprintf(stderr, "[nsk] Schur pattern on the device: %s — host loop instead\n", e.what());
+      on_device = false;
+    }
+  }
+  if (on_device) {
     S.n_rows = np;
     S.n_cols = ncols;
     S.n_own_cols = sp[1].n;
