@@ -401,7 +401,10 @@ def main():
                  20: (f"tri_blk_kernel: ILU(0)/SGS apply on F ({lu}+{lu} node-colour level launches "
                       "of one apply)" if args.sync_free != 2 else
                       "tri_blk_sf_kernel: ILU(0)/SGS apply on F (one launch per half, in-kernel hand-off)"),
-                 21: ("tri_stream_sf_kernel: ILU(0)/SGS apply on the pressure block (one launch per half, in-kernel hand-off)"
+                 21: ("tri_ring_kernel: natural-order ILU(0)/SGS apply on the pressure mass matrix (gather + one one-workgroup launch "
+                      "per half through an LDS ring; what bounds it is the chain of dependent levels on ONE CU, not HBM)"
+                      if st.get("ring_applies", 0) > 0 else
+                      "tri_stream_sf_kernel: ILU(0)/SGS apply on the pressure block (one launch per half, in-kernel hand-off)"
                       if args.sync_free >= 1 else
                       f"tri_stream_kernel: ILU(0)/SGS apply on the pressure block ({lp}+{lp} level "
                       "launches of one apply)")}

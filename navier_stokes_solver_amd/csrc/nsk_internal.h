@@ -19,6 +19,9 @@ enum {
   NSK_IOPT_HOST_ANALYSIS = 108, // 1: the symbolic set-up of the multicolour triangular factors (permuted pattern, split halves)
                                 // on the host as in rounds 1-3; 0 (default): on the device (nsk_setup_kernels.hip) wherever
                                 // it applies — no line groups, no sub-domains, no ghost columns.  Same arrays either way
+  NSK_IOPT_TIMEOP_BETWEEN = 109, // nsk_time_op: a block id (e.g. NSK_BLK_F) whose SpMV runs BETWEEN two repetitions, outside
+                                // the timed brackets (one pair of events per repetition) — the operation as a solver sees
+                                // it, with the caches and clocks another kernel leaves behind; -1 (default): back to back
   NSK_IOPT_FUSED_MGS = 106      // 1 (default): the modified Gram-Schmidt chain of an Arnoldi step in ONE launch when the
                                 // vector fits the registers of the co-resident grid (single rank); 0: one launch per link
 };

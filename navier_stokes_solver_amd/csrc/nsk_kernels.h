@@ -252,6 +252,12 @@ struct RingHalf {
 void tri_ring(hipStream_t s, const RingHalf &R, int lower, int kind, const double *own, double *dst);
 // the double at dst + stride i = idx[i] >= 0 ? x[idx[i]] : 0 (the value part of 12- / 16-byte records)
 void ring_fill_values(hipStream_t s, long n, const int *idx, const double *x, char *dst, int stride);
+// Reads one word of every 128-byte line of up to six byte ranges with the whole chip (nothing is kept: a word is written
+// to *sink only if the xor of everything read equals a constant).  The ring solve is ONE workgroup: from cold HBM a CU's
+// few dozen outstanding line fetches bound it (~10 bytes per cycle), from the memory-side cache the chain of levels does
+// — this pass, tens of microseconds, puts the records there first.
+struct TouchRanges { const char *p[6]; size_t bytes[6]; };
+void mem_touch(hipStream_t s, const TouchRanges &R, unsigned *sink);
 
 // ILU(0) numeric factorisation of one level, in place (one wavefront per row, row staged in LDS)
 void ilu0_factor_level(hipStream_t s, int n_level_rows, const int *rows, const int *rowptr, const int *diag,

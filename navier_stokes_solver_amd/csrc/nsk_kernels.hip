@@ -1214,6 +1214,17 @@ __global__ __launch_bounds__(64 * kRingWaves * G) void tri_ring_kernel(RingHalf 
   }
 }
 
+__global__ __launch_bounds__(BLK) void mem_touch_kernel(TouchRanges R, unsigned *sink) {
+  unsigned acc = 0u;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const size_t lines = (R.bytes[k] + 127) / 128;   // (the ranges are device allocations: a line's first word is inside)
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < lines; i += (size_t)gridDim.x * BLK)
+      acc ^= *reinterpret_cast<const unsigned *>(R.p[k] + 128 * i);
+  }
+  if (acc == 0x9E3779B9u && sink) *sink = acc;
+}
+
 __global__ __launch_bounds__(BLK) void ring_fill_values_kernel(long n, const int *__restrict__ idx, const double *__restrict__ x,
                                                                char *__restrict__ dst, int stride) {
   for (long i = (long)blockIdx.x * BLK + threadIdx.x; i < n; i += (long)gridDim.x * BLK) {
@@ -1937,6 +1948,13 @@ void tri_ring(hipStream_t s, const RingHalf &R0, int lower, int kind, const doub
     case 13: launch_ring<1, 3, false>(s, R, lower, kind, own, dst); break;
     default: launch_ring<2, 2, false>(s, R, lower, kind, own, dst); break;
   }
+}
+void mem_touch(hipStream_t s, const TouchRanges &R, unsigned *sink) {
+  size_t lines = 0;
+  for (int k = 0; k < 6; ++k) lines = std::max(lines, (R.bytes[k] + 127) / 128);
+  if (!lines) return;
+  const size_t b = std::min<size_t>((lines + BLK - 1) / BLK, 2048);
+  hipLaunchKernelGGL(mem_touch_kernel, dim3((unsigned)b), dim3(BLK), 0, s, R, sink);
 }
 void ring_fill_values(hipStream_t s, long n, const int *idx, const double *x, char *dst, int stride) {
   if (n <= 0) return;

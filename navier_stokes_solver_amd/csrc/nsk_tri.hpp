@@ -105,6 +105,7 @@ struct TriSolve {
     RingHalf view() const { return RingHalf{n_pass, epoch, hdr.p, ent.p, rowrec.p, rearm.p, nullptr}; }
   } ringL, ringU;
   bool ring_ready = false;
+  DBuf<unsigned> touch_sink;   // (mem_touch's never-written word)
 
   // A: host pattern of the local block (columns >= A.n_rows, i.e. ghosts, are dropped);
   // sub_off: optional n_sub+1 offsets of emulated MPI ranks inside this GPU (block Jacobi)

@@ -35,6 +35,7 @@ OPT_MASS_ORDERING = 13
 OPT_BLAS1_PAIRS = 15  # 16-byte loads in the reductions: 1 / 0 / -1 (default: stationary on, unsteady off), see include/nsk.h
 OPT_SCHUR_SIGN = 14   # +1 the reference's S (default); -1: labelled deviation, see include/nsk.h
 IOPT_FUSED_MGS, IOPT_OVERLAP_HALO = 106, 107
+IOPT_TIMEOP_BETWEEN = 109  # time_op: SpMV of this block between two repetitions, outside the timed brackets (-1: back to back)
 IOPT_HOST_ANALYSIS = 108   # 1: symbolic set-up of the multicolour factors on the host (A/B, tests); default: on the device
 ORDER_NATURAL, ORDER_MULTICOLOR = 0, 1
 

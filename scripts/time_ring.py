@@ -21,6 +21,13 @@ x_ring = ls.tri_apply(S.TRI_PRESSURE, b)
 assert ls.stats()["ring_applies"] == before + 1, "the ring solve did not run"
 ms, by = ls.time_op(21, reps)
 print(f"ring  : {ms:8.4f} ms per application ({by / 1e6:.1f} MB algorithmic, {by / 1e6 / ms:.1f} GB/s)", flush=True)
+# the same application as a solver sees it: another kernel's SpMV between two repetitions (outside the timed brackets) —
+# F streams 1.3 GB through every cache, Mp 30 MB
+for blk, name in ((S.BLK_F, "F"), (S.BLK_MP, "Mp")):
+    ls.set_option(S.IOPT_TIMEOP_BETWEEN, blk)
+    ms_c, _ = ls.time_op(21, reps)
+    print(f"ring  : {ms_c:8.4f} ms per application with an SpMV of {name} between two applications", flush=True)
+ls.set_option(S.IOPT_TIMEOP_BETWEEN, -1)
 ls.set_option(S.OPT_STREAM_KERNELS, 0)
 x_walk = ls.tri_apply(S.TRI_PRESSURE, b)
 ms_w, _ = ls.time_op(21, max(2, reps // 4))
