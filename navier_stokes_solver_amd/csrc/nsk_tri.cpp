@@ -12,19 +12,24 @@ namespace nsk {
 
 namespace {
 constexpr int kSerialThreshold = 1024;  // levels smaller than this are fused into single-workgroup runs
+// ... of the solves.  The numeric factorisation has its own limit: a row there is a chain of a dozen dependent trips to
+// L2 (one per entry of its lower part), ~12 us, and a workgroup's 16 wavefronts take the rows of a level in turns — the
+// 4 001 levels of ~120 rows of the natural-order pressure-mass factor at 600x200 took 474 ms in ONE workgroup, 43 % of
+// the GPU time of config 5's bench run.  One launch per level spreads a level's rows over the chip.
+constexpr int kFactorSerialThreshold = 48;
 
-void build_schedule(const std::vector<int> &lvl_ptr, std::vector<TriSolve::Step> &sched) {
+void build_schedule(const std::vector<int> &lvl_ptr, std::vector<TriSolve::Step> &sched, int threshold = kSerialThreshold) {
   sched.clear();
   const int nl = (int)lvl_ptr.size() - 1;
   int l = 0;
   while (l < nl) {
     const int sz = lvl_ptr[l + 1] - lvl_ptr[l];
-    if (sz >= kSerialThreshold) {
+    if (sz >= threshold) {
       sched.push_back(TriSolve::Step{0, l, l + 1, lvl_ptr[l], sz});
       ++l;
     } else {
       int e = l;
-      while (e < nl && lvl_ptr[e + 1] - lvl_ptr[e] < kSerialThreshold) ++e;
+      while (e < nl && lvl_ptr[e + 1] - lvl_ptr[e] < threshold) ++e;
       sched.push_back(TriSolve::Step{1, l, e, lvl_ptr[l], lvl_ptr[e] - lvl_ptr[l]});
       l = e;
     }
@@ -512,6 +517,7 @@ void TriSolve::analyze(Ctx *c, const Csr &A, int kind_, int ordering_, const std
   level_lists(levU, n_levels_U, hUp, hUr);
   build_schedule(hLp, schedL);
   build_schedule(hUp, schedU);
+  build_schedule(hLp, schedN, kFactorSerialThreshold);
 
   const double mean_half = n > 0 ? 0.5 * (double)nnz / n : 0.0;
   lpr = mean_half <= 6 ? 4 : (mean_half <= 14 ? 8 : (mean_half <= 48 ? 16 : 32));
@@ -976,7 +982,7 @@ void TriSolve::numeric(const double *a_val_dev) {
   hipStream_t s = ctx->stream;
   vec_gather(s, (int)nnz, srcpos.p, a_val_dev, val.p);
   if (kind == 0) {
-    for (const Step &st : schedL) {
+    for (const Step &st : schedN) {
       if (st.serial) ilu0_factor_serial(s, lvlL_ptr.p, lvlL_rows.p, st.l0, st.l1, rowptr.p, diag.p, col.p, val.p, max_row_nnz);
       else ilu0_factor_level(s, st.nrows, lvlL_rows.p + st.row_off, rowptr.p, diag.p, col.p, val.p, max_row_nnz);
     }

@@ -57,7 +57,7 @@ struct TriSolve {
     int l0, l1;  // level range
     int row_off, nrows;
   };
-  std::vector<Step> schedL, schedU;
+  std::vector<Step> schedL, schedU, schedN;   // (schedN: the numeric factorisation's walk of the lower levels)
 
   // split factors for the streamed kernels (multicolour ordering: one colour = one contiguous level)
   bool use_stream = true, stream_ready = false;
