@@ -233,9 +233,11 @@ void vec_gather_or_zero(hipStream_t s, long n, const int *idx, const double *x, 
 // count (12 per entry, 24 per row).
 constexpr int kRingGroups = 2, kRingWaves = 8, kRingThreads = 64 * kRingWaves * kRingGroups, kRingLpr = 2, kRingRegs = 8;
 constexpr int kRingRowsPerWave = 64 / kRingLpr, kRingRows = kRingWaves * kRingRowsPerWave;
-constexpr int kRingSlots = 8192;      // the ring: 64 KB of LDS (+ 16 bytes: the zero that padding reads, the give-up word)
+constexpr int kRingSlots = 16384;     // the ring: 128 KB of the CU's 160 KB of LDS (+ 16 bytes: the zero that padding reads, the
+                                      // give-up word) — two epochs + the longest dependency must fit: with 8 192 slots the
+                                      // 240-row levels of 1200x400 did not, and the solve fell back to the level walker
 constexpr int kRingDepth = 2;         // passes OF A GROUP whose records are in flight (registers)
-constexpr int kRingStep = 24;         // n_pass and epoch are multiples of this (any groups x depth the kernel is built for divides it)
+constexpr int kRingStep = 12;         // n_pass and epoch are multiples of this (any groups x depth the kernel is built for divides it)
 constexpr int kRingMaxEpoch = 48;     // passes between two workgroup barriers, at most (a multiple of kRingStep)
 constexpr int kRingMaxRows = 1 << 26; // (the header keeps a position in 26 bits)
 struct RingHalf {

@@ -1076,19 +1076,22 @@ void TriSolve::apply(const double *b, double *x) {
     return;
   }
   if (ring_ready && use_stream && !tiny) {   // the caller's order: one workgroup, passes through an LDS ring
-    // both halves' records into the memory-side cache with the whole chip first (NSK_RING_PREFETCH=0: off): in a solver
-    // gigabytes have streamed through it since the last application, and one CU fetching from HBM is what then bounds
-    // the solve (3.8 against 2.7 ms at 600x200)
+    // a half's records into the memory-side cache with the whole chip, right before its one workgroup starts
+    // (NSK_RING_PREFETCH=0: off): in a solver gigabytes have streamed through that cache since the last application,
+    // and one CU fetching from HBM is what then bounds the solve (3.8 against 2.7 ms at 600x200).  Half
+    // by half, so that factors of up to ~200 MB per half still find room in its 256 MB
     static const bool prefetch = [] { const char *e = getenv("NSK_RING_PREFETCH"); return !e || atoi(e) != 0; }();
-    if (prefetch) {
+    auto touch = [&](const Ring &Rg) {
+      if (!prefetch) return;
       if (!touch_sink.p) touch_sink.alloc(1);
-      const TouchRanges R{{ringL.ent.p, ringL.rowrec.p, (const char *)ringL.hdr.p, ringU.ent.p, ringU.rowrec.p, (const char *)ringU.hdr.p},
-                          {(size_t)ringL.n_ent * 12, (size_t)n * 16, (size_t)ringL.n_pass * kRingWaves * 16,
-                           (size_t)ringU.n_ent * 12, (size_t)n * 16, (size_t)ringU.n_pass * kRingWaves * 16}};
+      const TouchRanges R{{Rg.ent.p, Rg.rowrec.p, (const char *)Rg.hdr.p, nullptr, nullptr, nullptr},
+                          {(size_t)Rg.n_ent * 12, (size_t)n * 16, (size_t)Rg.n_pass * kRingWaves * 16, 0, 0, 0}};
       mem_touch(s, R, touch_sink.p);
-    }
+    };
     vec_gather(s, n, ringL.rowid.p, b, ringL.own.p);              // the right-hand side in the lower half's position order
+    touch(ringL);
     tri_ring(s, ringL.view(), 1, kind, ringL.own.p, ringU.own.p);   // (its result lands in the upper half's order)
+    touch(ringU);
     tri_ring(s, ringU.view(), 0, kind, ringU.own.p, x);
     ++ctx->st.ring_applies;
     ++ctx->st.tri_applies;

@@ -194,8 +194,9 @@ def test_line_group_sizes_in_the_single_launch_solves(group_u, group_p, subdomai
         ls.close()
 
 
-# (24 x 400: levels of 267 rows, more than one pass holds — and 49 k rows, six times round the ring)
-@pytest.mark.parametrize("mesh,subdomains", [((60, 20), 1), ((60, 20), 3), ((100, 70), 1), ((24, 400), 1)])
+# (24 x 400: levels of 267 rows, more than one pass holds — and 49 k rows, several times round the ring; 200 x 400: passes of
+#  ~240 rows as at 1200x400, where two epochs did not fit a ring of 8 192 slots and the walker took over unnoticed)
+@pytest.mark.parametrize("mesh,subdomains", [((60, 20), 1), ((60, 20), 3), ((100, 70), 1), ((24, 400), 1), ((200, 400), 1)])
 def test_natural_order_pressure_solves_through_the_lds_ring(mesh, subdomains):
     """The caller's order in the pressure-mass factor (default of the unsteady block-diagonal preconditioner; any factor
     under NSK_OPT_TRI_ORDERING = 0 with at most 16 entries per row and half): one workgroup walks passes of independent
